@@ -1,0 +1,238 @@
+/*
+ * contracts_engine.h — C-ABI of the MI355X-native batched multi-agent env engine.
+ *
+ * This is the drop-in boundary for the rollout hot path of
+ * Algorithmic-Alignment-Lab/contracts.  The reference is pure Python and has no FFI;
+ * the entry points below are what a ctypes binding on the reference side would load
+ * (INTEGRATION.md shows that stub).  Each entry cites the reference interface it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or
+ * a negative CE_E* code; no exceptions cross the boundary; no global state; one handle
+ * per GPU; a handle is NOT thread-safe (single stream-ordered caller), distinct handles
+ * are independent.  The library owns all device memory; pointers handed out by
+ * ce_get_buffers stay valid until ce_destroy and are DEVICE pointers (HBM).
+ *
+ * One handle = E independent env replicas of one family ("kind"), n agents each,
+ * stored struct-of-arrays in HBM (one array per field, each env's slice contiguous).
+ */
+#ifndef CONTRACTS_ENGINE_H
+#define CONTRACTS_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CE_ABI_VERSION 1
+
+/* error codes */
+#define CE_OK 0
+#define CE_EINVAL (-22)   /* bad argument / unsupported configuration           */
+#define CE_ENOMEM (-12)   /* device or host allocation failed                    */
+#define CE_ENODEV (-19)   /* no usable gfx950 device / HIP runtime error         */
+#define CE_EIO (-5)       /* a kernel reported a runtime fault (see last_error)  */
+#define CE_ERANGE (-34)   /* an action outside the action space was supplied     */
+
+/* env family: which reference class the replicas restate */
+enum ce_kind {
+  CE_KIND_CLEANUP = 0,   /* environments/cleanup_new.py:59  CleanupEnv(MapEnv)            */
+  CE_KIND_HARVEST = 1,   /* environments/harvest_new.py:48  HarvestEnv(MapEnv)            */
+  CE_KIND_SELFDRIVE = 2  /* environments/self_driving_car_accelerate.py:18                */
+};
+
+/* contract fused into the step epilogue (contract/contract_list.py) */
+enum ce_contract {
+  CE_CONTRACT_NONE = 0,               /* base env only (the "separate" baseline)          */
+  CE_CONTRACT_CLEANUP = 1,            /* CleanupContract.compute_transfer  :22-27         */
+  CE_CONTRACT_HARVEST_LOCAL = 2,      /* HarvestFeaturemodLocalContract    :45-54         */
+  CE_CONTRACT_SELFDRIVE_DISTPROP = 3  /* SelfdriveContractDistprop         :69-102        */
+};
+
+/* ce_config.flags */
+#define CE_FLAG_FIRING_ENABLED 0x1u   /* disable_firing=False: FIRE is in the action space
+                                         (cleanup_new.py:90-95, harvest_new.py:85-90)      */
+#define CE_FLAG_AUTO_RESET 0x2u       /* an env whose step returns done is reset inside the
+                                         same launch (RLlib calls reset() right after a done
+                                         step; same RNG order).  obs then holds the reset
+                                         observation; done/reward/info/final metrics keep the
+                                         terminal step's values                              */
+#define CE_FLAG_COLLECTIVE_REWARD 0x4u /* map_env.py:289-292                                */
+#define CE_FLAG_INEQUITY_AVERSE 0x8u   /* map_env.py:293-301 (alpha, beta)                  */
+#define CE_FLAG_COLLISION_ON 0x10u     /* self_driving_car_accelerate.py:195-215            */
+
+typedef struct ce_config {
+  uint32_t abi_version;    /* CE_ABI_VERSION                                               */
+  uint32_t kind;           /* enum ce_kind                                                 */
+  uint32_t num_envs;       /* E replicas on this handle                                    */
+  uint32_t num_agents;     /* n: 1..9 grid envs (agent colours '1'..'9', map_env.py:33-41),
+                              1..10 selfdrive (int(id[-1]) in contract_list.py:85)         */
+  uint32_t horizon;        /* episode length (MapEnv horizon kwarg, map_env.py:74); 0 = 1000 */
+  uint32_t contract;       /* enum ce_contract                                             */
+  uint32_t flags;          /* CE_FLAG_*                                                    */
+  int32_t device;          /* HIP device ordinal                                           */
+  uint64_t env_index_base; /* global index of env 0 of this handle (multi-GPU shard offset;
+                              only used by ce_reset's seed0+index convenience)             */
+  double contract_low;     /* Box low of the contract space (two_stage_train.py:39)        */
+  double contract_high;    /* Box high — pass the float32-rounded value the reference's Box
+                              holds, e.g. (double)0.2f (two_stage_train.py:40,164)         */
+  double null_prob;        /* two_stage_train.py:163 (default 0.0)                         */
+  double alpha, beta;      /* inequity aversion coefficients (map_env.py:71-72)            */
+  /* selfdrive constructor kwargs (self_driving_car_accelerate.py:19) */
+  double low_bound, high_bound, start_vel, start_vel_ambulance;
+} ce_config;
+
+/* Shapes, filled by ce_get_buffers.  Grid families: obs is the 15x15x3 egocentric
+ * uint8 crop (map_env.py:397-411) per agent; divide by 255 for the reference's float view
+ * (cleanup_new.py:258).  Selfdrive: obs_f64 is the 2n+5 vector (…:241-247) plus the two
+ * contract slots [theta, 0] appended by the wrapper (two_stage_train.py:113-117). */
+typedef struct ce_buffers {
+  uint32_t num_envs, num_agents;
+  uint32_t grid_h, grid_w;       /* 25x18 cleanup, 16x38 harvest, 0 selfdrive              */
+  uint32_t obs_bytes_per_agent;  /* 675 for grid families                                  */
+  uint32_t num_features;         /* 12+n cleanup (cleanup_new.py:243-251), 10+2n harvest
+                                    (harvest_new.py:215-222), 2n+7 selfdrive obs length    */
+  uint32_t num_int_metrics;      /* see CE_MI_* / CE_MIA_*                                  */
+  uint32_t num_f64_metrics;      /* see CE_MF_*                                            */
+
+  /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
+  uint8_t* grid;        /* [E][H*W]   cell codes CE_CELL_*                                  */
+  uint8_t* agents;      /* [E][n][4]  row, col, orientation (UP0 RIGHT1 DOWN2 LEFT3,
+                                      Agent.py:18-23), 0                                   */
+  uint8_t* spawn_perm;  /* [E][20]    persistent shuffled spawn list (map_env.py:821) as
+                                      indices into the static P-cell table                 */
+  uint8_t* waste_perm;  /* [E][119]   cleanup only: persistent shuffled waste list
+                                      (cleanup_new.py:339) as indices into the static table */
+  uint32_t* rng;        /* [E][RNG_WORDS] numpy legacy MT19937 key[624] + pos (+ Python
+                                      `random` MT for selfdrive, second 625-word block)    */
+  int32_t* timestep;    /* [E]        MapEnv.timesteps                                      */
+  double* theta;        /* [E]        contract parameter of the episode                     */
+  double* sd_state;     /* selfdrive: [E][CE_SD_STATE_DOUBLES(n)]                           */
+
+  /* ---- per-step outputs ---- */
+  uint8_t* obs;          /* [E][n][15][15][3] uint8                                         */
+  double* obs_f64;       /* selfdrive: [E][n][2n+7]                                         */
+  int32_t* base_reward;  /* [E][n]  MapEnv reward before the contract (ints, Agent.py:87)   */
+  double* reward;        /* [E][n]  reward after the contract transfer
+                                    (two_stage_train.py:69-90); == base when no contract    */
+  uint8_t* done;         /* [E]     dones['__all__']; selfdrive also [E][n+1] in done_agents */
+  uint8_t* done_agents;  /* selfdrive: [E][n] per-agent done                                */
+  uint8_t* info;         /* [E][n][2] grid: {eaten_apples, cleaned_squares|eaten_close_apples}
+                                      selfdrive: {just_passed, 0}                           */
+  int16_t* features;     /* [E][n][num_features] grid families: infos[k]['feature_obs'],
+                                      all entries are small integers                        */
+  /* ---- metrics (reference env.metrics, cleanup_new.py:186-188 / harvest_new.py:152-156) */
+  int64_t* int_metrics;  /* [E][num_int_metrics]  running episode                           */
+  double* f64_metrics;   /* [E][num_f64_metrics]  running episode                           */
+  int64_t* final_int_metrics; /* same layout, latched at the step that returned done        */
+  double* final_f64_metrics;
+  uint32_t* error_flags; /* [E] sticky per-env fault bits (CE_FAULT_*)                      */
+} ce_buffers;
+
+/* cell codes of `grid` (reference world_map chars) */
+#define CE_CELL_EMPTY 0 /* ' ' */
+#define CE_CELL_WALL 1  /* '@' */
+#define CE_CELL_APPLE 2 /* 'A' */
+#define CE_CELL_WASTE 3 /* 'H' */
+#define CE_CELL_RIVER 4 /* 'R' */
+#define CE_CELL_STREAM 5 /* 'S' */
+
+/* int_metrics layout: 4 globals then 4 per-agent blocks of n */
+#define CE_MI_TOTAL_APPLES_EATEN 0
+#define CE_MI_RAW_ENV_REWARDS 1
+#define CE_MI_DIRT_CLEANED 2           /* cleanup */
+#define CE_MI_LOW_DENSITY_APPLES 3     /* harvest 'low_density_apples_eaten' */
+#define CE_MI_GLOBALS 4
+#define CE_MIA_A 0  /* per agent: cleanup 'a{i}-waste_cleaned', harvest 'a{i}-apples_consumed' */
+#define CE_MIA_B 1  /* per agent: harvest 'a{i}-close_apples_consumed'                          */
+#define CE_MIA_SUM_R 2   /* per agent: sum_t r_i,t           (total_reward_dict)                */
+#define CE_MIA_SUM_TR 3  /* per agent: sum_t t*r_i,t                                           */
+#define CE_MI_COUNT(n) (CE_MI_GLOBALS + 4 * (n))
+#define CE_MI_AGENT(n, which, i) (CE_MI_GLOBALS + (which) * (n) + (i))
+
+/* f64_metrics layout */
+#define CE_MF_TRANSFERS 0              /* metrics['transfers'] two_stage_train.py:92 */
+#define CE_MF_EQUALITY 1               /* valid in final_* only (cleanup_new.py:422-434) */
+#define CE_MF_SUSTAINABILITY 2         /* (cleanup_new.py:436-445) */
+#define CE_MF_TRANSFER_EQUALITY 3      /* two_stage_train.py:97-99 */
+#define CE_MF_TRANSFER_SUSTAINABILITY 4
+#define CE_MF_GLOBALS 5
+#define CE_MFA_SUM_R 0   /* per agent: sum of transferred rewards  */
+#define CE_MFA_SUM_TR 1  /* per agent: sum of t * transferred reward */
+#define CE_MF_COUNT(n) (CE_MF_GLOBALS + 2 * (n))
+#define CE_MF_AGENT(n, which, i) (CE_MF_GLOBALS + (which) * (n) + (i))
+
+/* selfdrive state block: pos[n], vel[n], dist_to_front[n], done[n] (0/1), done_all,
+ * n_crossed, crossed[n] (agent indices in crossing order), transfers metric */
+#define CE_SD_STATE_DOUBLES(n) (5 * (n) + 3)
+
+#define CE_RNG_WORDS_GRID 625u       /* key[624] + pos                                      */
+#define CE_RNG_WORDS_SELFDRIVE 1250u /* numpy MT then Python `random` MT                    */
+
+#define CE_FAULT_BAD_ACTION 0x1u     /* action id outside the family's table (Agent.py:161,198)
+                                        — the reference raises KeyError                     */
+#define CE_FAULT_NO_SPAWN 0x2u       /* map_env.py:826 assertion                             */
+#define CE_FAULT_STEP_AFTER_DONE 0x4u /* selfdrive step after __all__ (…accelerate.py:154-167
+                                        raises AttributeError in the reference)              */
+
+typedef struct ce_engine* ce_handle;
+
+/* Library / device probe.  Never fails loudly: returns the ABI version. */
+int ce_abi_version(void);
+/* Number of gfx950 devices visible, or a negative CE_E* code. */
+int ce_device_count(void);
+
+/* Replaces: Cls(**config) in utils/env_creator_functions.py:12-36 +
+ * SeparateContractSubgameStage.__init__ (two_stage_train.py:152-157), for E replicas. */
+int ce_create(const ce_config* cfg, ce_handle* out);
+int ce_destroy(ce_handle h);
+
+/* Replaces: np.random.seed(s) (+ random.seed(s)) followed by CONSTRUCTING the env
+ * (MapEnv.__init__ -> setup_agents consumes RNG: map_env.py:131,816-832; CleanupEnv then
+ * duplicates the spawn list, cleanup_new.py:114-115).  seeds: host pointer [E] (or NULL:
+ * env b gets seed0 + env_index_base + b).  mask: host pointer [E] of 0/1 (NULL = all).
+ * replay_constructor=0 only re-seeds the generators (MapEnv.seed, map_env.py:344-345). */
+int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int replay_constructor);
+
+/* Replaces: SeparateContractSubgameStage.reset (two_stage_train.py:159-187) ->
+ * CleanupEnv/HarvestEnv.reset -> MapEnv.reset (map_env.py:306-342) /
+ * SelfAcceleratingCarEnv.reset (…accelerate.py:49-79).  mask as above (host pointer). */
+int ce_reset(ce_handle h, const uint8_t* mask, void* stream);
+
+/* Replaces: SeparateContractEnv.step (two_stage_train.py:62-121) -> CleanupEnv.step /
+ * HarvestEnv.step -> MapEnv.step (map_env.py:216-304) + contract.compute_transfer.
+ * actions: DEVICE pointer. grid families: uint8 [E][n] action ids (Agent.py:8-16,161,198).
+ * selfdrive: float [E][n] accelerations; active: DEVICE uint8 [E][n] (NULL = agents that are
+ * not done act, which is what RLlib sends).  Asynchronous on `stream` (hipStream_t). */
+int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream);
+
+/* Synthetic uniform i.i.d. actions for benchmarks, generated on device by a counter-based
+ * hash keyed (key, global env index, t, agent) — reproducible on host (ce_synth_action_host).
+ * out: DEVICE pointer, uint8 [T][E][n] (grid) or float [T][E][n] (selfdrive). */
+int ce_synth_actions(ce_handle h, uint64_t key, uint32_t t0, uint32_t T, void* out, void* stream);
+uint32_t ce_synth_action_host(uint64_t key, uint64_t env_index, uint32_t t, uint32_t agent, uint32_t num_actions);
+
+int ce_get_buffers(ce_handle h, ce_buffers* out);
+int ce_synchronize(ce_handle h, void* stream);
+
+/* Host copies (stream-synchronous helpers for tests / adapters without torch).
+ * field names: "grid","agents","spawn_perm","waste_perm","rng","timestep","theta","sd_state",
+ * "obs","obs_f64","base_reward","reward","done","done_agents","info","features",
+ * "int_metrics","f64_metrics","final_int_metrics","final_f64_metrics","error_flags".
+ * env_begin/env_count select a slice of the env axis; dst/src are host pointers. */
+int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
+int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);
+
+/* Timing of the last N ce_step launches measured with HIP events on the launch stream
+ * (bench.py roofline leg).  ce_timing_begin arms recording, ce_timing_end returns the mean
+ * step-kernel duration in milliseconds and the number of launches measured. */
+int ce_timing_begin(ce_handle h, void* stream);
+int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches);
+
+const char* ce_last_error(ce_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRACTS_ENGINE_H */

@@ -1,0 +1,144 @@
+"""Import harness for the upstream reference (runs ONLY in the build container).
+
+The reference at /root/reference is a Python/RLlib project; `gym`, `ray` and `cv2`
+are not installed here.  This module injects minimal stand-in modules (our own
+code, modelled on the gym-0.21 / ray-2.2 behaviours the hot path relies on, see
+SURVEY.md Appendix A) into `sys.modules`, puts /root/reference on `sys.path` and
+hands back the reference classes.  It is used by `make_golden.py` to produce the
+committed fixtures and by `tests/test_oracle_vs_reference.py` (skipped when
+/root/reference is absent, i.e. on the GPU box).
+
+Nothing from /root/reference is copied: the reference is imported where it lies.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = os.environ.get("CONTRACTS_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "environments"))
+
+
+# --------------------------------------------------------------------------- #
+# gym.spaces stand-ins (gym 0.21 semantics: Box default dtype float32, bounds
+# are broadcast to `shape` and cast to dtype).
+# --------------------------------------------------------------------------- #
+class _Space:
+    def __init__(self, shape=None, dtype=None):
+        self.shape = None if shape is None else tuple(shape)
+        self.dtype = None if dtype is None else np.dtype(dtype)
+
+
+class Box(_Space):
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        dtype = np.dtype(dtype)
+        if shape is None:
+            shape = np.asarray(low).shape
+        shape = tuple(shape)
+        self.low = np.broadcast_to(np.asarray(low), shape).astype(dtype)
+        self.high = np.broadcast_to(np.asarray(high), shape).astype(dtype)
+        super().__init__(shape, dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+class Discrete(_Space):
+    def __init__(self, n):
+        self.n = n
+        super().__init__((), np.int64)
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+
+class MultiDiscrete(_Space):
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        super().__init__(self.nvec.shape, np.int64)
+
+
+class Dict(_Space):
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+        super().__init__(None, None)
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+
+def _install_stubs():
+    if "gym" in sys.modules and getattr(sys.modules["gym"], "_contracts_amd_stub", False):
+        return
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    spaces = mod("gym.spaces", Box=Box, Discrete=Discrete, MultiDiscrete=MultiDiscrete, Dict=Dict)
+    gym = mod("gym", spaces=spaces, Env=object, _contracts_amd_stub=True)
+    gym.spaces = spaces
+
+    class MultiAgentEnv:  # ray.rllib.env.MultiAgentEnv: empty base is enough
+        pass
+
+    class DefaultCallbacks:
+        pass
+
+    class TaskSettableEnv:
+        pass
+
+    ray = mod("ray")
+    rllib = mod("ray.rllib")
+    env = mod("ray.rllib.env", MultiAgentEnv=MultiAgentEnv)
+    algos = mod("ray.rllib.algorithms")
+    cbs = mod("ray.rllib.algorithms.callbacks", DefaultCallbacks=DefaultCallbacks)
+    agents = mod("ray.rllib.agents", ppo=None)
+    utils = mod("ray.rllib.utils")
+    fw = mod(
+        "ray.rllib.utils.framework",
+        try_import_tf=lambda: (None, None, None),
+        try_import_torch=lambda: (None, None),
+    )
+    apis = mod("ray.rllib.env.apis")
+    tse = mod("ray.rllib.env.apis.task_settable_env", TaskSettableEnv=TaskSettableEnv)
+    ray.rllib = rllib
+    rllib.env, rllib.algorithms, rllib.agents, rllib.utils = env, algos, agents, utils
+    algos.callbacks = cbs
+    utils.framework = fw
+    env.apis = apis
+    apis.task_settable_env = tse
+    mod("cv2")
+
+
+def load_reference():
+    """Returns a namespace with the reference classes of the hot path."""
+    if not reference_available():
+        raise RuntimeError("reference not present at %s" % REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    ns = types.SimpleNamespace()
+    from environments.cleanup_new import CleanupEnv
+    from environments.harvest_new import HarvestEnv
+    from environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
+    from environments.two_stage_train import SeparateContractSubgameStage
+    import contract.contract_list as contract_list
+
+    ns.CleanupEnv = CleanupEnv
+    ns.HarvestEnv = HarvestEnv
+    ns.SelfAcceleratingCarEnv = SelfAcceleratingCarEnv
+    ns.SeparateContractSubgameStage = SeparateContractSubgameStage
+    ns.contract_list = contract_list
+    return ns

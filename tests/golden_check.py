@@ -1,0 +1,154 @@
+"""Replays a golden fixture (tests/golden/*.npz, produced by the reference itself) through an
+implementation exposing the Oracle/BatchedEnv protocol (seed/reset/step + state arrays) and
+asserts step-by-step identity.  Shared by the CPU-oracle tests and the GPU parity tests."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixtures(prefix=""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def grid_kwargs(g):
+    kind = str(g["kind"])
+    contract = None
+    if int(g["contract"]):
+        contract = "cleanup" if kind == "cleanup" else "harvest_local"
+    return kind, int(g["n"]), dict(contract=contract, horizon=int(g["horizon"]), firing=bool(int(g["firing"])))
+
+
+METRIC_INT = {"total_apples_eaten": 0, "raw_env_rewards": 1, "dirt_cleaned": 2, "low_density_apples_eaten": 3}
+METRIC_F64 = {"transfers": 0, "equality": 1, "sustainability": 2, "transfer_equality": 3, "transfer_sustainability": 4}
+
+
+def metrics_dict(kind, n, mi, mf, final):
+    """reference-style env.metrics dict from the engine's metric arrays"""
+    out = {"total_apples_eaten": mi[0], "raw_env_rewards": mi[1], "transfers": mf[0]}
+    if kind == "cleanup":
+        out["dirt_cleaned"] = mi[2]
+        for i in range(n):
+            out["a%d-waste_cleaned" % i] = mi[4 + i]
+    else:
+        out["low_density_apples_eaten"] = mi[3]
+        for i in range(n):
+            out["a%d-apples_consumed" % i] = mi[4 + i]
+            out["a%d-close_apples_consumed" % i] = mi[4 + n + i]
+    if final:
+        out["equality"], out["sustainability"] = mf[1], mf[2]
+        out["transfer_equality"], out["transfer_sustainability"] = mf[3], mf[4]
+    return out
+
+
+def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
+    """impl: object with seed/reset/step and array attributes; `get(name)` returns a host
+    array for a field (defaults to attribute access, i.e. oracle host views)."""
+    if get is None:
+        def get(name):
+            return getattr(impl, name)
+    kind, n = str(g["kind"]), int(g["n"])
+    seed = int(g["seed"])
+    E = impl.E
+    static_spawn = g["static_spawn"]
+
+    def spawn_cells():
+        sp = get("spawn_perm")[env]
+        return [int(p) % len(static_spawn) if kind == "cleanup" else int(p) for p in sp]
+
+    seeds = np.full((E,), seed, np.uint64)
+    impl.seed(seeds)
+    sync()
+    assert np.array_equal(get("agents")[env][:, :3], g["ctor_agents"]), "constructor agents"
+    assert spawn_cells() == list(g["ctor_spawn_perm"]), "constructor spawn list"
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    n_obs = len(g["obs"])
+    for ep in range(len(g["ep_start"])):
+        impl.reset()
+        sync()
+        assert np.array_equal(get("grid")[env], g["reset_grid"][ep]), "reset grid ep%d" % ep
+        assert np.array_equal(get("agents")[env][:, :3], g["reset_agents"][ep]), "reset agents ep%d" % ep
+        if check_obs:
+            assert np.array_equal(get("obs")[env], g["reset_obs"][ep]), "reset obs ep%d" % ep
+        rng = get("rng")[env]
+        fp = int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16)
+        assert (int(rng[624]), fp) == tuple(int(x) for x in g["reset_mt"][ep]), "MT state after reset ep%d" % ep
+        assert get("theta")[env] == g["theta"][ep], "theta ep%d" % ep
+        for t in range(ep_start[ep], ep_start[ep + 1]):
+            acts = np.broadcast_to(g["actions"][t], (E, n))
+            impl.step(acts)
+            sync()
+            tag = "step %d (ep %d)" % (t, ep)
+            assert np.array_equal(get("agents")[env][:, :3], g["agents"][t]), "agents " + tag
+            assert np.array_equal(get("grid")[env], g["grid"][t]), "grid " + tag
+            assert np.array_equal(get("base_reward")[env], g["base_rew"][t]), "base reward " + tag
+            np.testing.assert_allclose(get("reward")[env], g["rew"][t], rtol=0, atol=1e-9, err_msg="reward " + tag)
+            info = get("info")[env]
+            assert np.array_equal(info[:, 0], g["eaten"][t]), "eaten_apples " + tag
+            second = g["cleaned"][t] if kind == "cleanup" else g["eaten_close"][t]
+            assert np.array_equal(info[:, 1], second), "info[1] " + tag
+            assert np.array_equal(get("features")[env].astype(np.float64), g["feature_obs"][t]), "feature_obs " + tag
+            assert int(get("done")[env]) == int(g["done"][t]), "done " + tag
+            if check_obs:
+                ob = get("obs")[env]
+                if t < n_obs:
+                    assert np.array_equal(ob, g["obs"][t]), "obs " + tag
+                sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(ob).tobytes()).digest(), np.uint8)
+                assert np.array_equal(sha, g["obs_sha"][t]), "obs sha " + tag
+            rng = get("rng")[env]
+            fp = int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16)
+            assert (int(rng[624]), fp) == tuple(int(x) for x in g["mt"][t]), "MT state " + tag
+            if kind == "cleanup":
+                assert np.array_equal(get("waste_perm")[env], g["waste_perm"][t]), "waste perm " + tag
+        # metrics at the end of the recorded episode
+        keys = str(g["metrics_keys_ep%d" % ep]).split(",")
+        vals = g["metrics_vals_ep%d" % ep]
+        final = "equality" in keys
+        mi = get("final_int_metrics" if final else "int_metrics")[env]
+        mf = get("final_f64_metrics" if final else "f64_metrics")[env]
+        md = metrics_dict(kind, n, mi, mf, final)
+        for k, v in zip(keys, vals):
+            if k.startswith("transfer") and int(g["contract"]) == 0:
+                continue
+            np.testing.assert_allclose(md[k], v, rtol=1e-12, atol=1e-9, err_msg="metric %s ep%d" % (k, ep))
+        assert spawn_cells() == list(g["spawn_perm"][ep]), "spawn list after ep%d" % ep
+
+
+def replay_selfdrive(g, impl, env=0, sync=lambda: None, get=None, atol=1e-9):
+    if get is None:
+        def get(name):
+            return getattr(impl, name)
+    n = int(g["n"])
+    E = impl.E
+    impl.seed(np.full((E,), int(g["seed"]), np.uint64))
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    for ep in range(len(g["ep_start"])):
+        impl.reset()
+        sync()
+        np.testing.assert_allclose(get("obs_f64")[env], g["reset_obs"][ep], rtol=0, atol=atol, err_msg="reset obs")
+        np.testing.assert_allclose(get("theta")[env], g["theta"][ep], rtol=0, atol=atol)
+        for t in range(ep_start[ep], ep_start[ep + 1]):
+            impl.step(np.broadcast_to(g["actions"][t], (E, n)), np.broadcast_to(g["active"][t], (E, n)))
+            sync()
+            tag = "step %d (ep %d)" % (t, ep)
+            act = g["active"][t].astype(bool)
+            np.testing.assert_allclose(get("obs_f64")[env][act], g["obs"][t][act], rtol=0, atol=atol, err_msg="obs " + tag)
+            np.testing.assert_allclose(get("reward")[env][act], g["rew"][t][act], rtol=0, atol=1e-6, err_msg="rew " + tag)
+            st = get("sd_state")[env]
+            np.testing.assert_allclose(st[:n], g["pos"][t], rtol=0, atol=atol, err_msg="pos " + tag)
+            np.testing.assert_allclose(st[n:2 * n], g["vel"][t], rtol=0, atol=atol, err_msg="vel " + tag)
+            assert np.array_equal(get("done_agents")[env], g["done"][t][:n]), "done " + tag
+            assert int(get("done")[env]) == int(g["done"][t][n]), "done_all " + tag
+            assert np.array_equal(get("info")[env][:, 0][act], g["just_passed"][t][act]), "just_passed " + tag
+            np.testing.assert_allclose(get("f64_metrics")[env][0], g["transfers_metric"][t], rtol=0, atol=1e-6,
+                                       err_msg="transfers metric " + tag)
+            nc = int(st[4 * n + 1])
+            crossed = [int(x) for x in st[4 * n + 2:4 * n + 2 + nc]]
+            assert crossed == [int(x) for x in g["crossed"][t] if x >= 0], "crossed " + tag
