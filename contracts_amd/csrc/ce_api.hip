@@ -1,0 +1,583 @@
+// ce_api.hip — host side of the C-ABI declared in include/contracts_engine.h.
+// Owns device memory, builds the static map tables, validates arguments and launches the
+// gfx950 kernels.  No torch types, no exceptions across the boundary, no global mutable
+// state besides the per-process constant tables (idempotent uploads).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ce_device.h"
+
+using namespace ce;
+
+// ----------------------------------------------------------------------------------------
+// the two maps (the engine's own data; cells as in environments/cleanup_new.py:10-36 and
+// environments/harvest_new.py:10-27: '@' wall, 'P' spawn, 'B' cleanup apple area, 'H' waste,
+// 'R' river, 'S' stream, 'A' harvest apple)
+// ----------------------------------------------------------------------------------------
+static const char* kCleanupMap[25] = {
+    "@@@@@@@@@@@@@@@@@@", "@RRRRRR     BBBBB@", "@HHHHHH      BBBB@", "@RRRRRR     BBBBB@", "@RRRRR  P    BBBB@",
+    "@RRRRR    P BBBBB@", "@HHHHH       BBBB@", "@RRRRR      BBBBB@", "@HHHHHHSSSSSSBBBB@", "@HHHHHHSSSSSSBBBB@",
+    "@RRRRR   P P BBBB@", "@HHHHH   P  BBBBB@", "@RRRRRR    P BBBB@", "@HHHHHH P   BBBBB@", "@RRRRR       BBBB@",
+    "@HHHH    P  BBBBB@", "@RRRRR       BBBB@", "@HHHHH  P P BBBBB@", "@RRRRR       BBBB@", "@HHHH       BBBBB@",
+    "@RRRRR       BBBB@", "@HHHHH      BBBBB@", "@RRRRR       BBBB@", "@HHHH       BBBBB@", "@@@@@@@@@@@@@@@@@@"};
+static const char* kHarvestMap[16] = {
+    "@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@", "@ P   P      A    P AAAAA    P  A P  @",
+    "@  P     A P AA    P    AAA    A  A  @", "@     A AAA  AAA    A    A AA AAAA   @",
+    "@ A  AAA A    A  A AAA  A  A   A A   @", "@AAA  A A    A  AAA A  AAA        A P@",
+    "@ A A  AAA  AAA  A A    A AA   AA AA @", "@  A A  AAA    A A  AAA    AAA  A    @",
+    "@   AAA  A      AAA  A    AAAA       @", "@ P  A       A  A AAA    A  A      P @",
+    "@A  AAA  A  A  AAA A    AAAA     P   @", "@    A A   AAA  A A      A AA   A  P @",
+    "@     AAA   A A  AAA      AA   AAA P @", "@ A    A     AAA  A  P          A    @",
+    "@       P     A         P  P P     P @", "@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@@"};
+
+// colours: DEFAULT_COLOURS (map_env.py:24-42) + CLEANUP_COLORS (cleanup_new.py:42-47), packed 0x00BBGGRR
+static uint32_t rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
+
+template <int KIND> static void build_tables(GridTables& t) {
+  typedef Geo<KIND> G;
+  const char** map = KIND == CE_KIND_CLEANUP ? kCleanupMap : kHarvestMap;
+  std::memset(&t, 0, sizeof(t));
+  int na = 0, nw = 0, ns = 0;
+  for (int r = 0; r < G::H; ++r)
+    for (int c = 0; c < G::W; ++c) {
+      const char ch = map[r][c];
+      const uint32_t pad = (uint32_t)((r + kView) * G::PW + c + kView);
+      const uint32_t packed = pad | ((uint32_t)r << 11) | ((uint32_t)c << 16);
+      uint8_t code = CE_CELL_EMPTY;
+      if (ch == '@') code = CE_CELL_WALL;
+      if (ch == 'P') t.spawn[ns++] = packed;
+      if (KIND == CE_KIND_CLEANUP) {
+        if (ch == 'B') t.apple[na++] = packed;
+        if (ch == 'H' || ch == 'R') t.waste[nw++] = packed;
+        if (ch == 'H') code = CE_CELL_WASTE;
+        if (ch == 'R') code = CE_CELL_RIVER;
+        if (ch == 'S') code = CE_CELL_STREAM;
+      } else if (ch == 'A') {
+        t.apple[na++] = packed;
+        code = CE_CELL_APPLE;  // custom_reset: every apple cell starts as 'A' (harvest_new.py:143-146)
+      }
+      t.base_pmap[pad] = code;
+    }
+  if (KIND == CE_KIND_CLEANUP)
+    for (int i = 0; i < 10; ++i) t.spawn[10 + i] = t.spawn[i];  // cleanup_new.py:114-115
+  if (KIND == CE_KIND_CLEANUP) {
+    // compute_probabilities (cleanup_new.py:351-368) for every possible #H, as exact 53-bit
+    // thresholds: rand < p  <=>  X < ceil(p * 2^53) for the 53-bit integer X behind rand
+    const int potential = G::NWASTE;
+    for (int nH = 0; nH <= potential; ++nH) {
+      volatile double free_area = (double)(potential - nH);
+      volatile double density = 1 - free_area / (double)potential;
+      double p_apple, p_waste;
+      if (density >= 0.4) {
+        p_apple = 0;
+        p_waste = 0;
+      } else {
+        p_waste = 0.5;
+        if (density <= 0.0) {
+          p_apple = 0.05;
+        } else {
+          volatile double frac = (density - 0.0) / (0.4 - 0.0);
+          volatile double one_minus = 1 - frac;
+          p_apple = one_minus * 0.05;
+        }
+      }
+      t.apple_thresh[nH] = (uint64_t)std::ceil(std::ldexp(p_apple, 53));
+      t.waste_on[nH] = p_waste != 0;
+    }
+  } else {
+    const double spawn_prob[4] = {0, 0.005, 0.02, 0.05};  // SPAWN_PROB harvest_new.py:34
+    for (int k = 0; k < 4; ++k) t.apple_thresh[k] = (uint64_t)std::ceil(std::ldexp(spawn_prob[k], 53));
+    int k = 0;
+    for (int j = -5; j <= 5; ++j)
+      for (int kk = -5; kk <= 5; ++kk)
+        if (j * j + kk * kk <= 5) t.close_off[k++] = (uint32_t)(int32_t)(j * G::PW + kk);  // harvest_new.py:326-336
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+struct ce_engine {
+  ce_config cfg;
+  ce_buffers buf;  // device pointers
+  int grid_stride;
+  uint64_t* d_seeds;
+  uint8_t* d_mask;
+  uint8_t* d_stage_actions;  // E*n*4 bytes
+  uint8_t* d_stage_active;   // E*n
+  std::vector<std::pair<void**, size_t>> allocs;
+  std::string err;
+  // timing
+  hipEvent_t ev_start, ev_stop;
+  bool timing_armed;
+  uint32_t timed_launches;
+};
+
+static int fail(ce_engine* h, int code, const char* what, hipError_t e = hipSuccess) {
+  if (h) {
+    h->err = what;
+    if (e != hipSuccess) {
+      h->err += ": ";
+      h->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+template <class T> static int dalloc(ce_engine* h, T** p, size_t count) {
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) return fail(h, CE_ENOMEM, "hipMalloc", e);
+  e = hipMemset(*p, 0, bytes);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "hipMemset", e);
+  h->allocs.push_back({(void**)p, bytes});
+  return CE_OK;
+}
+
+extern "C" int ce_abi_version(void) { return CE_ABI_VERSION; }
+
+extern "C" int ce_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return CE_ENODEV;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.kind == CE_KIND_HARVEST; }
+
+extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
+  if (!cfg || !out) return CE_EINVAL;
+  *out = nullptr;
+  if (cfg->abi_version != CE_ABI_VERSION || cfg->kind > CE_KIND_SELFDRIVE || cfg->num_envs == 0) return CE_EINVAL;
+  const uint32_t maxn = cfg->kind == CE_KIND_SELFDRIVE ? 10 : kMaxGridAgents;
+  if (cfg->num_agents < 1 || cfg->num_agents > maxn) return CE_EINVAL;
+  if (cfg->kind == CE_KIND_CLEANUP && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_CLEANUP) return CE_EINVAL;
+  if (cfg->kind == CE_KIND_HARVEST && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
+  if (cfg->kind == CE_KIND_SELFDRIVE && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_SELFDRIVE_DISTPROP) return CE_EINVAL;
+  if ((cfg->flags & CE_FLAG_INEQUITY_AVERSE) && cfg->num_agents < 2) return CE_EINVAL;  // map_env.py:294 assertion
+
+  ce_engine* h = new (std::nothrow) ce_engine();
+  if (!h) return CE_ENOMEM;
+  h->cfg = *cfg;
+  if (h->cfg.horizon == 0) h->cfg.horizon = 1000;
+  h->timing_armed = false;
+  h->timed_launches = 0;
+  h->d_seeds = nullptr;
+  h->d_mask = nullptr;
+  h->d_stage_actions = nullptr;
+  h->d_stage_active = nullptr;
+  std::memset(&h->buf, 0, sizeof(h->buf));
+  *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(h, CE_ENODEV, "no HIP device visible (this engine has no CPU path)", e);
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(h, CE_EINVAL, "device ordinal out of range");
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail(h, CE_ENODEV, "hipSetDevice", e);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail(h, CE_ENODEV, "hipGetDeviceProperties", e);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(h, CE_ENODEV, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
+  if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) return fail(h, CE_ENODEV, "hipEventCreate");
+
+  const size_t E = cfg->num_envs, n = cfg->num_agents;
+  ce_buffers& b = h->buf;
+  b.num_envs = cfg->num_envs;
+  b.num_agents = cfg->num_agents;
+  b.num_int_metrics = CE_MI_COUNT(n);
+  b.num_f64_metrics = CE_MF_COUNT(n);
+  int rc = CE_OK;
+#define A(field, count) \
+  if (rc == CE_OK) rc = dalloc(h, &b.field, (count))
+  if (is_grid(*cfg)) {
+    const bool cl = cfg->kind == CE_KIND_CLEANUP;
+    b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
+    b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
+    h->grid_stride = cl ? Geo<0>::GRID_STRIDE : Geo<1>::GRID_STRIDE;
+    b.grid_env_stride = h->grid_stride;
+    b.obs_bytes_per_agent = kPixPerAgent * 3;
+    b.obs_env_stride = (uint32_t)((n * kPixPerAgent * 3 + 3) / 4 * 4);
+    b.num_features = (uint32_t)(cl ? 12 + n : 10 + 2 * n);
+    b.rng_words = CE_RNG_WORDS_GRID;
+    A(grid, E * h->grid_stride);
+    A(agents, E * n * 4);
+    A(spawn_perm, E * 20);
+    A(waste_perm, E * 119 + 8);
+    A(rng, E * CE_RNG_WORDS_GRID);
+    A(obs, E * b.obs_env_stride + 16);
+    A(features, E * n * b.num_features);
+    // static tables (process-wide constants; re-uploading identical bytes is harmless)
+    if (rc == CE_OK) {
+      static GridTables t0, t1;
+      build_tables<CE_KIND_CLEANUP>(t0);
+      build_tables<CE_KIND_HARVEST>(t1);
+      std::vector<uint16_t> pix(kMaxGridAgents * kPixPerAgent + 7, 0xF000);
+      for (int q = 0; q < kMaxGridAgents * kPixPerAgent; ++q) {
+        const int a = q / kPixPerAgent, pq = q % kPixPerAgent;
+        pix[q] = (uint16_t)(a << 8 | (pq / kWin) << 4 | (pq % kWin));
+      }
+      const uint32_t lut[16] = {rgb(0, 0, 0),       rgb(180, 180, 180), rgb(0, 255, 0),     rgb(99, 156, 194),
+                                rgb(113, 75, 24),   rgb(113, 75, 24),   rgb(0, 0, 255),     rgb(2, 81, 154),
+                                rgb(204, 0, 204),   rgb(216, 30, 54),   rgb(254, 151, 0),   rgb(100, 255, 255),
+                                rgb(99, 99, 255),   rgb(250, 204, 255), rgb(238, 223, 16),  0};
+      if (upload_grid_tables(CE_KIND_CLEANUP, t0, pix.data(), (int)pix.size(), lut) ||
+          upload_grid_tables(CE_KIND_HARVEST, t1, pix.data(), (int)pix.size(), lut))
+        rc = fail(h, CE_ENODEV, "constant table upload failed");
+    }
+  } else {
+    b.num_features = (uint32_t)(2 * n + 7);
+    b.rng_words = CE_RNG_WORDS_SELFDRIVE;
+    A(rng, E * CE_RNG_WORDS_SELFDRIVE);
+    A(sd_state, E * CE_SD_STATE_DOUBLES(n));
+    A(obs_f64, E * n * (2 * n + 7));
+    A(done_agents, E * n);
+  }
+  A(timestep, E);
+  A(theta, E);
+  A(base_reward, E * n);
+  A(reward, E * n);
+  A(done, E);
+  A(info, E * n * 2);
+  A(int_metrics, E * CE_MI_COUNT(n));
+  A(f64_metrics, E * CE_MF_COUNT(n));
+  A(final_int_metrics, E * CE_MI_COUNT(n));
+  A(final_f64_metrics, E * CE_MF_COUNT(n));
+  A(error_flags, E);
+  if (rc == CE_OK) rc = dalloc(h, &h->d_seeds, E);
+  if (rc == CE_OK) rc = dalloc(h, &h->d_mask, E);
+  if (rc == CE_OK) rc = dalloc(h, &h->d_stage_actions, E * n * 4);
+  if (rc == CE_OK) rc = dalloc(h, &h->d_stage_active, E * n);
+#undef A
+  return rc;
+}
+
+extern "C" int ce_destroy(ce_handle h) {
+  if (!h) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& a : h->allocs)
+    if (*a.first) (void)hipFree(*a.first);
+  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+  delete h;
+  return CE_OK;
+}
+
+static GridParams grid_params(ce_engine* h) {
+  GridParams p;
+  std::memset(&p, 0, sizeof(p));
+  const ce_buffers& b = h->buf;
+  p.grid = b.grid;
+  p.agents = b.agents;
+  p.spawn_perm = b.spawn_perm;
+  p.waste_perm = b.waste_perm;
+  p.rng = b.rng;
+  p.timestep = b.timestep;
+  p.theta = b.theta;
+  p.obs = b.obs;
+  p.base_reward = b.base_reward;
+  p.reward = b.reward;
+  p.done = b.done;
+  p.info = b.info;
+  p.features = b.features;
+  p.int_metrics = b.int_metrics;
+  p.f64_metrics = b.f64_metrics;
+  p.final_int_metrics = b.final_int_metrics;
+  p.final_f64_metrics = b.final_f64_metrics;
+  p.error_flags = b.error_flags;
+  p.E = h->cfg.num_envs;
+  p.n = h->cfg.num_agents;
+  p.horizon = h->cfg.horizon;
+  p.contract = h->cfg.contract;
+  p.flags = h->cfg.flags;
+  p.obs_env_stride = b.obs_env_stride;
+  p.num_features = b.num_features;
+  p.contract_low = h->cfg.contract_low;
+  p.contract_high = h->cfg.contract_high;
+  p.null_prob = h->cfg.null_prob;
+  p.alpha = h->cfg.alpha;
+  p.beta = h->cfg.beta;
+  return p;
+}
+
+static SdParams sd_params(ce_engine* h) {
+  SdParams p;
+  std::memset(&p, 0, sizeof(p));
+  const ce_buffers& b = h->buf;
+  p.sd_state = b.sd_state;
+  p.rng = b.rng;
+  p.theta = b.theta;
+  p.obs_f64 = b.obs_f64;
+  p.reward = b.reward;
+  p.done = b.done;
+  p.done_agents = b.done_agents;
+  p.info = b.info;
+  p.f64_metrics = b.f64_metrics;
+  p.final_f64_metrics = b.final_f64_metrics;
+  p.int_metrics = b.int_metrics;
+  p.final_int_metrics = b.final_int_metrics;
+  p.error_flags = b.error_flags;
+  p.E = h->cfg.num_envs;
+  p.n = h->cfg.num_agents;
+  p.contract = h->cfg.contract;
+  p.flags = h->cfg.flags;
+  p.contract_low = h->cfg.contract_low;
+  p.contract_high = h->cfg.contract_high;
+  p.null_prob = h->cfg.null_prob;
+  p.low_bound = h->cfg.low_bound;
+  p.high_bound = h->cfg.high_bound;
+  p.start_vel = h->cfg.start_vel;
+  p.start_vel_ambulance = h->cfg.start_vel_ambulance;
+  return p;
+}
+
+static int check_launch(ce_engine* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, CE_ENODEV, what, e);
+  return CE_OK;
+}
+
+static int stage_mask(ce_engine* h, const uint8_t* mask, hipStream_t s, const uint8_t** dmask) {
+  *dmask = nullptr;
+  if (!mask) return CE_OK;
+  hipError_t e = hipMemcpyAsync(h->d_mask, mask, h->cfg.num_envs, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "mask upload", e);
+  // the host buffer may be reused by the caller right away
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(h, CE_ENODEV, "mask upload sync", e);
+  *dmask = h->d_mask;
+  return CE_OK;
+}
+
+extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int replay_constructor) {
+  if (!h) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  const uint32_t E = h->cfg.num_envs;
+  std::vector<uint64_t> tmp;
+  if (!seeds) {
+    tmp.resize(E);
+    for (uint32_t i = 0; i < E; ++i) tmp[i] = seed0 + h->cfg.env_index_base + i;
+    seeds = tmp.data();
+  }
+  for (uint32_t i = 0; i < E; ++i)
+    if ((!mask || mask[i]) && seeds[i] > 0xffffffffull) return fail(h, CE_EINVAL, "seed must fit 32 bits (np.random.seed range)");
+  hipError_t e = hipMemcpy(h->d_seeds, seeds, sizeof(uint64_t) * E, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "seed upload", e);
+  const uint8_t* dmask;
+  int rc = stage_mask(h, mask, nullptr, &dmask);
+  if (rc) return rc;
+  if (is_grid(h->cfg)) {
+    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_GRID, 0, h->d_seeds, dmask, E, 0, nullptr);
+    if (replay_constructor) {
+      GridParams p = grid_params(h);
+      p.mask = dmask;
+      launch_grid_construct((int)h->cfg.kind, p, nullptr);
+    }
+  } else {
+    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
+    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, CE_RNG_WORDS_GRID, h->d_seeds, dmask, E, 1, nullptr);
+    if (replay_constructor) {
+      SdParams p = sd_params(h);
+      p.mask = dmask;
+      launch_sd_construct(p, nullptr);
+    }
+  }
+  if ((rc = check_launch(h, "seed kernels"))) return rc;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(h, CE_ENODEV, "seed sync", e);
+  return CE_OK;
+}
+
+extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
+  if (!h) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  const uint8_t* dmask;
+  int rc = stage_mask(h, mask, (hipStream_t)stream, &dmask);
+  if (rc) return rc;
+  if (is_grid(h->cfg)) {
+    GridParams p = grid_params(h);
+    p.mask = dmask;
+    launch_grid_reset((int)h->cfg.kind, p, stream);
+  } else {
+    SdParams p = sd_params(h);
+    p.mask = dmask;
+    launch_sd_reset(p, stream);
+  }
+  return check_launch(h, "reset kernel");
+}
+
+extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
+  if (!h || !actions) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  if (is_grid(h->cfg)) {
+    GridParams p = grid_params(h);
+    p.actions = (const uint8_t*)actions;
+    launch_grid_step((int)h->cfg.kind, p, stream);
+  } else {
+    SdParams p = sd_params(h);
+    p.actions = (const float*)actions;
+    p.active = active;
+    launch_sd_step(p, stream);
+  }
+  if (h->timing_armed) h->timed_launches++;
+  return check_launch(h, "step kernel");
+}
+
+extern "C" int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) {
+  if (!h || !host_actions) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+  const size_t abytes = cnt * (is_grid(h->cfg) ? 1 : 4);
+  hipError_t e = hipMemcpyAsync(h->d_stage_actions, host_actions, abytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e == hipSuccess && host_active) e = hipMemcpyAsync(h->d_stage_active, host_active, cnt, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // host buffers are the caller's again
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "action upload", e);
+  return ce_step(h, h->d_stage_actions, host_active ? h->d_stage_active : nullptr, stream);
+}
+
+extern "C" int ce_synth_actions(ce_handle h, uint64_t key, uint32_t t0, uint32_t T, void* out, void* stream) {
+  if (!h || !out || T == 0) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  const ce_config& c = h->cfg;
+  if (is_grid(c)) {
+    const bool firing = c.flags & CE_FLAG_FIRING_ENABLED;
+    const uint32_t na = c.kind == CE_KIND_CLEANUP ? (firing ? 9 : 8) : (firing ? 8 : 7);
+    launch_synth_actions_u8((uint8_t*)out, key, c.env_index_base, c.num_envs, c.num_agents, t0, T, na, stream);
+  } else {
+    launch_synth_actions_f32((float*)out, key, c.env_index_base, c.num_envs, c.num_agents, t0, T, stream);
+  }
+  return check_launch(h, "synth actions kernel");
+}
+
+extern "C" uint32_t ce_synth_action_host(uint64_t key, uint64_t env_index, uint32_t t, uint32_t agent, uint32_t num_actions) {
+  return synth_action(key, env_index, t, agent, num_actions);
+}
+
+extern "C" uint64_t ce_synth_hash_host(uint64_t key, uint64_t env_index, uint32_t t, uint32_t agent) {
+  return synth_hash(key, env_index, t, agent);
+}
+
+extern "C" int ce_get_buffers(ce_handle h, ce_buffers* out) {
+  if (!h || !out) return CE_EINVAL;
+  *out = h->buf;
+  return CE_OK;
+}
+
+extern "C" int ce_synchronize(ce_handle h, void* stream) {
+  if (!h) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "hipStreamSynchronize", e);
+  return CE_OK;
+}
+
+struct FieldDesc {
+  const char* name;
+  void* base;
+  size_t env_bytes;
+};
+
+static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
+  const ce_buffers& b = h->buf;
+  const size_t n = b.num_agents;
+  const FieldDesc fields[] = {
+      {"grid", b.grid, (size_t)h->grid_stride},
+      {"agents", b.agents, n * 4},
+      {"spawn_perm", b.spawn_perm, 20},
+      {"waste_perm", b.waste_perm, 119},
+      {"rng", b.rng, (size_t)b.rng_words * 4},
+      {"timestep", b.timestep, 4},
+      {"theta", b.theta, 8},
+      {"sd_state", b.sd_state, CE_SD_STATE_DOUBLES(n) * 8},
+      {"obs", b.obs, b.obs_env_stride},
+      {"obs_f64", b.obs_f64, n * (2 * n + 7) * 8},
+      {"base_reward", b.base_reward, n * 4},
+      {"reward", b.reward, n * 8},
+      {"done", b.done, 1},
+      {"done_agents", b.done_agents, n},
+      {"info", b.info, n * 2},
+      {"features", b.features, n * b.num_features * 2},
+      {"int_metrics", b.int_metrics, (size_t)b.num_int_metrics * 8},
+      {"f64_metrics", b.f64_metrics, (size_t)b.num_f64_metrics * 8},
+      {"final_int_metrics", b.final_int_metrics, (size_t)b.num_int_metrics * 8},
+      {"final_f64_metrics", b.final_f64_metrics, (size_t)b.num_f64_metrics * 8},
+      {"error_flags", b.error_flags, 4},
+  };
+  for (const FieldDesc& f : fields)
+    if (std::strcmp(f.name, name) == 0) {
+      if (!f.base) return false;
+      *out = f;
+      return true;
+    }
+  return false;
+}
+
+extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes) {
+  if (!h || !field || !dst) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  FieldDesc f;
+  if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
+  if ((uint64_t)env_begin + env_count > h->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "download", e);
+  return CE_OK;
+}
+
+extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes) {
+  if (!h || !field || !src) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  FieldDesc f;
+  if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
+  if ((uint64_t)env_begin + env_count > h->cfg.num_envs || src_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy((char*)f.base + (size_t)env_begin * f.env_bytes, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "upload", e);
+  return CE_OK;
+}
+
+extern "C" int ce_timing_begin(ce_handle h, void* stream) {
+  if (!h) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  hipError_t e = hipEventRecord(h->ev_start, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "hipEventRecord", e);
+  h->timing_armed = true;
+  h->timed_launches = 0;
+  return CE_OK;
+}
+
+extern "C" int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches) {
+  if (!h || !h->timing_armed) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  hipError_t e = hipEventRecord(h->ev_stop, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipEventSynchronize(h->ev_stop);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev_start, h->ev_stop);
+  h->timing_armed = false;
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "event timing", e);
+  if (launches) *launches = h->timed_launches;
+  if (mean_ms) *mean_ms = h->timed_launches ? (double)ms / h->timed_launches : 0.0;
+  return CE_OK;
+}
+
+extern "C" int ce_selftest(int device, uint32_t* failed_mask) {
+  if (hipSetDevice(device) != hipSuccess) return CE_ENODEV;
+  uint32_t* d = nullptr;
+  if (hipMalloc((void**)&d, 16) != hipSuccess) return CE_ENOMEM;
+  (void)hipMemset(d, 0xff, 16);
+  launch_selftest(d, nullptr);
+  uint32_t r = 0xffffffffu;
+  hipError_t e = hipMemcpy(&r, d, 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return CE_ENODEV;
+  if (failed_mask) *failed_mask = r;
+  return r == 0 ? CE_OK : CE_EIO;
+}
+
+extern "C" const char* ce_last_error(ce_handle h) { return h ? h->err.c_str() : "null handle"; }

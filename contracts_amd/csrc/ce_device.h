@@ -1,0 +1,130 @@
+// ce_device.h — structures shared by the host API (ce_api.hip) and the gfx950 kernels
+// (ce_grid_kernels.hip, ce_selfdrive_kernels.hip).  Not part of the public C-ABI.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/contracts_engine.h"
+
+namespace ce {
+
+constexpr int kWave = 64;
+constexpr int kView = 7;    // CLEANUP_VIEW_SIZE / HARVEST_VIEW_SIZE (cleanup_new.py:51, harvest_new.py:36)
+constexpr int kWin = 15;    // 2*view+1
+constexpr int kPixPerAgent = kWin * kWin;  // 225
+constexpr int kMaxGridAgents = 9;
+constexpr int kMtN = 624, kMtM = 397;
+constexpr int kRngStride = CE_RNG_WORDS_GRID;  // words per env row
+
+// Geometry of the two grid families.  The LDS copy of the map is padded by the view radius
+// on every side (PW x PH) so the egocentric crop and every neighbourhood scan need no
+// bounds checks; both maps have a closed wall perimeter, so moves and beams never leave
+// the interior either.
+template <int KIND> struct Geo;
+template <> struct Geo<CE_KIND_CLEANUP> {
+  static constexpr int H = 25, W = 18, CELLS = 450, PW = 32, PH = 39, PCELLS = PW * PH;
+  static constexpr int NAPPLE = 103, NWASTE = 119, RANDW = 2 * (103 + 119), NSPAWN_CTOR = 10;
+  static constexpr int GRID_STRIDE = 464;  // bytes per env row in HBM (CELLS rounded up to 16)
+};
+template <> struct Geo<CE_KIND_HARVEST> {
+  static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
+  static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
+  static constexpr int GRID_STRIDE = 608;
+};
+
+// Static per-family tables (host-built from the ASCII maps, uploaded to __constant__).
+// Cell entries are packed:  padded_index | row << 11 | col << 16.
+struct GridTables {
+  uint32_t apple[160];         // apple spawn cells, row-major (cleanup 'B', harvest 'A')
+  uint32_t waste[128];         // cleanup waste cells 'H' u 'R', row-major
+  uint32_t spawn[20];          // 'P' cells; cleanup: entries 10..19 repeat 0..9 (cleanup_new.py:114-115)
+  uint64_t apple_thresh[120];  // cleanup: by #H on the map -> ceil(p_apple * 2^53); harvest: [0..3] by neighbour count
+  uint8_t waste_on[120];       // cleanup: by #H -> waste spawn probability is non-zero
+  uint8_t base_pmap[1568];     // padded reset-time map (walls + H/R/S, or harvest apples)
+  uint32_t close_off[24];      // harvest: 21 padded-index offsets with j^2+k^2 <= 5 (as int32)
+};
+
+struct GridParams {
+  // persistent state
+  uint8_t* grid;
+  uint8_t* agents;
+  uint8_t* spawn_perm;
+  uint8_t* waste_perm;
+  uint32_t* rng;
+  int32_t* timestep;
+  double* theta;
+  // outputs
+  uint8_t* obs;
+  int32_t* base_reward;
+  double* reward;
+  uint8_t* done;
+  uint8_t* info;
+  int16_t* features;
+  int64_t* int_metrics;
+  double* f64_metrics;
+  int64_t* final_int_metrics;
+  double* final_f64_metrics;
+  uint32_t* error_flags;
+  // inputs
+  const uint8_t* actions;  // [E][n]
+  const uint8_t* mask;     // [E] or null (seed/reset)
+  uint32_t E, n, horizon, contract, flags, obs_env_stride, num_features;
+  uint32_t replay_constructor;
+  double contract_low, contract_high, null_prob, alpha, beta;
+};
+
+struct SdParams {
+  double* sd_state;
+  uint32_t* rng;
+  double* theta;
+  double* obs_f64;
+  double* reward;
+  uint8_t* done;
+  uint8_t* done_agents;
+  uint8_t* info;
+  double* f64_metrics;
+  double* final_f64_metrics;
+  int64_t* int_metrics;
+  int64_t* final_int_metrics;
+  uint32_t* error_flags;
+  const float* actions;
+  const uint8_t* active;
+  const uint8_t* mask;
+  uint32_t E, n, contract, flags, replay_constructor;
+  double contract_low, contract_high, null_prob, low_bound, high_bound, start_vel, start_vel_ambulance;
+};
+
+// host-callable launchers implemented in the kernel translation units
+int upload_grid_tables(int kind, const GridTables& t, const uint16_t* pix, int npix, const uint32_t* rgb16);
+void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,
+                    const uint8_t* mask_dev, uint32_t E, int python_seeding, void* stream);
+void launch_grid_construct(int kind, const GridParams& p, void* stream);
+void launch_grid_reset(int kind, const GridParams& p, void* stream);
+void launch_grid_step(int kind, const GridParams& p, void* stream);
+void launch_sd_construct(const SdParams& p, void* stream);
+void launch_sd_reset(const SdParams& p, void* stream);
+void launch_sd_step(const SdParams& p, void* stream);
+void launch_synth_actions_u8(uint8_t* out, uint64_t key, uint64_t env_base, uint32_t E, uint32_t n, uint32_t t0,
+                             uint32_t T, uint32_t num_actions, void* stream);
+void launch_synth_actions_f32(float* out, uint64_t key, uint64_t env_base, uint32_t E, uint32_t n, uint32_t t0,
+                              uint32_t T, void* stream);
+int launch_selftest(uint32_t* out_dev, void* stream);
+
+// counter-based action hash shared by host and device (splitmix64 finaliser)
+#if defined(__HIPCC__)
+#define CE_HD __host__ __device__
+#else
+#define CE_HD
+#endif
+CE_HD inline uint64_t synth_hash(uint64_t key, uint64_t env, uint32_t t, uint32_t agent) {
+  uint64_t z = key ^ (env * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)t << 32 | (uint64_t)agent) * 0xD1B54A32D192ED03ull;
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+CE_HD inline uint32_t synth_action(uint64_t key, uint64_t env, uint32_t t, uint32_t agent, uint32_t num_actions) {
+  // multiply-shift range reduction of the high 32 bits (bias < 2^-29 for num_actions <= 9)
+  return (uint32_t)(((synth_hash(key, env, t, agent) >> 32) * (uint64_t)num_actions) >> 32);
+}
+
+}  // namespace ce

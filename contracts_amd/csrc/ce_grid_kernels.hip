@@ -1,0 +1,1322 @@
+// ce_grid_kernels.hip — gfx950 kernels for the Cleanup / Harvest grid families.
+//
+// Execution model: ONE 64-lane wavefront owns ONE env replica for the whole step.  The env's
+// map (padded by the view radius), its MT19937 state and the step's random words live in the
+// wave's private slice of LDS; the agent table lives in VGPRs with lane a = agent a, and all
+// order-dependent logic of the reference (move conflict resolution, beam order, Fisher-Yates
+// shuffles) runs as wave-uniform scalar control flow that addresses agents with
+// v_readlane/v_writelane and takes set-membership decisions with 64-bit ballots.  Waves never
+// talk to each other: no block barriers, no atomics, no inter-workgroup traffic.
+//
+// What each phase restates (reference paths relative to the reference root):
+//   update_moves            environments/map_env.py:483-676   
+//   consume                 map_env.py:244-247, Agent.py:189-195,228-234
+//   update_custom_moves     map_env.py:678-693  + update_map_fire :721-814
+//   spawn (cleanup)         cleanup_new.py:294-376 ; (harvest) harvest_new.py:251-317
+//   color_view crop         map_env.py:397-411
+//   infos/feature obs       cleanup_new.py:211-267,378-420 ; harvest_new.py:181-239,326-336
+//   contract + wrapper      contract/contract_list.py:22-27,45-54 ; two_stage_train.py:62-121,159-187
+//   numpy legacy RandomState shuffle / random_sample / randint / uniform (MT19937)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ce_device.h"
+
+namespace ce {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+#define DEVINL __device__ __forceinline__
+
+__constant__ GridTables c_tab[2];
+__constant__ __attribute__((aligned(16))) uint16_t c_pix[kMaxGridAgents * kPixPerAgent + 7];  // env-wide pixel -> agent<<8 | i<<4 | j
+__constant__ u32 c_rgb[16];                                       // colour LUT, 0x00BBGGRR
+
+// ----------------------------------------------------------------------------------------
+// wave primitives
+// ----------------------------------------------------------------------------------------
+DEVINL u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+DEVINL u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DEVINL u32 rdl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+// v_writelane has no clang builtin; a compare+select against the lane id is one VALU op more and
+// lets the compiler schedule it (no hand-padded SGPR hazards).
+DEVINL u32 wrl(u32 val, u32 l, u32 old) { return lane_id() == l ? val : old; }
+DEVINL u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+DEVINL u32 bperm(u32 v, u32 src_lane) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+DEVINL u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
+DEVINL u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
+DEVINL u32 fls64(u64 x) { return 63u - (u32)__builtin_clzll(x); }
+DEVINL bool bit(u64 m, u32 i) { return (m >> i) & 1ull; }
+
+// Lanes of one wave exchange data through LDS in program order; this only stops the compiler
+// from reordering one lane's LDS accesses around another lane's (no instruction is emitted).
+DEVINL void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wave-wide unsigned min via DPP row shifts + row broadcasts (result uniform)
+DEVINL u32 wave_min_u32(u32 v) {
+  const int id = (int)0xffffffffu;
+#define CE_DPP_MIN(ctrl, rmask)                                                                        \
+  {                                                                                                    \
+    u32 t = (u32)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rmask, 0xf, false);                     \
+    v = t < v ? t : v;                                                                                 \
+  }
+  CE_DPP_MIN(0x111, 0xf)  // row_shr:1
+  CE_DPP_MIN(0x112, 0xf)  // row_shr:2
+  CE_DPP_MIN(0x114, 0xf)  // row_shr:4
+  CE_DPP_MIN(0x118, 0xf)  // row_shr:8
+  CE_DPP_MIN(0x142, 0xa)  // row_bcast:15 -> rows 1,3
+  CE_DPP_MIN(0x143, 0xc)  // row_bcast:31 -> rows 2,3
+#undef CE_DPP_MIN
+  return rdl(v, 63);
+}
+
+// ----------------------------------------------------------------------------------------
+// MT19937 in LDS (numpy legacy RandomState stream)
+// ----------------------------------------------------------------------------------------
+DEVINL u32 mt_temper(u32 y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+DEVINL u32 mt_mix(u32 a, u32 b, u32 c) {  // new = c ^ twist(a,b)
+  u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Regenerates the 624-word state with 64 lanes: three dependent chunks (0..226 read only old
+// words, 227..453 read chunk-1 results, 454..622 read chunk-2 results), then word 623.
+__device__ __noinline__ void mt_twist(u32* mt, u32 lane) {
+  wave_sync();
+  for (u32 b = 0; b < 227; b += 64) {
+    const u32 i = b + lane, ic = i < 227 ? i : 0;
+    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic + kMtM]);
+    wave_sync();
+    if (i < 227) mt[i] = v;
+    wave_sync();
+  }
+  for (u32 b = 227; b < 454; b += 64) {
+    const u32 i = b + lane, ic = i < 454 ? i : 227;
+    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+    wave_sync();
+    if (i < 454) mt[i] = v;
+    wave_sync();
+  }
+  for (u32 b = 454; b < 623; b += 64) {
+    const u32 i = b + lane, ic = i < 623 ? i : 454;
+    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+    wave_sync();
+    if (i < 623) mt[i] = v;
+    wave_sync();
+  }
+  if (lane == 0) mt[623] = mt_mix(mt[623], mt[0], mt[396]);
+  wave_sync();
+}
+
+struct Rng {
+  u32* mt;     // LDS, 624 words
+  u32 pos;     // words consumed from the current generation (uniform)
+  u32 cache;   // lane k: tempered word cbase + k
+  u32 cbase;   // uniform
+  u32 ccount;  // uniform; 0 = cache invalid
+};
+
+DEVINL u32 rng_next(Rng& r, u32 lane) {
+  u32 off = r.pos - r.cbase;
+  if (off >= r.ccount) {
+    if (r.pos >= (u32)kMtN) {
+      mt_twist(r.mt, lane);
+      r.pos = 0;
+    }
+    r.cbase = r.pos;
+    u32 left = (u32)kMtN - r.pos;
+    r.ccount = left < 64u ? left : 64u;
+    u32 idx = r.pos + lane;
+    r.cache = mt_temper(r.mt[idx < (u32)kMtN ? idx : (u32)kMtN - 1]);
+    off = 0;
+  }
+  r.pos += 1;
+  return rdl(r.cache, off);
+}
+
+// legacy random_interval(max): masked rejection sampling, one word per attempt (max >= 1)
+DEVINL u32 rng_interval(Rng& r, u32 max, u32 lane) {
+  u32 mask = max;
+  mask |= mask >> 1;
+  mask |= mask >> 2;
+  mask |= mask >> 4;
+  mask |= mask >> 8;
+  u32 v;
+  do {
+    v = rng_next(r, lane) & mask;
+  } while (v > max);
+  return v;
+}
+
+// `count` tempered words of the stream into LDS (the rand(k) call of the spawn models)
+DEVINL void rng_bulk(Rng& r, u32* U, u32 count, u32 lane) {
+  u32 done = 0;
+  while (done < count) {
+    if (r.pos >= (u32)kMtN) {
+      mt_twist(r.mt, lane);
+      r.pos = 0;
+    }
+    u32 chunk = (u32)kMtN - r.pos;
+    if (chunk > count - done) chunk = count - done;
+    for (u32 k = lane; k < chunk; k += 64) U[done + k] = mt_temper(r.mt[r.pos + k]);
+    r.pos += chunk;
+    done += chunk;
+  }
+  r.ccount = 0;
+  wave_sync();
+}
+
+// the 53-bit integer X with random_sample() == X / 2^53, from words 2r and 2r+1 of U
+DEVINL u64 u53(const u32* U, u32 r) {
+  u32 a = U[2 * r] >> 5, b = U[2 * r + 1] >> 6;
+  return ((u64)a << 26) | (u64)b;
+}
+DEVINL double u53_to_double(u64 x) { return (double)x / 9007199254740992.0; }
+
+DEVINL double rng_double(Rng& r, u32 lane) {
+  u32 a = rng_next(r, lane) >> 5;
+  u32 b = rng_next(r, lane) >> 6;
+  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+// Fisher-Yates over a list held across lanes: element k (k < 64) in lane k of L0, element 64+k
+// in lane k of L1 (np.random.shuffle's untyped path: for i = len-1..1: j = interval(i); swap).
+DEVINL void shuffle_lanes(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
+  for (u32 i = len - 1; i >= 1 && len > 1; --i) {
+    u32 j = rng_interval(r, i, lane);
+    if (j != i) {
+      u32 vi = i < 64 ? rdl(L0, i) : rdl(L1, i - 64);
+      u32 vj = j < 64 ? rdl(L0, j) : rdl(L1, j - 64);
+      if (i < 64) L0 = wrl(vj, i, L0); else L1 = wrl(vj, i - 64, L1);
+      if (j < 64) L0 = wrl(vi, j, L0); else L1 = wrl(vi, j - 64, L1);
+    }
+  }
+}
+DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
+  for (u32 i = len - 1; i >= 1 && len > 1; --i) {
+    u32 j = rng_interval(r, i, lane);
+    if (j != i) {
+      u32 vi = rdl(L0, i), vj = rdl(L0, j);
+      L0 = wrl(vj, i, L0);
+      L0 = wrl(vi, j, L0);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// per-wave LDS
+// ----------------------------------------------------------------------------------------
+template <int KIND> struct alignas(16) WaveLds {
+  u32 mt[kMtN];
+  u32 U[Geo<KIND>::RANDW];
+  uint8_t pmap[Geo<KIND>::PCELLS];
+  u32 view[12];  // per agent: o0 | A << 16 | B << 24 of the crop address off = o0 + i*A + j*B
+  u32 rgb[16];
+};
+
+constexpr u32 kCellPadMask = 0x7ffu;
+DEVINL u32 cell_pad(u32 packed) { return packed & kCellPadMask; }
+DEVINL u32 cell_row(u32 packed) { return (packed >> 11) & 31u; }
+DEVINL u32 cell_col(u32 packed) { return (packed >> 16) & 63u; }
+
+// env context: everything a wave keeps in registers for its env
+template <int KIND> struct Env {
+  typedef Geo<KIND> G;
+  WaveLds<KIND>* L;
+  Rng rng;
+  u32 lane, n, e;
+  bool is_agent;
+  // lane a < n: agent a
+  u32 P;    // padded cell index of the agent
+  u32 O;    // orientation UP0 RIGHT1 DOWN2 LEFT3
+  i32 RW;   // reward_this_turn
+  // persistent lists across lanes
+  u32 SP;      // spawn list entry k in lane k (k < 20)
+  u32 WP0, WP1;  // waste list entries k / 64 + k
+  // static lane data: packed cells handled by this lane in round r
+  u32 AP[3];
+  u32 WS[2];
+};
+
+DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-index deltas
+  return o == 0 ? -PW : o == 1 ? 1 : o == 2 ? PW : -1;
+}
+
+template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return (row + kView) * Geo<KIND>::PW + col + kView; }
+template <int KIND> DEVINL u32 row_of(u32 pad) { return pad / Geo<KIND>::PW - kView; }
+template <int KIND> DEVINL u32 col_of(u32 pad) { return pad % Geo<KIND>::PW - kView; }
+
+// is some agent standing on padded cell `cell` (per-lane query); returns highest agent id + 1 or 0
+template <int KIND> DEVINL u32 agent_on(const Env<KIND>& E, u32 cell) {
+  u32 hit = 0;
+  for (u32 b = 0; b < E.n; ++b) {
+    u32 pb = rdl(E.P, b);
+    hit = (cell == pb) ? b + 1 : hit;
+  }
+  return hit;
+}
+
+// ----------------------------------------------------------------------------------------
+// state load / store
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL void load_static(Env<KIND>& E) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    u32 idx = E.lane + 64 * r;
+    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    u32 idx = E.lane + 64 * r;
+    E.WS[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+  }
+  if (E.lane < 16) E.L->rgb[E.lane] = c_rgb[E.lane];
+}
+
+template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
+  const uint4* src = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
+  uint4* dst = (uint4*)E.L->mt;
+  for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+  E.rng.mt = E.L->mt;
+  E.rng.pos = rfl(p.rng[(size_t)E.e * kRngStride + kMtN]);
+  E.rng.cbase = 0;
+  E.rng.ccount = 0;
+  E.rng.cache = 0;
+  wave_sync();
+}
+template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
+  wave_sync();
+  uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
+  const uint4* src = (const uint4*)E.L->mt;
+  for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+  if (E.lane == 0) p.rng[(size_t)E.e * kRngStride + kMtN] = E.rng.pos;
+}
+
+template <int KIND> DEVINL void zero_pmap(Env<KIND>& E) {
+  typedef Geo<KIND> G;
+  u32* pm = (u32*)E.L->pmap;
+  for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) pm[k] = 0;
+  wave_sync();
+}
+
+template <int KIND> DEVINL void load_grid(Env<KIND>& E, const GridParams& p) {
+  typedef Geo<KIND> G;
+  zero_pmap(E);
+  const u32* src = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
+  for (u32 k = E.lane; k < (u32)(G::CELLS + 3) / 4; k += 64) {
+    u32 w = src[k];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      u32 idx = 4 * k + bb;
+      if (idx < (u32)G::CELLS) {
+        u32 row = idx / G::W, col = idx - row * G::W;
+        E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((w >> (8 * bb)) & 0xff);
+      }
+    }
+  }
+  wave_sync();
+}
+template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
+  typedef Geo<KIND> G;
+  wave_sync();
+  u32* dst = (u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
+  for (u32 k = E.lane; k < (u32)(G::CELLS + 3) / 4; k += 64) {
+    u32 w = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      u32 idx = 4 * k + bb;
+      if (idx < (u32)G::CELLS) {
+        u32 row = idx / G::W, col = idx - row * G::W;
+        w |= (u32)E.L->pmap[pad_of<KIND>(row, col)] << (8 * bb);
+      }
+    }
+    dst[k] = w;
+  }
+}
+
+template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
+  u32 w = 0;
+  if (E.is_agent) w = ((const u32*)p.agents)[(size_t)E.e * E.n + E.lane];
+  E.P = pad_of<KIND>(w & 0xff, (w >> 8) & 0xff);
+  E.O = (w >> 16) & 3;
+  E.RW = 0;
+  if (!E.is_agent) E.P = 0xffffu;  // never equals a real cell
+}
+template <int KIND> DEVINL void store_agents(Env<KIND>& E, const GridParams& p) {
+  if (E.is_agent) {
+    u32 w = row_of<KIND>(E.P) | (col_of<KIND>(E.P) << 8) | (E.O << 16);
+    ((u32*)p.agents)[(size_t)E.e * E.n + E.lane] = w;
+  }
+}
+template <int KIND> DEVINL void load_perms(Env<KIND>& E, const GridParams& p) {
+  E.SP = E.lane < 20 ? p.spawn_perm[(size_t)E.e * 20 + E.lane] : 0;
+  E.WP0 = E.WP1 = 0;
+  if (KIND == CE_KIND_CLEANUP) {
+    const uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
+    E.WP0 = wp[E.lane];
+    E.WP1 = E.lane + 64 < 119 ? wp[E.lane + 64] : 0;
+  }
+}
+template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, bool spawn_too) {
+  if (spawn_too && E.lane < 20) p.spawn_perm[(size_t)E.e * 20 + E.lane] = (uint8_t)E.SP;
+  if (KIND == CE_KIND_CLEANUP) {
+    uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
+    wp[E.lane] = (uint8_t)E.WP0;
+    if (E.lane + 64 < 119) wp[E.lane + 64] = (uint8_t)E.WP1;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// update_moves (map_env.py:483-676)
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
+  typedef Geo<KIND> G;
+  const u32 lane = E.lane;
+  const bool mover = E.is_agent && ACT <= 4;
+  // phase A: targets (rotate_action + return_valid_pos), turns take effect immediately
+  i32 v0 = ACT == 2 ? -1 : ACT == 3 ? 1 : 0;  // MOVE_UP / MOVE_DOWN row component
+  i32 v1 = ACT == 0 ? -1 : ACT == 1 ? 1 : 0;  // MOVE_LEFT / MOVE_RIGHT col component
+  i32 dr, dc;
+  if (E.O == 0) { dr = v0; dc = v1; }          // UP: as is
+  else if (E.O == 3) { dr = -v1; dc = v0; }    // LEFT: rotate_left
+  else if (E.O == 1) { dr = v1; dc = -v0; }    // RIGHT: rotate_right
+  else { dr = -v0; dc = -v1; }                 // DOWN: two rotate_left
+  u32 tgt = E.P;
+  if (mover) {
+    u32 cand = (u32)((i32)E.P + dr * G::PW + dc);
+    if (E.L->pmap[cand] != CE_CELL_WALL) tgt = cand;
+  }
+  const u32 TGT0 = tgt;
+  if (E.is_agent && (ACT == 5 || ACT == 6)) E.O = (E.O + (ACT == 5 ? 1u : 3u)) & 3u;
+  const u64 M = ballot(mover);
+  if (M == 0) return;
+  const u32 m = popc64(M);
+  // slot list in agent order, then np.random.shuffle of the (agent, slot) pairs
+  u32 SA = 0;
+  {
+    u64 mm = M;
+    u32 s = 0;
+    while (mm) {
+      SA = wrl(ctz64(mm), s, SA);
+      mm &= mm - 1;
+      ++s;
+    }
+  }
+  shuffle_lanes1(E.rng, SA, m, lane);
+  const bool valid_s = lane < m;
+  const u32 T = bperm(TGT0, valid_s ? SA : 0);  // target of the agent at shuffled position `lane`
+  u32 cnt = 0;
+  for (u32 s2 = 0; s2 < m; ++s2) cnt += (rdl(T, s2) == T) ? 1u : 0u;
+  u32 MOVE = TGT0;  // agent_moves[a]
+  u64 HM = M;       // keys of agent_moves
+  u32 BYPOS = E.P;  // positions agent_by_pos was last built from
+  u64 todo = ballot(valid_s && cnt > 1);
+  // phase B: contested cells in ascending (row, col) order
+  while (todo) {
+    u32 cmin = 0xffffffffu;
+    for (u64 tt = todo; tt; tt &= tt - 1) {
+      u32 tv = rdl(T, ctz64(tt));
+      cmin = tv < cmin ? tv : cmin;
+    }
+    const u64 Gm = ballot(valid_s && T == cmin);
+    todo &= ~Gm;
+    const u32 w = rdl(SA, ctz64(Gm));            // first contender in shuffled order
+    const u64 CA = ballot(mover && TGT0 == cmin);  // contenders as agent lanes
+    const u64 occ = ballot(E.is_agent && E.P == cmin);
+    bool free_cell = true;
+    if (occ) {
+      const u64 bp = ballot(E.is_agent && BYPOS == cmin);
+      const u32 conf = fls64(bp | 1ull);
+      const bool conf_has = bit(HM, conf);
+      const u32 cpos = rdl(E.P, conf);
+      const u32 cmove = conf_has ? rdl(MOVE, conf) : cpos;
+      if (bit(CA, conf)) free_cell = false;                      // (1) a contender is the occupant
+      else if (!conf_has || cpos == cmove) free_cell = false;    // (2) occupant stays / has no move
+      else if (cmin == cpos && ballot(bit(CA, lane) && E.P == cmove) != 0) free_cell = false;  // (3) swap
+    }
+    if (free_cell) {
+      E.P = wrl(cmin, w, E.P);
+      BYPOS = E.P;
+    }
+    if (bit(CA, lane)) MOVE = E.P;  // every contender's move := its live position
+  }
+  // phase C: passes over the remaining moves in insertion (agent) order
+  while (HM) {
+    BYPOS = E.P;
+    const u64 snap = HM;
+    const u32 before = popc64(HM);
+    u64 del = 0;
+    for (u64 it = snap; it; it &= it - 1) {
+      const u32 x = ctz64(it);
+      if (bit(del, x)) continue;
+      const u32 mv = rdl(MOVE, x);
+      const u64 occ = ballot(E.is_agent && E.P == mv);
+      if (occ) {
+        const u64 bp = ballot(E.is_agent && BYPOS == mv);
+        if (bp == 0) {  // reference would raise KeyError; unreachable (targets are unique after phase B)
+          HM &= ~(1ull << x);
+          del |= 1ull << x;
+          continue;
+        }
+        const u32 conf = fls64(bp);
+        const u32 cpos = rdl(E.P, conf);
+        const u32 cmove = bit(HM, conf) ? rdl(MOVE, conf) : cpos;
+        const u32 xpos = rdl(E.P, x);
+        if (x == conf) {
+          HM &= ~(1ull << x);
+          del |= 1ull << x;
+        } else if (!bit(snap, conf) || cpos == cmove) {
+          HM &= ~(1ull << x);
+          del |= 1ull << x;
+        } else if (cmove == xpos && mv == cpos) {
+          HM &= ~((1ull << x) | (1ull << conf));
+          del |= (1ull << x) | (1ull << conf);
+        }
+      } else {
+        E.P = wrl(mv, x, E.P);
+        HM &= ~(1ull << x);
+        del |= 1ull << x;
+      }
+    }
+    if (popc64(HM) == before) {  // cycle: move everyone that is left
+      if (bit(HM, lane)) E.P = MOVE;
+      break;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// beams (update_map_fire map_env.py:721-814); lanes 0..14 = 3 rays x 5 cells
+// returns number of cells cleaned (CLEAN) — hits are applied to E.RW (FIRE)
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean) {
+  typedef Geo<KIND> G;
+  const u32 lane = E.lane;
+  const u32 o = rdl(E.O, firer), p0 = rdl(E.P, firer);
+  const i32 dd = dir_delta(G::PW, o), rr = dir_delta(G::PW, (o + 1) & 3);  // right(dir(o)) == dir(o+1)
+  const u32 ray = lane / 5, step = lane - 5 * ray;
+  const bool in_beam = lane < 15;
+  i32 start = (i32)p0;
+  if (ray == 1) start += rr - dd;
+  if (ray == 2) start += -rr - dd;
+  const u32 cell = in_beam ? (u32)(start + (i32)(step + 1) * dd) : 0u;
+  const u32 code = E.L->pmap[cell];
+  const bool invalid = code == CE_CELL_WALL;
+  const u32 hit = agent_on(E, cell);  // highest agent id on the cell + 1 (agent_by_pos: later wins)
+  const bool stopper = invalid || hit != 0 || (is_clean && code == CE_CELL_WASTE);
+  const u64 S = ballot(in_beam && stopper);
+  const u32 rb = (u32)(S >> (5 * ray)) & 31u;
+  const u32 f = rb ? (u32)__builtin_ctz(rb) : 5u;  // first stopping cell of this ray
+  const bool processed = in_beam && (step < f || (step == f && !invalid));
+  u32 cleaned = 0;
+  if (is_clean) {
+    const bool upd = processed && code == CE_CELL_WASTE;
+    cleaned = popc64(ballot(upd));
+    wave_sync();
+    if (upd) E.L->pmap[cell] = CE_CELL_RIVER;
+    wave_sync();
+  } else {
+    for (u64 hm = ballot(processed && hit != 0); hm; hm &= hm - 1) {
+      const u32 hid = rdl(hit, ctz64(hm)) - 1;
+      if (lane == hid) E.RW -= 50;  // Agent.hit(b"F")
+    }
+  }
+  return cleaned;
+}
+
+// ----------------------------------------------------------------------------------------
+// spawn models
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  const u32 lane = E.lane;
+  const u64 lt = (1ull << lane) - 1ull;
+  uint8_t* pm = E.L->pmap;
+  if (KIND == CE_KIND_CLEANUP) {
+    // compute_probabilities: #H on the map -> host-precomputed 53-bit threshold
+    u32 nH = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool v = lane + 64 * r < (u32)G::NWASTE;
+      nH += popc64(ballot(v && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE));
+    }
+    const u64 thr = T.apple_thresh[nH];
+    const bool waste_on = T.waste_on[nH] != 0;
+    rng_bulk(E.rng, E.L->U, (u32)G::RANDW, lane);
+    u32 rbase = 0;
+    bool spawnA[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool v = lane + 64 * r < (u32)G::NAPPLE;
+      const u32 cell = cell_pad(E.AP[r]);
+      const u32 occupied = agent_on(E, cell);
+      const bool elig = v && pm[cell] != CE_CELL_APPLE && occupied == 0;
+      const u64 eb = ballot(elig);
+      const u32 ri = rbase + popc64(eb & lt);
+      const u64 x = u53(E.L->U, elig ? ri : 0);
+      spawnA[r] = elig && x < thr;
+      rbase += popc64(eb);
+    }
+    u32 waste_cell = 0;
+    bool waste_found = false;
+    if (waste_on) {
+      shuffle_lanes(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (!waste_found) {
+          const bool v = lane + 64 * r < (u32)G::NWASTE;
+          const u32 widx = r == 0 ? E.WP0 : E.WP1;
+          const u32 cell = cell_pad(T.waste[v ? widx : 0]);
+          const bool cand = v && pm[cell] != CE_CELL_WASTE;
+          const u64 cb = ballot(cand);
+          const u32 ri = rbase + popc64(cb & lt);
+          const u64 x = u53(E.L->U, cand ? ri : 0);
+          const bool ok = cand && x < (1ull << 52);  // u < 0.5
+          const u64 ob = ballot(ok);
+          if (ob) {
+            waste_found = true;
+            waste_cell = rdl(cell, ctz64(ob));
+          }
+          rbase += popc64(cb);
+        }
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
+    if (waste_found && lane == 0) pm[waste_cell] = CE_CELL_WASTE;
+    wave_sync();
+  } else {
+    rng_bulk(E.rng, E.L->U, (u32)G::RANDW, lane);
+    u32 rbase = 0;
+    bool spawnA[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool v = lane + 64 * r < (u32)G::NAPPLE;
+      const u32 cell = cell_pad(E.AP[r]);
+      const u32 occupied = agent_on(E, cell);
+      const bool elig = v && pm[cell] != CE_CELL_APPLE && occupied == 0;
+      // apples in the 3x3 block around the cell (j^2 + k^2 <= APPLE_RADIUS = 2), pre-update map
+      u32 num = 0;
+      if (elig) {
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+          for (int k = -1; k <= 1; ++k) num += pm[(i32)cell + j * G::PW + k] == CE_CELL_APPLE ? 1u : 0u;
+      }
+      const u64 thr = T.apple_thresh[num < 3 ? num : 3];
+      const u64 eb = ballot(elig);
+      const u32 ri = rbase + popc64(eb & lt);
+      const u64 x = u53(E.L->U, elig ? ri : 0);
+      spawnA[r] = elig && x < thr;
+      rbase += popc64(eb);
+    }
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
+    wave_sync();
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// observation crop: the env's n*225 pixels as one byte stream, 4 pixels (12 B) per lane
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, bool paint_agents) {
+  typedef Geo<KIND> G;
+  const u32 lane = E.lane;
+  uint8_t* pm = E.L->pmap;
+  wave_sync();
+  if (paint_agents) {
+    // agents painted in agent order, the later agent wins on a shared cell (map_env.py:257-261)
+    for (u32 a = 0; a < E.n; ++a) {
+      const u32 pa = rdl(E.P, a);
+      if (lane == 0) pm[pa] = (uint8_t)(6 + a);
+      wave_sync();
+    }
+  }
+  if (E.is_agent) {
+    const i32 base = (i32)E.P - kView * G::PW - kView;
+    i32 o0, A, B;
+    if (E.O == 0) { o0 = base; A = G::PW; B = 1; }                                   // UP
+    else if (E.O == 3) { o0 = base + 14; A = -1; B = G::PW; }                        // LEFT  rot90(k=1)
+    else if (E.O == 2) { o0 = base + 14 * G::PW + 14; A = -G::PW; B = -1; }          // DOWN  rot90(k=2)
+    else { o0 = base + 14 * G::PW; A = 1; B = -G::PW; }                              // RIGHT rot90(k=1,(1,0))
+    E.L->view[lane] = ((u32)o0 & 0xffffu) | (((u32)A & 0xffu) << 16) | (((u32)B & 0xffu) << 24);
+  }
+  wave_sync();
+  const u32 npix = E.n * kPixPerAgent;
+  const u32 units = (npix + 3) / 4;
+  uint8_t* dst_env = p.obs + (size_t)E.e * p.obs_env_stride;
+  for (u32 u = lane; u < units; u += 64) {
+    const uint2 ent2 = *(const uint2*)(c_pix + 4 * u);
+    u32 col[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 ent = (k < 2 ? ent2.x : ent2.y) >> (16 * (k & 1)) & 0xffffu;
+      const u32 a = ent >> 8, i = (ent >> 4) & 15u, j = ent & 15u;
+      u32 c = 0;
+      if (4 * u + k < npix) {
+        const u32 vw = E.L->view[a];
+        const i32 off = (i32)(vw & 0xffffu) + (i32)i * ((i32)(vw << 8) >> 24) + (i32)j * ((i32)vw >> 24);
+        c = E.L->rgb[pm[off]];
+      }
+      col[k] = c;
+    }
+    const u32 d0 = (col[0] & 0xffffffu) | (col[1] << 24);
+    const u32 d1 = ((col[1] >> 8) & 0xffffu) | (col[2] << 16);
+    const u32 d2 = ((col[2] >> 16) & 0xffu) | (col[3] << 8);
+    u32* dst = (u32*)(dst_env + (size_t)u * 12);
+    if (u * 12 + 12 <= p.obs_env_stride) {
+      dst[0] = d0;
+      dst[1] = d1;
+      dst[2] = d2;
+    } else {
+      if (u * 12 + 4 <= p.obs_env_stride) dst[0] = d0;
+      if (u * 12 + 8 <= p.obs_env_stride) dst[1] = d1;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// metrics helpers
+// ----------------------------------------------------------------------------------------
+DEVINL double shfl_f64(double v, u32 src_lane_uniform) {
+  u64 b = (u64)__double_as_longlong(v);
+  u32 lo = rdl((u32)b, src_lane_uniform), hi = rdl((u32)(b >> 32), src_lane_uniform);
+  return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+DEVINL i32 shfl_i32(i32 v, u32 src_lane_uniform) { return (i32)rdl((u32)v, src_lane_uniform); }
+DEVINL long long shfl_i64(long long v, u32 l) {
+  u64 b = (u64)v;
+  return (long long)(((u64)rdl((u32)(b >> 32), l) << 32) | rdl((u32)b, l));
+}
+
+// numpy pairwise sum of the n (< 128) per-agent values held in lanes 0..n-1 (np.mean of a list)
+DEVINL double np_sum_lanes(double v, u32 n) {
+  if (n < 8) {
+    double res = 0.;
+    for (u32 i = 0; i < n; ++i) res += shfl_f64(v, i);
+    return res;
+  }
+  double r[8];
+  for (u32 j = 0; j < 8; ++j) r[j] = shfl_f64(v, j);
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (u32 i = 8; i < n; ++i) res += shfl_f64(v, i);  // n <= 9: tail only
+  return res;
+}
+
+template <int KIND> DEVINL void zero_metrics(Env<KIND>& E, const GridParams& p) {
+  const u32 nmi = CE_MI_COUNT(E.n), nmf = CE_MF_COUNT(E.n);
+  for (u32 k = E.lane; k < nmi; k += 64) p.int_metrics[(size_t)E.e * nmi + k] = 0;
+  for (u32 k = E.lane; k < nmf; k += 64) p.f64_metrics[(size_t)E.e * nmf + k] = 0.0;
+}
+
+// ----------------------------------------------------------------------------------------
+// setup_agents (cleanup_new.py:302-320, map_env.py:816-832): n x (shuffle the persistent
+// spawn list, take the LAST free entry, randint(4) orientation)
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL bool setup_agents(Env<KIND>& E, u32 list_len) {
+  const GridTables& T = c_tab[KIND];
+  const u32 lane = E.lane;
+  bool ok = true;
+  E.P = 0xffffu;
+  E.O = 0;
+  E.RW = 0;
+  for (u32 i = 0; i < E.n; ++i) {
+    shuffle_lanes1(E.rng, E.SP, list_len, lane);
+    const u32 cell = cell_pad(T.spawn[lane < list_len ? E.SP : 0]);
+    bool taken = false;
+    for (u32 b = 0; b < i; ++b) taken = taken || (rdl(E.P, b) == cell);
+    const u64 fb = ballot(lane < list_len && !taken);
+    const u32 r = rng_next(E.rng, lane) & 3u;  // randint(4)
+    if (fb == 0) {
+      ok = false;
+      continue;
+    }
+    const u32 pc = rdl(cell, fls64(fb));
+    const u32 orient = r == 0 ? 3u : r == 1 ? 1u : r == 2 ? 0u : 2u;  // keys order LEFT,RIGHT,UP,DOWN
+    E.P = wrl(pc, i, E.P);
+    E.O = wrl(orient, i, E.O);
+  }
+  return ok;
+}
+
+template <int KIND> DEVINL void sample_theta(Env<KIND>& E, const GridParams& p, double& theta) {
+  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
+  if (p.contract == CE_CONTRACT_NONE) {
+    theta = 0.0;
+    return;
+  }
+  const double u0 = rng_double(E.rng, E.lane);
+  if (u0 > p.null_prob) {
+    const double u1 = rng_double(E.rng, E.lane);
+    theta = p.contract_low + (p.contract_high - p.contract_low) * u1;
+  } else {
+    theta = p.contract_low;
+  }
+}
+
+// MapEnv.reset + CleanupEnv/HarvestEnv.reset + wrapper reset (state ends up in E / LDS)
+template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, double& theta, u32& t, u32& fault) {
+  typedef Geo<KIND> G;
+  if (!setup_agents(E, 20)) fault |= CE_FAULT_NO_SPAWN;
+  if (!E.is_agent) E.P = 0xffffu;
+  wave_sync();
+  {  // reset_map + custom_reset: the static padded base map
+    const u32* src = (const u32*)c_tab[KIND].base_pmap;
+    u32* dst = (u32*)E.L->pmap;
+    for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k];
+  }
+  wave_sync();
+  zero_metrics(E, p);
+  custom_map_update(E);
+  t = 0;
+  sample_theta(E, p, theta);
+}
+
+// ----------------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------------
+constexpr int kWavesPerBlock = 4;
+
+template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds) {
+  const u32 wave = threadIdx.x >> 6;
+  E.lane = lane_id();
+  E.e = rfl(blockIdx.x * kWavesPerBlock + wave);
+  E.n = p.n;
+  E.is_agent = E.lane < E.n;
+  E.L = lds + wave;
+  return E.e < p.E;
+}
+
+// --- seed + "construct": replay the RNG use of MapEnv.__init__ (map_env.py:122-131) ---
+template <int KIND> __global__ __launch_bounds__(256) void k_grid_construct(GridParams p) {
+  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
+  Env<KIND> E;
+  if (!env_begin(E, p, lds)) return;
+  if (p.mask && p.mask[E.e] == 0) return;
+  typedef Geo<KIND> G;
+  load_static(E);
+  load_rng(E, p);
+  E.SP = E.lane < 20 ? E.lane : 0;
+  E.WP0 = E.lane;
+  E.WP1 = E.lane + 64;
+  u32 fault = 0;
+  if (!setup_agents(E, (u32)G::NSPAWN_CTOR)) fault |= CE_FAULT_NO_SPAWN;
+  zero_pmap(E);  // world_map is blank until the first reset
+  store_grid(E, p);
+  store_agents(E, p);
+  store_perms(E, p, true);
+  store_rng(E, p);
+  zero_metrics(E, p);
+  if (E.lane == 0) {
+    p.timestep[E.e] = 0;
+    p.theta[E.e] = 0.0;
+    p.done[E.e] = 0;
+    p.error_flags[E.e] = fault;
+  }
+}
+
+template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParams& p) {
+  if (E.is_agent) {
+    const size_t ia = (size_t)E.e * E.n + E.lane;
+    p.base_reward[ia] = 0;
+    p.reward[ia] = 0.0;
+    p.info[ia * 2] = 0;
+    p.info[ia * 2 + 1] = 0;
+    for (u32 k = 0; k < p.num_features; ++k) p.features[ia * p.num_features + k] = 0;
+  }
+}
+
+template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridParams p) {
+  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
+  Env<KIND> E;
+  if (!env_begin(E, p, lds)) return;
+  if (p.mask && p.mask[E.e] == 0) return;
+  load_static(E);
+  load_rng(E, p);
+  load_perms(E, p);
+  double theta = 0.0;
+  u32 t = 0, fault = 0;
+  reset_env(E, p, theta, t, fault);
+  store_grid(E, p);
+  store_agents(E, p);
+  store_perms(E, p, true);
+  store_rng(E, p);
+  clear_step_outputs(E, p);
+  write_obs(E, p, false);  // reset() does not paint the agents on the colour map
+  if (E.lane == 0) {
+    p.timestep[E.e] = 0;
+    p.theta[E.e] = theta;
+    p.done[E.e] = 0;
+    if (fault) p.error_flags[E.e] |= fault;
+  }
+}
+
+template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParams p) {
+  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
+  Env<KIND> E;
+  if (!env_begin(E, p, lds)) return;
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  const u32 lane = E.lane, n = E.n;
+  const size_t ia = (size_t)E.e * n + lane;
+
+  u32 ACT = E.is_agent ? (u32)p.actions[ia] : 4u;
+  const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
+  if (ballot(E.is_agent && ACT > max_action) != 0) {  // KeyError in the reference (Agent.py:174,213)
+    if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
+    return;
+  }
+  load_static(E);
+  load_rng(E, p);
+  load_grid(E, p);
+  load_agents(E, p);
+  load_perms(E, p);
+  u32 t = (u32)p.timestep[E.e];
+  double theta = p.theta[E.e];
+  u32 fault = 0;
+  uint8_t* pm = E.L->pmap;
+
+  // ---------------- MapEnv.step ----------------
+  t += 1;
+  update_moves(E, ACT);
+  if (!E.is_agent) E.P = 0xffffu;
+
+  // eaten_apples: final position held an apple when the step was entered (nothing has touched
+  // the map yet, so the pre-consume map IS the reference's current_apple_points)
+  const bool onA = E.is_agent && pm[E.is_agent ? E.P : 0] == CE_CELL_APPLE;
+  u32 eaten = onA ? 1u : 0u, eaten_close = 0, cleaned = 0;
+  if (KIND == CE_KIND_HARVEST) {
+    for (u64 om = ballot(onA); om; om &= om - 1) {  // count_apples_in_radius(5, pos) < 4
+      const u32 a = ctz64(om);
+      const u32 pa = rdl(E.P, a);
+      const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+      const u32 cnt = popc64(ballot(v));
+      if (lane == a && cnt < 4) eaten_close = 1;
+    }
+  }
+  {  // consume in agent order: the first agent on the cell gets the apple
+    bool first = true;
+    for (u32 b = 0; b < n; ++b) {
+      const u32 pb = rdl(E.P, b);
+      if (lane > b && E.P == pb) first = false;
+    }
+    if (onA && first) E.RW += 1;
+    wave_sync();
+    if (onA) pm[E.P] = CE_CELL_EMPTY;
+    wave_sync();
+  }
+  {  // update_custom_moves: always shuffles the n ids, then fires in that order
+    u32 IDS = lane;
+    shuffle_lanes1(E.rng, IDS, n, lane);
+    if (ballot(E.is_agent && ACT >= 7) != 0) {
+      for (u32 k = 0; k < n; ++k) {
+        const u32 a = rdl(IDS, k);
+        const u32 act = rdl(ACT, a);
+        if (act < 7) continue;
+        if (KIND == CE_KIND_CLEANUP && act == 7) {
+          const u32 c = fire_beam(E, a, true);
+          if (lane == a) cleaned = c;
+        } else {
+          if (lane == a) E.RW -= 1;  // fire_beam(b"F")
+          fire_beam(E, a, false);
+        }
+      }
+    }
+  }
+  custom_map_update(E);
+
+  // ---------------- rewards ----------------
+  i32 base_rew = E.is_agent ? E.RW : 0;
+  E.RW = 0;
+  if (p.flags & CE_FLAG_COLLECTIVE_REWARD) {
+    i32 s = 0;
+    for (u32 b = 0; b < n; ++b) s += shfl_i32(base_rew, b);
+    base_rew = s;
+  }
+  double rew = (double)base_rew;
+  if (p.flags & CE_FLAG_INEQUITY_AVERSE) {
+    long long pos = 0, neg = 0;
+    for (u32 b = 0; b < n; ++b) {
+      const i32 d = shfl_i32(base_rew, b) - base_rew;
+      if (d > 0) pos += d;
+      if (d < 0) neg += d;
+    }
+    const double dis = p.alpha * (double)pos, adv = p.beta * (double)neg;
+    rew = (double)base_rew - (dis + adv) / (double)(n - 1);
+  }
+
+  // ---------------- infos, metrics, feature obs ----------------
+  const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
+  int64_t* mi = p.int_metrics + (size_t)E.e * nmi;
+  double* mf = p.f64_metrics + (size_t)E.e * nmf;
+  {
+    u32 sum_eaten = 0, sum_clean = 0, sum_close = 0;
+    i32 sum_rew = 0;
+    for (u32 b = 0; b < n; ++b) {
+      sum_eaten += rdl(eaten, b);
+      sum_clean += rdl(cleaned, b);
+      sum_close += rdl(eaten_close, b);
+      sum_rew += shfl_i32(base_rew, b);
+    }
+    if (lane == 0) {
+      mi[CE_MI_TOTAL_APPLES_EATEN] += sum_eaten;
+      mi[CE_MI_RAW_ENV_REWARDS] += sum_rew;
+      if (KIND == CE_KIND_CLEANUP) mi[CE_MI_DIRT_CLEANED] += sum_clean;
+      else mi[CE_MI_LOW_DENSITY_APPLES] += sum_close;
+    }
+    if (E.is_agent) {
+      mi[CE_MI_AGENT(n, CE_MIA_A, lane)] += KIND == CE_KIND_CLEANUP ? cleaned : eaten;
+      if (KIND == CE_KIND_HARVEST) mi[CE_MI_AGENT(n, CE_MIA_B, lane)] += eaten_close;
+      mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] += base_rew;
+      mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] += (long long)(t - 1) * base_rew;
+    }
+  }
+  // feature obs
+  u32 feat8 = 0;
+  {
+    const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
+    const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
+    const u32 myrow = row_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+    const u32 mycol = col_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+    const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
+    bool aflag[3];
+    u32 napples = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      aflag[r] = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r])] == CE_CELL_APPLE;
+      napples += popc64(ballot(aflag[r]));
+    }
+    bool wflag[2] = {false, false};
+    u32 nwaste = 0;
+    if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        wflag[r] = lane + 64 * r < (u32)G::NWASTE && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE;
+        nwaste += popc64(ballot(wflag[r]));
+      }
+    }
+    u32 ca_r = 0, ca_c = 0, cw_r = 0, cw_c = 0, close_now = 0;
+    for (u32 a = 0; a < n; ++a) {
+      const u32 pa = rdl(E.P, a);
+      const i32 ar = (i32)row_of<KIND>(pa), ac = (i32)col_of<KIND>(pa);
+      u32 key = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (64 * r < G::NAPPLE) {
+          const i32 d = abs((i32)cell_row(E.AP[r]) - ar) + abs((i32)cell_col(E.AP[r]) - ac);
+          const u32 k2 = aflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
+          key = k2 < key ? k2 : key;
+        }
+      }
+      const u32 best = wave_min_u32(key);
+      u32 br = 0, bc = 0;
+      if (best != 0xffffffffu) {
+        const u32 cellp = T.apple[best & 0xffu];
+        br = cell_row(cellp);
+        bc = cell_col(cellp);
+      }
+      if (lane == a) { ca_r = br; ca_c = bc; }
+      if (KIND == CE_KIND_CLEANUP) {
+        u32 keyw = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const i32 d = abs((i32)cell_row(E.WS[r]) - ar) + abs((i32)cell_col(E.WS[r]) - ac);
+          const u32 k2 = wflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
+          keyw = k2 < keyw ? k2 : keyw;
+        }
+        const u32 bw = wave_min_u32(keyw);
+        u32 wr = 0, wc = 0;
+        if (bw != 0xffffffffu) {
+          const u32 cellp = T.waste[bw & 0xffu];
+          wr = cell_row(cellp);
+          wc = cell_col(cellp);
+        }
+        if (lane == a) { cw_r = wr; cw_c = wc; }
+      } else {
+        const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+        const u32 cnt = popc64(ballot(v));
+        if (lane == a) close_now = cnt;
+      }
+    }
+    feat8 = close_now;
+    if (KIND == CE_KIND_CLEANUP) {
+      for (u32 b = 0; b < n; ++b) {
+        const u32 cb = rdl(cleaned, b);
+        if (E.is_agent) p.features[ia * p.num_features + 12 + b] = (int16_t)cb;
+      }
+    }
+    if (E.is_agent) {
+      int16_t* f = p.features + ia * p.num_features;
+      f[0] = (int16_t)myrow;
+      f[1] = (int16_t)mycol;
+      f[2] = (int16_t)E.O;
+      f[3] = (int16_t)row_of<KIND>(cpp);
+      f[4] = (int16_t)col_of<KIND>(cpp);
+      f[5] = (int16_t)cpo;
+      f[6] = (int16_t)ca_r;
+      f[7] = (int16_t)ca_c;
+      if (KIND == CE_KIND_CLEANUP) {
+        f[8] = (int16_t)cw_r;
+        f[9] = (int16_t)cw_c;
+        f[10] = (int16_t)napples;
+        f[11] = (int16_t)nwaste;
+      } else {
+        f[8] = (int16_t)close_now;
+        f[9] = (int16_t)napples;
+        for (u32 b = 0; b < 2 * n; ++b) f[10 + b] = 0;
+      }
+    }
+  }
+
+  // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
+  if (p.contract != CE_CONTRACT_NONE) {
+    double tr;
+    if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;  // contract_list.py:26
+    else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
+    double total = 0.0;
+    const double nm1 = (double)(n - 1);
+    for (u32 i = 0; i < n; ++i) {
+      const double ti = shfl_f64(tr, i);
+      if (lane == i) rew -= ti;
+      else rew += ti / nm1;
+      total += ti;
+    }
+    if (lane == 0) mf[CE_MF_TRANSFERS] += total;
+    if (E.is_agent) {
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] += rew;
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] += (double)(t - 1) * rew;
+    }
+  }
+  const bool done = t == p.horizon;
+  if (E.is_agent) {
+    p.base_reward[ia] = base_rew;
+    p.reward[ia] = rew;
+    p.info[ia * 2] = (uint8_t)eaten;
+    p.info[ia * 2 + 1] = (uint8_t)(KIND == CE_KIND_CLEANUP ? cleaned : eaten_close);
+  }
+
+  bool did_reset = false;
+  if (done) {
+    // equality / sustainability (cleanup_new.py:422-445) and their transferred versions
+    __threadfence_block();
+    const long long sr = E.is_agent ? mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane < n ? lane : 0)] : 0;
+    const long long str_ = E.is_agent ? mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane < n ? lane : 0)] : 0;
+    long long eq = 0, total = 0;
+    for (u32 i = 0; i < n; ++i) {
+      const long long ri = shfl_i64(sr, i);
+      for (u32 j = 0; j < n; ++j) {
+        const long long d = ri - shfl_i64(sr, j);
+        eq += d < 0 ? -d : d;
+      }
+      total += ri;
+    }
+    const double ts = total == 0 ? 0.001 : (double)total;
+    const double equality = 1.0 - (double)eq / ((double)(2 * n) * ts);
+    const long long den = sr < 1 ? 1 : sr;
+    const double sust = np_sum_lanes((double)str_ / (double)den, n) / (double)n;
+    double teq = 0.0, tsust = 0.0;
+    if (p.contract != CE_CONTRACT_NONE) {
+      const double fr = E.is_agent ? mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane < n ? lane : 0)] : 0.0;
+      const double ftr = E.is_agent ? mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane < n ? lane : 0)] : 0.0;
+      double e2 = 0.0, tot = 0.0;
+      for (u32 i = 0; i < n; ++i) {
+        const double ri = shfl_f64(fr, i);
+        for (u32 j = 0; j < n; ++j) e2 += fabs(ri - shfl_f64(fr, j));
+        tot += ri;
+      }
+      if (tot == 0.0) tot = 0.001;
+      teq = 1.0 - e2 / ((double)(2 * n) * tot);
+      const double dn = fr > 1.0 ? fr : 1.0;
+      tsust = np_sum_lanes(ftr / dn, n) / (double)n;
+    }
+    if (lane == 0) {
+      mf[CE_MF_EQUALITY] = equality;
+      mf[CE_MF_SUSTAINABILITY] = sust;
+      mf[CE_MF_TRANSFER_EQUALITY] = teq;
+      mf[CE_MF_TRANSFER_SUSTAINABILITY] = tsust;
+    }
+    __threadfence_block();
+    for (u32 k = lane; k < nmi; k += 64) p.final_int_metrics[(size_t)E.e * nmi + k] = mi[k];
+    for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
+    if (p.flags & CE_FLAG_AUTO_RESET) {
+      __threadfence_block();
+      reset_env(E, p, theta, t, fault);
+      did_reset = true;
+    }
+  }
+
+  // ---------------- state out, then the observation ----------------
+  store_grid(E, p);
+  store_agents(E, p);
+  store_perms(E, p, did_reset);
+  store_rng(E, p);
+  if (lane == 0) {
+    p.timestep[E.e] = (i32)t;
+    p.done[E.e] = done ? 1 : 0;
+    if (did_reset) p.theta[E.e] = theta;
+    if (fault) p.error_flags[E.e] |= fault;
+  }
+  write_obs(E, p, !did_reset);
+}
+
+// ----------------------------------------------------------------------------------------
+// MT seeding: one thread per env (sequential recurrence), numpy init_genrand or CPython
+// init_by_array([seed])
+// ----------------------------------------------------------------------------------------
+__global__ void k_mt_seed(u32* rng, u32 stride, u32 block_off, const u64* seeds, const uint8_t* mask, u32 E, int python_seeding) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (mask && mask[e] == 0) return;
+  u32* mt = rng + (size_t)e * stride + block_off;
+  const u32 seed = (u32)seeds[e];
+  u32 s = python_seeding ? 19650218u : seed;
+  for (u32 i = 0; i < (u32)kMtN; ++i) {
+    mt[i] = s;
+    s = 1812433253u * (s ^ (s >> 30)) + i + 1u;
+  }
+  if (python_seeding) {
+    u32 i = 1;
+    for (u32 k = kMtN; k; --k) {  // key_length = 1, j stays 0
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + seed + 0u;
+      ++i;
+      if (i >= (u32)kMtN) {
+        mt[0] = mt[kMtN - 1];
+        i = 1;
+      }
+    }
+    for (u32 k = kMtN - 1; k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - i;
+      ++i;
+      if (i >= (u32)kMtN) {
+        mt[0] = mt[kMtN - 1];
+        i = 1;
+      }
+    }
+    mt[0] = 0x80000000u;
+  }
+  mt[kMtN] = kMtN;  // pos: state exhausted, first draw twists
+  mt[kMtN + 1] = mt[kMtN + 2] = mt[kMtN + 3] = 0;
+}
+
+__global__ void k_synth_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions) {
+  const size_t total = (size_t)T * E * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const u32 a = (u32)(i % n);
+    const size_t r = i / n;
+    const u32 e = (u32)(r % E);
+    const u32 t = (u32)(r / E);
+    out[i] = (uint8_t)synth_action(key, env_base + e, t0 + t, a, num_actions);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// self-test of the wave primitives (ce_selftest): bit i of out[0] set = check i failed
+// ----------------------------------------------------------------------------------------
+__global__ void k_selftest(u32* out) {
+  __shared__ u32 mt[kMtN];
+  __shared__ u32 ref[kMtN];
+  const u32 lane = lane_id();
+  u32 fail = 0;
+  // (0) wave_min_u32 against a shuffle butterfly
+  for (u32 round = 0; round < 8; ++round) {
+    u32 v = (lane * 2654435761u + round * 40503u) ^ (round << 20);
+    if (round == 3) v = 0xffffffffu;
+    if (round == 4) v = lane == 63 ? 5u : 0xffffffffu;
+    if (round == 5) v = lane == 0 ? 7u : 0xffffffffu;
+    u32 b = v;
+    for (int s = 1; s < 64; s <<= 1) {
+      u32 o = bperm(b, lane ^ s);
+      b = o < b ? o : b;
+    }
+    if (wave_min_u32(v) != rfl(b)) fail |= 1u;
+  }
+  // (1) parallel twist against the sequential recurrence
+  for (u32 k = lane; k < (u32)kMtN; k += 64) {
+    u32 s = 1234567u + k * 2246822519u;
+    s ^= s >> 15;
+    mt[k] = s;
+    ref[k] = s;
+  }
+  wave_sync();
+  if (lane == 0) {
+    for (int i = 0; i < kMtN; ++i) {
+      u32 y = (ref[i] & 0x80000000u) | (ref[(i + 1) % kMtN] & 0x7fffffffu);
+      ref[i] = ref[(i + kMtM) % kMtN] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
+  wave_sync();
+  mt_twist(mt, lane);
+  bool bad = false;
+  for (u32 k = lane; k < (u32)kMtN; k += 64) bad = bad || (mt[k] != ref[k]);
+  if (ballot(bad)) fail |= 2u;
+  // (2) readlane / writelane list swap
+  {
+    u32 L0 = lane, L1 = lane + 64;
+    u32 vi = rdl(L0, 5), vj = rdl(L1, 3);
+    L0 = wrl(vj, 5, L0);
+    L1 = wrl(vi, 3, L1);
+    if (ballot((lane == 5 && L0 != 67) || (lane == 3 && L1 != 5) || (lane != 5 && L0 != lane)) != 0) fail |= 4u;
+  }
+  if (lane == 0) out[0] = fail;
+}
+
+// ----------------------------------------------------------------------------------------
+// host launchers
+// ----------------------------------------------------------------------------------------
+int upload_grid_tables(int kind, const GridTables& t, const uint16_t* pix, int npix, const u32* rgb16) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(GridTables), sizeof(GridTables) * kind) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_pix), pix, sizeof(uint16_t) * npix) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_rgb), rgb16, sizeof(u32) * 16) != hipSuccess) return -1;
+  return 0;
+}
+
+void launch_mt_seed(u32* rng, u32 stride_words, u32 block_offset_words, const u64* seeds_dev, const uint8_t* mask_dev,
+                    u32 E, int python_seeding, void* stream) {
+  hipLaunchKernelGGL(k_mt_seed, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, rng, stride_words,
+                     block_offset_words, seeds_dev, mask_dev, E, python_seeding);
+}
+
+#define CE_LAUNCH_GRID(kern)                                                                          \
+  do {                                                                                                \
+    dim3 grid((p.E + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);               \
+    if (kind == CE_KIND_CLEANUP)                                                                      \
+      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, 0, (hipStream_t)stream, p);              \
+    else                                                                                              \
+      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, 0, (hipStream_t)stream, p);              \
+  } while (0)
+
+void launch_grid_construct(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
+void launch_grid_reset(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
+void launch_grid_step(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+
+void launch_synth_actions_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions,
+                             void* stream) {
+  hipLaunchKernelGGL(k_synth_u8, dim3(2048), dim3(256), 0, (hipStream_t)stream, out, key, env_base, E, n, t0, T,
+                     num_actions);
+}
+
+int launch_selftest(u32* out_dev, void* stream) {
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev);
+  return 0;
+}
+
+}  // namespace ce

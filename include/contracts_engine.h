@@ -95,23 +95,29 @@ typedef struct ce_buffers {
                                     (harvest_new.py:215-222), 2n+7 selfdrive obs length    */
   uint32_t num_int_metrics;      /* see CE_MI_* / CE_MIA_*                                  */
   uint32_t num_f64_metrics;      /* see CE_MF_*                                            */
+  uint32_t obs_env_stride;       /* bytes between consecutive envs in `obs`:
+                                    round_up(n*675, 4) (== n*675 when n is a multiple of 4) */
+  uint32_t rng_words;            /* CE_RNG_WORDS_GRID / CE_RNG_WORDS_SELFDRIVE             */
+  uint32_t grid_env_stride;      /* bytes between consecutive envs in `grid` (H*W rounded up
+                                    to 16: 464 cleanup, 608 harvest)                       */
+  uint32_t reserved0;
 
   /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
-  uint8_t* grid;        /* [E][H*W]   cell codes CE_CELL_*                                  */
+  uint8_t* grid;        /* [E] x grid_env_stride, each env holding [H][W] cell codes CE_CELL_* */
   uint8_t* agents;      /* [E][n][4]  row, col, orientation (UP0 RIGHT1 DOWN2 LEFT3,
                                       Agent.py:18-23), 0                                   */
   uint8_t* spawn_perm;  /* [E][20]    persistent shuffled spawn list (map_env.py:821) as
                                       indices into the static P-cell table                 */
   uint8_t* waste_perm;  /* [E][119]   cleanup only: persistent shuffled waste list
                                       (cleanup_new.py:339) as indices into the static table */
-  uint32_t* rng;        /* [E][RNG_WORDS] numpy legacy MT19937 key[624] + pos (+ Python
-                                      `random` MT for selfdrive, second 625-word block)    */
+  uint32_t* rng;        /* [E][CE_RNG_WORDS_*] numpy legacy MT19937 key[624], pos, pad[3]
+                                      (+ Python `random` MT for selfdrive, second 628-word block) */
   int32_t* timestep;    /* [E]        MapEnv.timesteps                                      */
   double* theta;        /* [E]        contract parameter of the episode                     */
   double* sd_state;     /* selfdrive: [E][CE_SD_STATE_DOUBLES(n)]                           */
 
   /* ---- per-step outputs ---- */
-  uint8_t* obs;          /* [E][n][15][15][3] uint8                                         */
+  uint8_t* obs;          /* [E] x obs_env_stride bytes, each env holding [n][15][15][3] uint8 */
   double* obs_f64;       /* selfdrive: [E][n][2n+7]                                         */
   int32_t* base_reward;  /* [E][n]  MapEnv reward before the contract (ints, Agent.py:87)   */
   double* reward;        /* [E][n]  reward after the contract transfer
@@ -167,8 +173,8 @@ typedef struct ce_buffers {
  * n_crossed, crossed[n] (agent indices in crossing order), transfers metric */
 #define CE_SD_STATE_DOUBLES(n) (5 * (n) + 3)
 
-#define CE_RNG_WORDS_GRID 625u       /* key[624] + pos                                      */
-#define CE_RNG_WORDS_SELFDRIVE 1250u /* numpy MT then Python `random` MT                    */
+#define CE_RNG_WORDS_GRID 628u       /* key[624], pos, 3 pad words (16-byte aligned rows)   */
+#define CE_RNG_WORDS_SELFDRIVE 1256u /* numpy MT block then Python `random` MT block        */
 
 #define CE_FAULT_BAD_ACTION 0x1u     /* action id outside the family's table (Agent.py:161,198)
                                         — the reference raises KeyError                     */
@@ -207,6 +213,10 @@ int ce_reset(ce_handle h, const uint8_t* mask, void* stream);
  * not done act, which is what RLlib sends).  Asynchronous on `stream` (hipStream_t). */
 int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream);
 
+/* Same as ce_step with HOST action / active pointers: they are copied to an engine-owned
+ * staging buffer on `stream` first (the per-env adapters use this). */
+int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream);
+
 /* Synthetic uniform i.i.d. actions for benchmarks, generated on device by a counter-based
  * hash keyed (key, global env index, t, agent) — reproducible on host (ce_synth_action_host).
  * out: DEVICE pointer, uint8 [T][E][n] (grid) or float [T][E][n] (selfdrive). */
@@ -229,6 +239,13 @@ int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_c
  * step-kernel duration in milliseconds and the number of launches measured. */
 int ce_timing_begin(ce_handle h, void* stream);
 int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches);
+
+/* Device self-test of the wave primitives the kernels rely on (DPP reduction, parallel MT
+ * twist, cross-lane list swap).  failed_mask: bit i set = check i failed.  0 on success. */
+int ce_selftest(int device, uint32_t* failed_mask);
+
+/* 64-bit counter hash behind ce_synth_actions (selfdrive: action = ((hash>>40) / 2^24) * 0.2f - 0.1f) */
+uint64_t ce_synth_hash_host(uint64_t key, uint64_t env_index, uint32_t t, uint32_t agent);
 
 const char* ce_last_error(ce_handle h);
 

@@ -450,7 +450,7 @@ static void cell_rgb_with_agents(const orc_t* o, const env_t* e, int r, int c, i
 
 static void write_obs(orc_t* o, env_t* e, int ei, int paint_agents) {
   for (int a = 0; a < o->n; a++) {
-    uint8_t* out = o->b.obs + ((size_t)ei * o->n + a) * (WIN * WIN * 3);
+    uint8_t* out = o->b.obs + (size_t)ei * o->b.obs_env_stride + (size_t)a * (WIN * WIN * 3);
     int row = e->pos[a].row, col = e->pos[a].col;
     for (int i = 0; i < WIN; i++)
       for (int j = 0; j < WIN; j++) {
@@ -808,8 +808,8 @@ static void export_state(orc_t* o, int ei) {
   memcpy(rw, e->np_rng.key, 624 * 4);
   rw[624] = e->np_rng.pos;
   if (o->kind == CE_KIND_SELFDRIVE) {
-    memcpy(rw + 625, e->py_rng.key, 624 * 4);
-    rw[625 + 624] = e->py_rng.pos;
+    memcpy(rw + CE_RNG_WORDS_GRID, e->py_rng.key, 624 * 4);
+    rw[CE_RNG_WORDS_GRID + 624] = e->py_rng.pos;
   }
 }
 
@@ -1382,16 +1382,20 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     o->b.grid_h = o->H;
     o->b.grid_w = o->W;
     o->b.obs_bytes_per_agent = WIN * WIN * 3;
+    o->b.obs_env_stride = (uint32_t)((n * WIN * WIN * 3 + 3) / 4 * 4);
+    o->b.rng_words = CE_RNG_WORDS_GRID;
+    o->b.grid_env_stride = (uint32_t)o->cells;
     o->b.num_features = o->kind == CE_KIND_CLEANUP ? 12 + n : 10 + 2 * n;
     ALLOC(grid, uint8_t, E * o->cells);
     ALLOC(agents, uint8_t, E * n * 4);
     ALLOC(spawn_perm, uint8_t, E * 20);
     ALLOC(waste_perm, uint8_t, E * 119);
     ALLOC(rng, uint32_t, E * CE_RNG_WORDS_GRID);
-    ALLOC(obs, uint8_t, E * n * WIN * WIN * 3);
+    ALLOC(obs, uint8_t, E * o->b.obs_env_stride);
     ALLOC(features, int16_t, E * n * o->b.num_features);
   } else {
     o->b.num_features = 2 * n + 7;
+    o->b.rng_words = CE_RNG_WORDS_SELFDRIVE;
     ALLOC(rng, uint32_t, E * CE_RNG_WORDS_SELFDRIVE);
     ALLOC(sd_state, double, E * CE_SD_STATE_DOUBLES(n));
     ALLOC(obs_f64, double, E * n * (2 * n + 7));
@@ -1504,8 +1508,8 @@ int orc_import_state(orc_t* o, uint32_t ei) {
   memcpy(e->np_rng.key, rw, 624 * 4);
   e->np_rng.pos = rw[624];
   if (o->kind == CE_KIND_SELFDRIVE) {
-    memcpy(e->py_rng.key, rw + 625, 624 * 4);
-    e->py_rng.pos = rw[625 + 624];
+    memcpy(e->py_rng.key, rw + CE_RNG_WORDS_GRID, 624 * 4);
+    e->py_rng.pos = rw[CE_RNG_WORDS_GRID + 624];
   }
   return CE_OK;
 }

@@ -36,7 +36,8 @@ class CeBuffers(C.Structure):
     _fields_ = [
         ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("grid_h", C.c_uint32), ("grid_w", C.c_uint32),
         ("obs_bytes_per_agent", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
-        ("num_f64_metrics", C.c_uint32),
+        ("num_f64_metrics", C.c_uint32), ("obs_env_stride", C.c_uint32), ("rng_words", C.c_uint32),
+        ("grid_env_stride", C.c_uint32), ("reserved0", C.c_uint32),
         ("grid", _P), ("agents", _P), ("spawn_perm", _P), ("waste_perm", _P), ("rng", _P), ("timestep", _P),
         ("theta", _P), ("sd_state", _P),
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
@@ -117,22 +118,27 @@ def _view(ptr, dtype, shape):
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+def obs_view(raw, n):
+    """[E][obs_env_stride] raw bytes -> zero-copy [E][n][15][15][3] view"""
+    E, stride = raw.shape
+    return np.lib.stride_tricks.as_strided(raw, shape=(E, n, 15, 15, 3), strides=(stride, 675, 45, 3, 1), writeable=False)
+
+
 def buffer_views(b, kind):
     """numpy views (host memory) with the shapes documented in include/contracts_engine.h"""
     E, n = b.num_envs, b.num_agents
     v = {}
     if kind != "selfdrive":
         cells = b.grid_h * b.grid_w
-        v["grid"] = _view(b.grid, np.uint8, (E, b.grid_h, b.grid_w))
+        v["grid"] = _view(b.grid, np.uint8, (E, b.grid_env_stride))[:, :cells].reshape(E, b.grid_h, b.grid_w)
         v["agents"] = _view(b.agents, np.uint8, (E, n, 4))
         v["spawn_perm"] = _view(b.spawn_perm, np.uint8, (E, 20))
         v["waste_perm"] = _view(b.waste_perm, np.uint8, (E, 119))
-        v["rng"] = _view(b.rng, np.uint32, (E, 625))
-        v["obs"] = _view(b.obs, np.uint8, (E, n, 15, 15, 3))
+        v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
+        v["obs"] = obs_view(_view(b.obs, np.uint8, (E, b.obs_env_stride)), n)
         v["features"] = _view(b.features, np.int16, (E, n, b.num_features))
-        del cells
     else:
-        v["rng"] = _view(b.rng, np.uint32, (E, 1250))
+        v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
         v["sd_state"] = _view(b.sd_state, np.float64, (E, 5 * n + 3))
         v["obs_f64"] = _view(b.obs_f64, np.float64, (E, n, 2 * n + 7))
         v["done_agents"] = _view(b.done_agents, np.uint8, (E, n))

@@ -1,0 +1,19 @@
+"""CPU: the oracle (oracle/oracle.c) against every golden fixture produced by the reference.
+This is the pin that makes the oracle trustworthy as the GPU parity checker."""
+import pytest
+
+import golden_check as gc
+from oracle.pyoracle import Oracle
+
+
+@pytest.mark.parametrize("name", [f for f in gc.fixtures("g") if "selfdrive" not in f])
+def test_oracle_grid_golden(name):
+    g = gc.load(name)
+    kind, n, kw = gc.grid_kwargs(g)
+    gc.replay_grid(g, Oracle(kind, 2, n, **kw), env=1)
+
+
+@pytest.mark.parametrize("name", gc.fixtures("g5_selfdrive"))
+def test_oracle_selfdrive_golden(name):
+    g = gc.load(name)
+    gc.replay_selfdrive(g, Oracle("selfdrive", 2, int(g["n"]), contract="selfdrive_distprop"), env=1)
