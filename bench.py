@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the rollout hot path on MI355X.
+
+Workload (BASELINE.json north star / configs[3]): CleanupEnv `cleanup_new`, 8 agents, CleanupContract,
+16384 env replicas per GPU (131072 over 8 GPUs; weak scaling, plain shard of the env axis, no
+collectives), horizon 1000 with in-engine auto-reset, uniform i.i.d. synthetic actions generated on
+device by the counter hash keyed (seed, global env index, t, agent) and resident in HBM before the
+timed region.  A "step" = one ce_step launch over the whole env batch of this rank (MapEnv.step +
+obs crop + contract transfer for every env).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 16384
+N_AGENTS = 8
+SEED0 = 73907  # the reference's seed multiplier (runner.py:130)
+# algorithmic bytes per env-step, cleanup n=8 (state read+written once, uint8 obs)
+ALGO_BYTES_PER_ENV_STEP = 7235
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--agents", type=int, default=N_AGENTS)
+    ap.add_argument("--kind", default="cleanup", choices=["cleanup", "harvest"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(kind, n, contract, target_s):
+    """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this
+    box's host cores with OpenMP over envs: a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle
+    threads = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    E = 256 * threads
+    orc = Oracle(kind, E, n, contract=contract, horizon=1000, auto_reset=True)
+    orc.seed(seed0=SEED0)
+    orc.reset()
+    rs = np.random.RandomState(1)
+    na = 8 if kind == "cleanup" else 7
+    acts = rs.randint(na, size=(32, E, n)).astype(np.uint8)
+    for t in range(8):
+        orc.step(acts[t % 32])
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(8):
+            orc.step(acts[steps % 32])
+            steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_s:
+            break
+    return {"value": E * n * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d steps, %s n=%d + contract, auto-reset, OpenMP over envs, %.1f s"
+                      % (E, steps, kind, n, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(a.gpus, 1):
+        if rank == 0 and world == 1 and a.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
+            sys.exit(2)
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from contracts_amd.engine import BatchedEnv
+    kind, n, E = a.kind, a.agents, a.envs_per_gpu
+    contract = "cleanup" if kind == "cleanup" else "harvest_local"
+    env = BatchedEnv(kind, E, n, contract=contract, horizon=1000, auto_reset=True, device=local_rank,
+                     env_index_base=rank * E)
+    env.seed(seed0=SEED0)  # env b (global index) is seeded SEED0 + b: results independent of GPU count
+    env.reset()
+    K, W = a.steps, a.warmup
+    # synthetic inputs: all K+W action planes resident in HBM before timing
+    acts = torch.empty((W + K, E, n), dtype=torch.uint8, device="cuda")
+    env.synth_actions(SEED0 + 1, 0, W + K, acts.data_ptr())
+    env.synchronize()
+    plane = E * n
+    base = acts.data_ptr()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(W):
+        env.step_device(base + t * plane)
+    barrier()
+    env.timing_begin()  # HIP events on the launch stream (the null stream the engine launches on)
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        env.step_device(base + t * plane)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    kernel_ms, launches = env.timing_end()
+    barrier()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    env.check_faults()
+    # sanity statistics of the simulated workload (not timed)
+    mi = env.download("int_metrics")
+    stats = {"apples_eaten_running_episode_mean": float(mi[:, 0].mean()), "dirt_cleaned_mean": float(mi[:, 2].mean())}
+
+    if rank == 0:
+        total_agent_steps = world * E * n * K
+        value = total_agent_steps / elapsed
+        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * E if (kind == "cleanup" and n == 8) else None
+        roof = None
+        if algo_bytes_launch:
+            achieved = algo_bytes_launch / (kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("envs") == E and tj.get("agents") == n and tj.get("kind") == kind:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": "k_grid_step<%s>" % kind, "kernel_ms": kernel_ms, "launches": launches,
+                    "algorithmic_bytes_per_launch": algo_bytes_launch}
+        out = {
+            "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "cleanup_new 8 agents + CleanupContract, %d envs/GPU, horizon 1000, auto-reset" % E
+                       if kind == "cleanup" else "harvest_new %d agents + HarvestFeaturemodLocalContract, %d envs/GPU" % (n, E),
+                       "envs_per_gpu": E, "agents": n, "global_envs": world * E, "rng": "mt19937-numpy-compat",
+                       "parallelism": "env-shard x%d, no collectives" % world, "sanity": stats},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kind, n, contract, a.cpu_seconds)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
