@@ -53,6 +53,7 @@ EXPORTS = {
     "ce_device_count": (C.c_int, []),
     "ce_create": (C.c_int, [C.POINTER(CeConfig), C.POINTER(C.c_void_p)]),
     "ce_destroy": (C.c_int, [C.c_void_p]),
+    "ce_set_contract": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "ce_seed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "ce_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

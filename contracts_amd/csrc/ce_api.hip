@@ -271,6 +271,23 @@ extern "C" int ce_destroy(ce_handle h) {
   return CE_OK;
 }
 
+static int contract_ok(uint32_t kind, uint32_t contract) {
+  if (contract == CE_CONTRACT_NONE) return 1;
+  if (kind == CE_KIND_CLEANUP) return contract == CE_CONTRACT_CLEANUP;
+  if (kind == CE_KIND_HARVEST) return contract == CE_CONTRACT_HARVEST_LOCAL;
+  return contract == CE_CONTRACT_SELFDRIVE_DISTPROP;
+}
+
+extern "C" int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob) {
+  if (!h) return CE_EINVAL;
+  if (!contract_ok(h->cfg.kind, contract)) return fail(h, CE_EINVAL, "contract does not belong to this env family");
+  h->cfg.contract = contract;
+  h->cfg.contract_low = contract_low;
+  h->cfg.contract_high = contract_high;
+  h->cfg.null_prob = null_prob;
+  return CE_OK;
+}
+
 static GridParams grid_params(ce_engine* h) {
   GridParams p;
   std::memset(&p, 0, sizeof(p));
@@ -316,6 +333,7 @@ static SdParams sd_params(ce_engine* h) {
   p.rng = b.rng;
   p.theta = b.theta;
   p.obs_f64 = b.obs_f64;
+  p.base_reward = b.base_reward;
   p.reward = b.reward;
   p.done = b.done;
   p.done_agents = b.done_agents;
@@ -356,7 +374,7 @@ static int stage_mask(ce_engine* h, const uint8_t* mask, hipStream_t s, const ui
   return CE_OK;
 }
 
-extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int replay_constructor) {
+extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int mode) {
   if (!h) return CE_EINVAL;
   (void)hipSetDevice(h->cfg.device);
   const uint32_t E = h->cfg.num_envs;
@@ -373,16 +391,18 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
   const uint8_t* dmask;
   int rc = stage_mask(h, mask, nullptr, &dmask);
   if (rc) return rc;
+  if ((mode & (CE_SEED_RESEED | CE_SEED_CONSTRUCT)) == 0) return fail(h, CE_EINVAL, "ce_seed: empty mode");
+  const bool reseed = mode & CE_SEED_RESEED, replay_constructor = mode & CE_SEED_CONSTRUCT;
   if (is_grid(h->cfg)) {
-    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_GRID, 0, h->d_seeds, dmask, E, 0, nullptr);
+    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_GRID, 0, h->d_seeds, dmask, E, 0, nullptr);
     if (replay_constructor) {
       GridParams p = grid_params(h);
       p.mask = dmask;
       launch_grid_construct((int)h->cfg.kind, p, nullptr);
     }
   } else {
-    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
-    launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, CE_RNG_WORDS_GRID, h->d_seeds, dmask, E, 1, nullptr);
+    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
+    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, CE_RNG_WORDS_GRID, h->d_seeds, dmask, E, 1, nullptr);
     if (replay_constructor) {
       SdParams p = sd_params(h);
       p.mask = dmask;

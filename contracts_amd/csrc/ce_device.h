@@ -77,6 +77,7 @@ struct SdParams {
   uint32_t* rng;
   double* theta;
   double* obs_f64;
+  int32_t* base_reward;
   double* reward;
   uint8_t* done;
   uint8_t* done_agents;

@@ -792,6 +792,112 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
 }
 
 // ----------------------------------------------------------------------------------------
+// infos[k]['feature_obs'] (cleanup_new.py:243-251 / harvest_new.py:215-222), also the feature-mode
+// reset observation (cleanup_new.py:193-202).  Returns this lane's feature 8 (harvest
+// total_close_apples).  Apples / wastes only ever sit on the static apple / waste cells, so the
+// closest-cell searches scan those lists (2-3 lane rounds) instead of the whole map.
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, u32 cleaned) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  const u32 lane = E.lane, n = E.n;
+  const size_t ia = (size_t)E.e * n + lane;
+  uint8_t* pm = E.L->pmap;
+    const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
+    const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
+    const u32 myrow = row_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+    const u32 mycol = col_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+    const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
+    bool aflag[3];
+    u32 napples = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      aflag[r] = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r])] == CE_CELL_APPLE;
+      napples += popc64(ballot(aflag[r]));
+    }
+    bool wflag[2] = {false, false};
+    u32 nwaste = 0;
+    if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        wflag[r] = lane + 64 * r < (u32)G::NWASTE && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE;
+        nwaste += popc64(ballot(wflag[r]));
+      }
+    }
+    u32 ca_r = 0, ca_c = 0, cw_r = 0, cw_c = 0, close_now = 0;
+    for (u32 a = 0; a < n; ++a) {
+      const u32 pa = rdl(E.P, a);
+      const i32 ar = (i32)row_of<KIND>(pa), ac = (i32)col_of<KIND>(pa);
+      u32 key = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (64 * r < G::NAPPLE) {
+          const i32 d = abs((i32)cell_row(E.AP[r]) - ar) + abs((i32)cell_col(E.AP[r]) - ac);
+          const u32 k2 = aflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
+          key = k2 < key ? k2 : key;
+        }
+      }
+      const u32 best = wave_min_u32(key);
+      u32 br = 0, bc = 0;
+      if (best != 0xffffffffu) {
+        const u32 cellp = T.apple[best & 0xffu];
+        br = cell_row(cellp);
+        bc = cell_col(cellp);
+      }
+      if (lane == a) { ca_r = br; ca_c = bc; }
+      if (KIND == CE_KIND_CLEANUP) {
+        u32 keyw = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const i32 d = abs((i32)cell_row(E.WS[r]) - ar) + abs((i32)cell_col(E.WS[r]) - ac);
+          const u32 k2 = wflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
+          keyw = k2 < keyw ? k2 : keyw;
+        }
+        const u32 bw = wave_min_u32(keyw);
+        u32 wr = 0, wc = 0;
+        if (bw != 0xffffffffu) {
+          const u32 cellp = T.waste[bw & 0xffu];
+          wr = cell_row(cellp);
+          wc = cell_col(cellp);
+        }
+        if (lane == a) { cw_r = wr; cw_c = wc; }
+      } else {
+        const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+        const u32 cnt = popc64(ballot(v));
+        if (lane == a) close_now = cnt;
+      }
+    }
+    if (KIND == CE_KIND_CLEANUP) {
+      for (u32 b = 0; b < n; ++b) {
+        const u32 cb = rdl(cleaned, b);
+        if (E.is_agent) p.features[ia * p.num_features + 12 + b] = (int16_t)cb;
+      }
+    }
+    if (E.is_agent) {
+      int16_t* f = p.features + ia * p.num_features;
+      f[0] = (int16_t)myrow;
+      f[1] = (int16_t)mycol;
+      f[2] = (int16_t)E.O;
+      f[3] = (int16_t)row_of<KIND>(cpp);
+      f[4] = (int16_t)col_of<KIND>(cpp);
+      f[5] = (int16_t)cpo;
+      f[6] = (int16_t)ca_r;
+      f[7] = (int16_t)ca_c;
+      if (KIND == CE_KIND_CLEANUP) {
+        f[8] = (int16_t)cw_r;
+        f[9] = (int16_t)cw_c;
+        f[10] = (int16_t)napples;
+        f[11] = (int16_t)nwaste;
+      } else {
+        f[8] = (int16_t)close_now;
+        f[9] = (int16_t)napples;
+        for (u32 b = 0; b < 2 * n; ++b) f[10 + b] = 0;
+      }
+    }
+  return close_now;
+}
+
+// ----------------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------------
 constexpr int kWavesPerBlock = 4;
@@ -841,7 +947,6 @@ template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParam
     p.reward[ia] = 0.0;
     p.info[ia * 2] = 0;
     p.info[ia * 2 + 1] = 0;
-    for (u32 k = 0; k < p.num_features; ++k) p.features[ia * p.num_features + k] = 0;
   }
 }
 
@@ -861,6 +966,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridPara
   store_perms(E, p, true);
   store_rng(E, p);
   clear_step_outputs(E, p);
+  if (!E.is_agent) E.P = 0xffffu;
+  compute_features(E, p, 0u);
   write_obs(E, p, false);  // reset() does not paint the agents on the colour map
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
@@ -990,103 +1097,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
       mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] += (long long)(t - 1) * base_rew;
     }
   }
-  // feature obs
-  u32 feat8 = 0;
-  {
-    const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
-    const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
-    const u32 myrow = row_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
-    const u32 mycol = col_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
-    const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
-    bool aflag[3];
-    u32 napples = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      aflag[r] = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r])] == CE_CELL_APPLE;
-      napples += popc64(ballot(aflag[r]));
-    }
-    bool wflag[2] = {false, false};
-    u32 nwaste = 0;
-    if (KIND == CE_KIND_CLEANUP) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        wflag[r] = lane + 64 * r < (u32)G::NWASTE && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE;
-        nwaste += popc64(ballot(wflag[r]));
-      }
-    }
-    u32 ca_r = 0, ca_c = 0, cw_r = 0, cw_c = 0, close_now = 0;
-    for (u32 a = 0; a < n; ++a) {
-      const u32 pa = rdl(E.P, a);
-      const i32 ar = (i32)row_of<KIND>(pa), ac = (i32)col_of<KIND>(pa);
-      u32 key = 0xffffffffu;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (64 * r < G::NAPPLE) {
-          const i32 d = abs((i32)cell_row(E.AP[r]) - ar) + abs((i32)cell_col(E.AP[r]) - ac);
-          const u32 k2 = aflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
-          key = k2 < key ? k2 : key;
-        }
-      }
-      const u32 best = wave_min_u32(key);
-      u32 br = 0, bc = 0;
-      if (best != 0xffffffffu) {
-        const u32 cellp = T.apple[best & 0xffu];
-        br = cell_row(cellp);
-        bc = cell_col(cellp);
-      }
-      if (lane == a) { ca_r = br; ca_c = bc; }
-      if (KIND == CE_KIND_CLEANUP) {
-        u32 keyw = 0xffffffffu;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const i32 d = abs((i32)cell_row(E.WS[r]) - ar) + abs((i32)cell_col(E.WS[r]) - ac);
-          const u32 k2 = wflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
-          keyw = k2 < keyw ? k2 : keyw;
-        }
-        const u32 bw = wave_min_u32(keyw);
-        u32 wr = 0, wc = 0;
-        if (bw != 0xffffffffu) {
-          const u32 cellp = T.waste[bw & 0xffu];
-          wr = cell_row(cellp);
-          wc = cell_col(cellp);
-        }
-        if (lane == a) { cw_r = wr; cw_c = wc; }
-      } else {
-        const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
-        const u32 cnt = popc64(ballot(v));
-        if (lane == a) close_now = cnt;
-      }
-    }
-    feat8 = close_now;
-    if (KIND == CE_KIND_CLEANUP) {
-      for (u32 b = 0; b < n; ++b) {
-        const u32 cb = rdl(cleaned, b);
-        if (E.is_agent) p.features[ia * p.num_features + 12 + b] = (int16_t)cb;
-      }
-    }
-    if (E.is_agent) {
-      int16_t* f = p.features + ia * p.num_features;
-      f[0] = (int16_t)myrow;
-      f[1] = (int16_t)mycol;
-      f[2] = (int16_t)E.O;
-      f[3] = (int16_t)row_of<KIND>(cpp);
-      f[4] = (int16_t)col_of<KIND>(cpp);
-      f[5] = (int16_t)cpo;
-      f[6] = (int16_t)ca_r;
-      f[7] = (int16_t)ca_c;
-      if (KIND == CE_KIND_CLEANUP) {
-        f[8] = (int16_t)cw_r;
-        f[9] = (int16_t)cw_c;
-        f[10] = (int16_t)napples;
-        f[11] = (int16_t)nwaste;
-      } else {
-        f[8] = (int16_t)close_now;
-        f[9] = (int16_t)napples;
-        for (u32 b = 0; b < 2 * n; ++b) f[10 + b] = 0;
-      }
-    }
-  }
-
+  const u32 feat8 = compute_features(E, p, cleaned);
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   if (p.contract != CE_CONTRACT_NONE) {
     double tr;

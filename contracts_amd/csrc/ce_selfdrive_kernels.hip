@@ -192,6 +192,7 @@ template <int N> __global__ void k_sd_reset(SdParams p) {
 #pragma unroll
   for (int a = 0; a < N; ++a) {
     p.reward[(size_t)e * N + a] = 0.0;
+    p.base_reward[(size_t)e * N + a] = 0;
     p.info[((size_t)e * N + a) * 2] = 0;
     p.info[((size_t)e * N + a) * 2 + 1] = 0;
     p.done_agents[(size_t)e * N + a] = 0;
@@ -353,6 +354,8 @@ template <int N> __global__ void k_sd_step(SdParams p) {
     c.done_all = all_done;
     sd_write_obs(p, e, c, active, theta, 0.0);
   }
+#pragma unroll
+  for (int k = 0; k < N; ++k) p.base_reward[(size_t)e * N + k] = active[k] ? (int32_t)rews[k] : 0;  // -1 / -100 / -10000
   // SelfdriveContractDistprop.compute_transfer on a0's observation (contract_list.py:69-102)
   if (p.contract == CE_CONTRACT_SELFDRIVE_DISTPROP) {
     // ob0[2+i] = pos_i - pos_0 as written above (for the crash branch: the OLD positions)

@@ -95,13 +95,27 @@ class BatchedEnv:
         except Exception:
             pass
 
+    def set_contract(self, contract, low=None, high=None, null_prob=0.0):
+        lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
+        lo = lo if low is None else float(low)
+        hi = hi if high is None else float(high)
+        check(self._L.ce_set_contract(self._h, _lib.CONTRACT[contract], lo, hi, float(null_prob)), self._h,
+              "ce_set_contract")
+        self.cfg.contract, self.cfg.contract_low, self.cfg.contract_high = _lib.CONTRACT[contract], lo, hi
+        self.cfg.null_prob = float(null_prob)
+
     # ---- reference-protocol entry points ---------------------------------------------
     def seed(self, seeds=None, seed0=0, mask=None, replay_constructor=True):
         """np.random.seed(s) (+ random.seed(s)) then construct the env (see ce_seed)."""
         s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         check(self._L.ce_seed(self._h, None if s is None else s.ctypes.data, int(seed0),
-                              None if m is None else m.ctypes.data, int(replay_constructor)), self._h, "ce_seed")
+                              None if m is None else m.ctypes.data, 3 if replay_constructor else 1), self._h, "ce_seed")
+
+    def construct(self, mask=None):
+        """replay the constructor's RNG use on the CURRENT generator state (no re-seed)"""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        check(self._L.ce_seed(self._h, None, 0, None if m is None else m.ctypes.data, 2), self._h, "ce_seed")
 
     def reset(self, mask=None, stream=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

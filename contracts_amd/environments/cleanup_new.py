@@ -1,0 +1,34 @@
+"""CleanupEnv — drop-in for the reference's environments/cleanup_new.py:59 `CleanupEnv(MapEnv)`,
+stepped by the HIP engine.  Same constructor kwargs (cleanup_new.py:60-74), spaces (:90-169), step /
+reset dictionaries (:191-267) and `metrics` keys (:186-188,264-266)."""
+import numpy as np
+
+from .. import spaces
+from .map_env import GridEnvAdapter
+
+CLEANUP_VIEW_SIZE = 7
+
+
+class CleanupEnv(GridEnvAdapter):
+    KIND = "cleanup"
+    GRID_SHAPE = (25, 18)
+    N_ACTIONS = (8, 9)  # Discrete(8) without the punishment beam, Discrete(9) with it (cleanup_new.py:90-95)
+    N_APPLE_CELLS, POTENTIAL_WASTE_AREA = 103, 119
+
+    def _feature_space(self):
+        H, W = self.GRID_SHAPE
+        n = self.num_agents
+        return spaces.Box(low=np.array([0.0] * (12 + n)),
+                          high=np.array([H, W, 4, H, W, 4, H, W, H, W, self.N_APPLE_CELLS + 1,
+                                         self.POTENTIAL_WASTE_AREA + 1] + [np.inf] * n))
+
+    def _info_entry(self, eaten, second):
+        return {"eaten_apples": eaten, "cleaned_squares": second}
+
+    def _metrics_from(self, mi, mf):
+        n = self.num_agents
+        m = {"total_apples_eaten": int(mi[0]), "raw_env_rewards": int(mi[1]), "transfers": float(mf[0]) if self._contract[0] else 0,
+             "dirt_cleaned": int(mi[2])}
+        for i in range(n):
+            m["a%d-waste_cleaned" % i] = int(mi[4 + i])
+        return m

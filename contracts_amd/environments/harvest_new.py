@@ -1,0 +1,35 @@
+"""HarvestEnv — drop-in for the reference's environments/harvest_new.py:48 `HarvestEnv(MapEnv)`,
+stepped by the HIP engine.  Same constructor kwargs (harvest_new.py:49-63), spaces (:85-130), step /
+reset dictionaries (:158-239) and `metrics` keys (:152-156,235-237)."""
+import numpy as np
+
+from .. import spaces
+from .map_env import GridEnvAdapter
+
+HARVEST_VIEW_SIZE = 7
+
+
+class HarvestEnv(GridEnvAdapter):
+    KIND = "harvest"
+    GRID_SHAPE = (16, 38)
+    N_ACTIONS = (7, 8)  # harvest_new.py:85-90
+    N_APPLE_CELLS = 155
+
+    def _feature_space(self):
+        H, W = self.GRID_SHAPE
+        n = self.num_agents
+        return spaces.Box(low=np.array([0.0] * (10 + 2 * n)),
+                          high=np.array([H, W, 4, H, W, 4, H, W, self.N_APPLE_CELLS + 1, self.N_APPLE_CELLS + 1]
+                                        + [1] * (2 * n)))
+
+    def _info_entry(self, eaten, second):
+        return {"eaten_apples": eaten, "eaten_close_apples": second}
+
+    def _metrics_from(self, mi, mf):
+        n = self.num_agents
+        m = {"total_apples_eaten": int(mi[0]), "low_density_apples_eaten": int(mi[3]), "raw_env_rewards": int(mi[1]),
+             "transfers": float(mf[0]) if self._contract[0] else 0}
+        for i in range(n):
+            m["a%d-apples_consumed" % i] = int(mi[4 + i])
+            m["a%d-close_apples_consumed" % i] = int(mi[4 + n + i])
+        return m

@@ -1,0 +1,286 @@
+"""GridEnvAdapter — the RLlib `MultiAgentEnv`-shaped face of one HIP-stepped grid env.
+
+Mirrors the interface of the reference's `MapEnv` subclasses (environments/map_env.py:60-342,
+cleanup_new.py:59-267, harvest_new.py:48-239): constructor kwargs, `reset()`/`step()` dictionaries
+keyed 'a0'..'a{n-1}', spaces, `metrics`, `seed`, `compute_equality/compute_sustainability`.  All
+stepping happens in the engine (one wavefront per env); this class only converts between the engine's
+arrays and the reference's Python containers.
+
+RNG semantics.  The reference draws from the PROCESS-GLOBAL `np.random`.  With `rng="global"` (default)
+the adapter uploads the current global MT19937 state before every engine call and installs the advanced
+state afterwards, so `np.random.seed(s); env = CleanupEnv(...); env.reset(); env.step(...)` consumes the
+very same stream, interleaved correctly with any other user of `np.random` in the process.
+`rng="private"` keeps a per-env stream inside the engine (what the batched API uses).
+"""
+import numpy as np
+
+from .. import spaces
+from ..engine import BatchedEnv
+
+try:  # the real base class when RLlib is installed, so RLlib's isinstance checks pass
+    from ray.rllib.env import MultiAgentEnv as _Base  # pragma: no cover
+except Exception:
+    _Base = object
+
+VIEW = 7
+# colour LUT of the reference (map_env.py:24-42, cleanup_new.py:42-47), indexed by engine cell code,
+# then agents '1'..'9'
+CELL_RGB = np.array([[0, 0, 0], [180, 180, 180], [0, 255, 0], [99, 156, 194], [113, 75, 24], [113, 75, 24]], np.uint8)
+AGENT_RGB = np.array([[0, 0, 255], [2, 81, 154], [204, 0, 204], [216, 30, 54], [254, 151, 0], [100, 255, 255],
+                      [99, 99, 255], [250, 204, 255], [238, 223, 16]], np.uint8)
+CELL_CHARS = np.array([b" ", b"@", b"A", b"H", b"R", b"S"], dtype="S1")
+ORIENT_NAMES = ["UP", "RIGHT", "DOWN", "LEFT"]
+
+
+def push_global_rng(engine, python_random=False):
+    st = np.random.get_state(legacy=True)
+    words = np.zeros((1, engine.b.rng_words), np.uint32)
+    words[0, :624] = st[1]
+    words[0, 624] = st[2]
+    if python_random:
+        import random
+        ps = random.getstate()
+        words[0, 628:628 + 624] = np.array(ps[1][:624], np.uint32)
+        words[0, 628 + 624] = ps[1][624]
+    engine.upload("rng", words)
+    return st
+
+
+def pull_global_rng(engine, st, python_random=False):
+    words = engine.download("rng")[0]
+    np.random.set_state((st[0], words[:624].copy(), int(words[624]), st[3], st[4]))
+    if python_random:
+        import random
+        ps = random.getstate()
+        random.setstate((ps[0], tuple(int(x) for x in words[628:628 + 624]) + (int(words[628 + 624]),), ps[2]))
+
+
+class GridEnvAdapter(_Base):
+    KIND = None          # "cleanup" | "harvest"
+    GRID_SHAPE = None    # (H, W)
+    N_ACTIONS = None     # (disable_firing=True, False)
+
+    def __init__(self, ascii_map=None, num_agents=1, disable_firing=True, image_obs=True, return_agent_actions=False,
+                 use_collective_reward=False, inequity_averse_reward=False, alpha=0.0, beta=0.0, horizon=1000,
+                 one_hot_id=False, rng="global", device=0, **kwargs):
+        if ascii_map is not None:
+            raise NotImplementedError("custom ascii maps are not supported by the HIP engine (static map tables)")
+        if inequity_averse_reward:
+            assert num_agents > 1, "Cannot use inequity aversion with only one agent!"  # map_env.py:294
+        self.num_agents = num_agents
+        self.disable_firing = disable_firing
+        self.image_obs = image_obs
+        self.return_agent_actions = return_agent_actions  # no effect on the returned obs (cleanup_new.py:258)
+        self.use_collective_reward = use_collective_reward
+        self.inequity_averse_reward = inequity_averse_reward
+        self.alpha, self.beta = alpha, beta
+        self.horizon = horizon
+        self.one_hot_id = one_hot_id
+        self.view_len = self.map_padding = VIEW
+        self._rng_mode = rng
+        self._device = device
+        self._engine = None
+        self._contract = (None, None, None, 0.0)
+        self._keys = ["a%d" % i for i in range(num_agents)]
+        self.metrics = {}
+        self._build_spaces()
+        self._ensure_engine()
+        # the reference constructor consumes RNG (MapEnv.__init__ -> setup_agents, map_env.py:131)
+        self._call(self._engine.construct)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = BatchedEnv(
+                self.KIND, 1, self.num_agents, horizon=self.horizon, firing=not self.disable_firing,
+                collective=self.use_collective_reward, inequity=self.inequity_averse_reward, alpha=self.alpha,
+                beta=self.beta, device=self._device)
+            c, lo, hi, null_prob = self._contract
+            if c is not None:
+                self._engine.set_contract(c, lo, hi, null_prob)
+            pending = getattr(self, "_pending_state", None)
+            if pending:
+                for field, arr in pending.items():
+                    self._engine.upload(field, arr)
+                self._pending_state = None
+        return self._engine
+
+    def _call(self, fn, *args):
+        eng = self._ensure_engine()
+        if self._rng_mode == "global":
+            st = push_global_rng(eng)
+            fn(*args)
+            pull_global_rng(eng, st)
+        else:
+            fn(*args)
+
+    _STATE_FIELDS = ("grid", "agents", "spawn_perm", "waste_perm", "rng", "timestep", "theta", "int_metrics",
+                     "f64_metrics", "final_int_metrics", "final_f64_metrics")
+
+    def __getstate__(self):
+        # the instance is shipped inside RLlib's env_config (ray_config_utils.py:198-202): drop the device
+        # handle, keep the env state, re-create the engine lazily on the other side
+        d = dict(self.__dict__)
+        eng = d.pop("_engine", None)
+        if eng is not None:
+            fields = [f for f in self._STATE_FIELDS if not (f == "waste_perm" and self.KIND != "cleanup")]
+            d["_pending_state"] = {f: eng.download(f, raw=True) for f in fields}
+        d["_engine"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    # ------------------------------------------------------------------ spaces
+    def _build_spaces(self):
+        n, (H, W) = self.num_agents, self.GRID_SHAPE
+        na = self.N_ACTIONS[0] if self.disable_firing else self.N_ACTIONS[1]
+        self.action_space = spaces.Discrete(na)
+        self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(na,))
+        self.global_observation_space = spaces.Dict({"image": spaces.Box(low=0, high=1, shape=(H, W, 3), dtype=np.uint8)})
+        self.concatenated_observation_space = spaces.Dict(
+            {"image": spaces.Box(low=0, high=1, shape=(15, 15, 3 * n), dtype=np.uint8)})
+        self.global_action_space = spaces.MultiDiscrete([na] * n)
+        if not self.image_obs:
+            self.observation_space = self._feature_space()
+        else:
+            img = spaces.Box(low=0, high=1, shape=(2 * VIEW + 1, 2 * VIEW + 1, 3), dtype=np.uint8)
+            if not self.one_hot_id:
+                self.observation_space = spaces.Dict({"image": img})
+            else:
+                self.observation_space = spaces.Dict({"image": img, "features": spaces.Box(low=0, high=1, shape=(n,))})
+
+    # ------------------------------------------------------------------ reference API
+    def seed(self, seed=None):
+        """MapEnv.seed (map_env.py:344-345) == np.random.seed(seed)"""
+        if self._rng_mode == "global":
+            np.random.seed(seed)
+        else:
+            self._ensure_engine().seed(np.array([0 if seed is None else seed], np.uint64), replay_constructor=False)
+
+    def one_hot(self, key):
+        v = np.zeros(self.num_agents)
+        v[int(key[1:])] = 1
+        return v
+
+    def _obs_dict(self, feats=None):
+        eng = self._engine
+        if not self.image_obs:
+            f = eng.download("features")[0].astype(np.float64) if feats is None else feats
+            return {k: f[i] for i, k in enumerate(self._keys)}
+        img = eng.download("obs")[0]
+        out = {}
+        for i, k in enumerate(self._keys):
+            o = {"image": img[i] / 255}  # uint8/255 -> float64, as cleanup_new.py:258 / harvest_new.py:229
+            if self.one_hot_id:
+                o["features"] = self.one_hot(k)
+            out[k] = o
+        return out
+
+    def reset(self):
+        self._call(self._ensure_engine().reset)
+        self._engine.check_faults()
+        self._refresh_metrics(final=False)
+        return self._obs_dict()
+
+    def _step_engine(self, acts):
+        a = np.zeros((1, self.num_agents), np.uint8)
+        for i, k in enumerate(self._keys):
+            v = int(acts[k])
+            na = self.N_ACTIONS[1]
+            if not 0 <= v < na:
+                raise KeyError(v)  # Agent.action_map raises KeyError on an unknown id (Agent.py:174-176,213-215)
+            a[0, i] = v
+        self._call(self._ensure_engine().step, a)
+        self._engine.check_faults()
+
+    def step(self, acts):
+        self._step_engine(acts)
+        eng = self._engine
+        base = eng.download("base_reward")[0]
+        rew_f = eng.download("reward")[0]
+        float_rewards = self.inequity_averse_reward
+        r = {k: (float(rew_f[i]) if float_rewards else int(base[i])) for i, k in enumerate(self._keys)}
+        done = bool(eng.download("done")[0])
+        d = {"__all__": done, "a0": done, "a1": done}  # cleanup_new.py:242 / harvest_new.py:214 (sic)
+        infos = self._infos()
+        self._refresh_metrics(final=done)
+        feats = np.stack([infos[k]["feature_obs"] for k in self._keys])
+        return self._obs_dict(feats), r, d, infos
+
+    def _infos(self):
+        eng = self._engine
+        info = eng.download("info")[0]
+        feats = eng.download("features")[0].astype(np.float64)
+        out = {}
+        for i, k in enumerate(self._keys):
+            out[k] = self._info_entry(int(info[i, 0]), int(info[i, 1]))
+            out[k]["feature_obs"] = feats[i]
+        return out
+
+    # ------------------------------------------------------------------ state views (host copies)
+    @property
+    def agent_pos(self):
+        return [[int(a[0]), int(a[1])] for a in self._engine.download("agents")[0]]
+
+    @property
+    def timesteps(self):
+        return int(self._engine.download("timestep")[0])
+
+    @property
+    def world_map(self):
+        return CELL_CHARS[self._engine.download("grid")[0]]
+
+    def full_map_to_colors(self):
+        """map_env.py:389-392 (beams are never on the map when this is called between steps)"""
+        grid = self._engine.download("grid")[0]
+        rgb = CELL_RGB[grid].astype(int)
+        for i, a in enumerate(self._engine.download("agents")[0]):
+            rgb[a[0], a[1]] = AGENT_RGB[i]
+        return rgb
+
+    def render(self, filename=None, mode="human"):
+        return self.full_map_to_colors()
+
+    def get_global_obs(self):
+        return {"image": self.full_map_to_colors().astype(np.uint8) / 255}
+
+    # ------------------------------------------------------------------ metrics
+    def compute_equality(self, reward_dict):
+        """cleanup_new.py:422-434 (host helper kept for API parity; the env's own metrics come from the engine)"""
+        eq, total_sum = 0, 0
+        reward_dict = {k: sum(v) for k, v in reward_dict.items()}
+        n = len(reward_dict.keys())
+        for i in reward_dict.keys():
+            for j in reward_dict.keys():
+                eq += abs(reward_dict[i] - reward_dict[j])
+            total_sum += reward_dict[i]
+        if total_sum == 0:
+            total_sum = 0.001
+        return 1 - eq / (2 * n * total_sum)
+
+    def compute_sustainability(self, reward_dict):
+        avg_times = []
+        for k in reward_dict.keys():
+            t_sum = 0
+            for t, i in enumerate(reward_dict[k]):
+                t_sum += t * i
+            denom = max(sum(reward_dict[k]), 1)
+            avg_times.append(t_sum / denom)
+        return np.mean(avg_times)
+
+    def _refresh_metrics(self, final):
+        eng = self._engine
+        mi = eng.download("final_int_metrics" if final else "int_metrics")[0]
+        mf = eng.download("final_f64_metrics" if final else "f64_metrics")[0]
+        m = self._metrics_from(mi, mf)
+        if final:
+            m["equality"], m["sustainability"] = float(mf[1]), float(mf[2])
+            if self._contract[0] is not None:
+                m["transfer_equality"], m["transfer_sustainability"] = float(mf[3]), float(mf[4])
+        self.metrics = m

@@ -1,0 +1,132 @@
+"""SelfAcceleratingCarEnv — drop-in for environments/self_driving_car_accelerate.py:18, stepped by the
+HIP engine (float64 state, one lane per env).  Same constructor kwargs (:19), spaces (:40-47), reset /
+step dictionaries (:49-79,151-250).  The action dict may hold a subset of the agents (RLlib stops
+sending actions for agents whose done flag is set); obs/rewards/infos are returned for those keys."""
+import numpy as np
+
+from .. import spaces
+from ..engine import BatchedEnv
+from .map_env import _Base, pull_global_rng, push_global_rng
+
+ACCEL_LOW_THRESH, ACCEL_HIGH_THRESH = -0.1, 0.1
+
+
+class SelfAcceleratingCarEnv(_Base):
+    def __init__(self, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8, num_agents=2,
+                 collision_on=False, rng="global", device=0, **kwargs):
+        self.num_agents = num_agents
+        self.low_bound, self.high_bound = low_bound, high_bound
+        self.start_vel, self.start_vel_ambulance = start_vel, start_vel_ambulance
+        self.collision_on = collision_on
+        self.metrics = {"transfers": 0}
+        self._keys = ["a%d" % i for i in range(num_agents)]
+        self._rng_mode, self._device = rng, device
+        self._engine = None
+        self._contract = (None, None, None, 0.0)
+        self.observation_space = spaces.Box(low=low_bound - 20, high=high_bound + 20,
+                                            shape=(2 * (num_agents + 1) + 3,), dtype=np.float32)
+        self.action_space = spaces.Box(low=ACCEL_LOW_THRESH, high=ACCEL_HIGH_THRESH, shape=(1,), dtype=np.float32)
+        self._ensure_engine().construct()  # __init__ uses no RNG
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = BatchedEnv("selfdrive", 1, self.num_agents, collision_on=self.collision_on,
+                                      low_bound=self.low_bound, high_bound=self.high_bound, start_vel=self.start_vel,
+                                      start_vel_ambulance=self.start_vel_ambulance, device=self._device)
+            c, lo, hi, null_prob = self._contract
+            if c is not None:
+                self._engine.set_contract(c, lo, hi, null_prob)
+            pending = getattr(self, "_pending_state", None)
+            if pending:
+                for f, arr in pending.items():
+                    self._engine.upload(f, arr)
+                self._pending_state = None
+        return self._engine
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        eng = d.pop("_engine", None)
+        if eng is not None:
+            d["_pending_state"] = {f: eng.download(f, raw=True) for f in ("sd_state", "rng", "theta", "f64_metrics")}
+        d["_engine"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    def _call(self, fn, *args):
+        eng = self._ensure_engine()
+        if self._rng_mode == "global":
+            st = push_global_rng(eng, python_random=True)
+            fn(*args)
+            pull_global_rng(eng, st, python_random=True)
+        else:
+            fn(*args)
+
+    def seed(self, seed=None):
+        if self._rng_mode == "global":
+            import random
+            np.random.seed(seed)
+            random.seed(seed)
+        else:
+            self._ensure_engine().seed(np.array([0 if seed is None else seed], np.uint64), replay_constructor=False)
+
+    @property
+    def agent_positions(self):
+        s = self._engine.download("sd_state")[0]
+        return {k: float(s[i]) for i, k in enumerate(self._keys)}
+
+    @property
+    def agent_vels(self):
+        s, n = self._engine.download("sd_state")[0], self.num_agents
+        return {k: float(s[n + i]) for i, k in enumerate(self._keys)}
+
+    @property
+    def crossed_agents(self):
+        s, n = self._engine.download("sd_state")[0], self.num_agents
+        return ["a%d" % int(x) for x in s[4 * n + 2:4 * n + 2 + int(s[4 * n + 1])]]
+
+    def _base_obs(self, keys):
+        L = 2 * self.num_agents + 5
+        ob = self._engine.download("obs_f64")[0]
+        return {k: ob[int(k[1:]), :L].copy() for k in keys}
+
+    def reset(self):
+        self._call(self._ensure_engine().reset)
+        self.metrics = {"transfers": 0}
+        return self._base_obs(self._keys)
+
+    def _step_engine(self, acts):
+        n = self.num_agents
+        a = np.zeros((1, n), np.float32)
+        active = np.zeros((1, n), np.uint8)
+        for k, v in acts.items():
+            i = int(k[1:])
+            a[0, i] = np.float32(np.asarray(v).reshape(-1)[0])
+            active[0, i] = 1
+        self._call(self._ensure_engine().step, a, active)
+        f = int(self._engine.download("error_flags")[0])
+        if f & 4:  # the reference raises AttributeError here (collision_check_all is undefined, :160)
+            raise AttributeError("'SelfAcceleratingCarEnv' object has no attribute 'collision_check_all'")
+
+    def _dones(self):
+        da = self._engine.download("done_agents")[0]
+        d = {k: bool(da[i]) for i, k in enumerate(self._keys)}
+        d["__all__"] = bool(self._engine.download("done")[0])
+        return d
+
+    def _infos(self, keys):
+        info = self._engine.download("info")[0]
+        return {k: {"just_passed": bool(info[int(k[1:]), 0]), "is_crashed": int(info[int(k[1:]), 1]) if k == keys[0] else 0}
+                for k in keys}
+
+    def step(self, acts):
+        keys = list(acts.keys())
+        self._step_engine(acts)
+        base = self._engine.download("base_reward")[0]  # -1 / -100 (ambulance) / -10000 (crash), before any contract
+        r = {k: float(base[int(k[1:])]) for k in keys}
+        self.metrics = {"transfers": float(self._engine.download("f64_metrics")[0][0])}
+        return self._base_obs(keys), r, self._dones(), self._infos(keys)
+
+    def render(self, mode="rgb"):
+        return True

@@ -1,0 +1,39 @@
+"""Registry: the reference's env tags (utils/env_creator_functions.py:12-60) -> HIP-backed classes.
+`register_env` is called when RLlib is importable, so `runner.py`-style configs resolve to these."""
+from ..environments.cleanup_new import CleanupEnv
+from ..environments.harvest_new import HarvestEnv
+from ..environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
+from ..environments.two_stage_train import SeparateContractSubgameStage
+
+_ACCELERATED = {
+    "SelfDrive": SelfAcceleratingCarEnv,
+    "HarvestNew": HarvestEnv,
+    "CleanupNew": CleanupEnv,
+    "ContractWrapperSubgame": SeparateContractSubgameStage,
+}
+# tags of the reference that are callers of the hot path or legacy envs, not the path itself
+_OUT_OF_SCOPE = ("Harvest", "Cleanup", "ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver", "JointEnv")
+
+
+def env_creator(name, config):
+    if name in _ACCELERATED:
+        return _ACCELERATED[name](**config)
+    if name in _OUT_OF_SCOPE:
+        raise NotImplementedError("env tag %r is outside the accelerated hot path (SURVEY.md §8f)" % name)
+    raise ValueError("Environment not found")
+
+
+def get_base_env_tag(arg_dict):
+    env = arg_dict.get("environment")
+    tags = {"selfdrive": "SelfDrive", "harvest": "Harvest", "harvest_new": "HarvestNew", "cleanup": "Cleanup",
+            "cleanup_new": "CleanupNew"}
+    assert env in tags
+    return tags[env]
+
+
+try:  # pragma: no cover - RLlib is absent in the build image
+    from ray.tune.registry import register_env
+    for _tag in _ACCELERATED:
+        register_env(_tag, lambda config, _t=_tag: env_creator(_t, config))
+except Exception:
+    pass

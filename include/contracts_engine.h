@@ -194,12 +194,21 @@ int ce_device_count(void);
 int ce_create(const ce_config* cfg, ce_handle* out);
 int ce_destroy(ce_handle h);
 
+/* Replaces: wrapping an already constructed base env in SeparateContractSubgameStage
+ * (two_stage_train.py:34-44,152-157): switches the fused contract epilogue of an existing
+ * handle on/off and sets the contract space + null_prob.  Takes effect at the next reset/step. */
+int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob);
+
 /* Replaces: np.random.seed(s) (+ random.seed(s)) followed by CONSTRUCTING the env
  * (MapEnv.__init__ -> setup_agents consumes RNG: map_env.py:131,816-832; CleanupEnv then
  * duplicates the spawn list, cleanup_new.py:114-115).  seeds: host pointer [E] (or NULL:
  * env b gets seed0 + env_index_base + b).  mask: host pointer [E] of 0/1 (NULL = all).
- * replay_constructor=0 only re-seeds the generators (MapEnv.seed, map_env.py:344-345). */
-int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int replay_constructor);
+ * mode: CE_SEED_RESEED re-seeds both generators (np.random.seed / MapEnv.seed map_env.py:344-345,
+ * random.seed); CE_SEED_CONSTRUCT replays the constructor's RNG use on the CURRENT generator
+ * state; the usual "seed, then construct" is CE_SEED_RESEED | CE_SEED_CONSTRUCT. */
+#define CE_SEED_RESEED 1
+#define CE_SEED_CONSTRUCT 2
+int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int mode);
 
 /* Replaces: SeparateContractSubgameStage.reset (two_stage_train.py:159-187) ->
  * CleanupEnv/HarvestEnv.reset -> MapEnv.reset (map_env.py:306-342) /

@@ -766,6 +766,42 @@ static double np_sum(const double* a, int n) {
   return res;
 }
 
+/* infos[k]['feature_obs'] (cleanup_new.py:243-251, harvest_new.py:215-222); also the feature-mode
+ * reset observation (cleanup_new.py:193-202, harvest_new.py:160-168) with cleaned = 0 */
+static void write_features(orc_t* o, env_t* e, int ei, const int* cleaned) {
+  int n = o->n;
+  int16_t* feat = o->b.features + (size_t)ei * n * o->b.num_features;
+  uint8_t now_apples[16 * 38];
+  for (int i = 0; i < o->cells; i++) now_apples[i] = e->grid[i] == CE_CELL_APPLE;
+  for (int a = 0; a < n; a++) {
+    int16_t* f = feat + (size_t)a * o->b.num_features;
+    /* compute_closest_pos (cleanup_new.py:405-412): index 1 for a0, else 0; n==1 -> 0 */
+    int cp = (a == 0 && n > 1) ? 1 : 0;
+    int ar, ac2, napples, wr = 0, wc = 0, nwaste = 0;
+    closest_of(o, e, CE_CELL_APPLE, e->pos[a], &ar, &ac2, &napples);
+    f[0] = (int16_t)e->pos[a].row;
+    f[1] = (int16_t)e->pos[a].col;
+    f[2] = (int16_t)e->orient[a];
+    f[3] = (int16_t)e->pos[cp].row;
+    f[4] = (int16_t)e->pos[cp].col;
+    f[5] = (int16_t)e->orient[cp];
+    f[6] = (int16_t)ar;
+    f[7] = (int16_t)ac2;
+    if (o->kind == CE_KIND_CLEANUP) {
+      closest_of(o, e, CE_CELL_WASTE, e->pos[a], &wr, &wc, &nwaste);
+      f[8] = (int16_t)wr;
+      f[9] = (int16_t)wc;
+      f[10] = (int16_t)napples;
+      f[11] = (int16_t)nwaste;
+      for (int b2 = 0; b2 < n; b2++) f[12 + b2] = (int16_t)cleaned[b2];
+    } else {
+      f[8] = (int16_t)apples_in_radius5(o, now_apples, e->pos[a]);
+      f[9] = (int16_t)napples;
+      for (int b2 = 0; b2 < 2 * n; b2++) f[10 + b2] = 0;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* grid env: seed+construct, reset, step                                      */
 /* ------------------------------------------------------------------------- */
@@ -813,12 +849,14 @@ static void export_state(orc_t* o, int ei) {
   }
 }
 
-static void grid_seed_construct(orc_t* o, int ei, uint64_t seed, int replay_constructor) {
+static void grid_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
   env_t* e = &o->envs[ei];
-  mt_init_genrand(&e->np_rng, (uint32_t)seed);
-  uint32_t k32 = (uint32_t)seed;
-  mt_init_by_array(&e->py_rng, &k32, 1);
-  if (!replay_constructor) return;
+  if (mode & CE_SEED_RESEED) {
+    mt_init_genrand(&e->np_rng, (uint32_t)seed);
+    uint32_t k32 = (uint32_t)seed;
+    mt_init_by_array(&e->py_rng, &k32, 1);
+  }
+  if (!(mode & CE_SEED_CONSTRUCT)) return;
   /* MapEnv.__init__: spawn_points = the P cells in row-major order, then setup_agents() */
   int base_len = o->kind == CE_KIND_CLEANUP ? 10 : 20;
   for (int i = 0; i < 20; i++) e->spawn_perm[i] = (uint8_t)i;
@@ -862,7 +900,10 @@ static void grid_reset(orc_t* o, int ei) {
     o->b.info[((size_t)ei * n + a) * 2] = 0;
     o->b.info[((size_t)ei * n + a) * 2 + 1] = 0;
   }
-  memset(o->b.features + (size_t)ei * n * o->b.num_features, 0, sizeof(int16_t) * n * o->b.num_features);
+  {
+    int zero[MAXN] = {0};
+    write_features(o, e, ei, zero);
+  }
   o->b.done[ei] = 0;
   export_state(o, ei);
 }
@@ -1001,37 +1042,8 @@ static void grid_step(orc_t* o, int ei, const uint8_t* act) {
     mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, a)] += (int64_t)(e->timesteps - 1) * rew_i[a];
     mi[CE_MI_RAW_ENV_REWARDS] += rew_i[a];
   }
-  /* feature obs */
+  write_features(o, e, ei, cleaned);
   int16_t* feat = o->b.features + (size_t)ei * n * o->b.num_features;
-  uint8_t now_apples[16 * 38];
-  for (int i = 0; i < o->cells; i++) now_apples[i] = e->grid[i] == CE_CELL_APPLE;
-  for (int a = 0; a < n; a++) {
-    int16_t* f = feat + (size_t)a * o->b.num_features;
-    /* compute_closest_pos (cleanup_new.py:405-412): index 1 for a0, else 0; n==1 -> 0 */
-    int cp = (a == 0 && n > 1) ? 1 : 0;
-    int ar, ac2, napples, wr = 0, wc = 0, nwaste = 0;
-    closest_of(o, e, CE_CELL_APPLE, e->pos[a], &ar, &ac2, &napples);
-    f[0] = (int16_t)e->pos[a].row;
-    f[1] = (int16_t)e->pos[a].col;
-    f[2] = (int16_t)e->orient[a];
-    f[3] = (int16_t)e->pos[cp].row;
-    f[4] = (int16_t)e->pos[cp].col;
-    f[5] = (int16_t)e->orient[cp];
-    f[6] = (int16_t)ar;
-    f[7] = (int16_t)ac2;
-    if (o->kind == CE_KIND_CLEANUP) {
-      closest_of(o, e, CE_CELL_WASTE, e->pos[a], &wr, &wc, &nwaste);
-      f[8] = (int16_t)wr;
-      f[9] = (int16_t)wc;
-      f[10] = (int16_t)napples;
-      f[11] = (int16_t)nwaste;
-      for (int b2 = 0; b2 < n; b2++) f[12 + b2] = (int16_t)cleaned[b2];
-    } else {
-      f[8] = (int16_t)apples_in_radius5(o, now_apples, e->pos[a]);
-      f[9] = (int16_t)napples;
-      for (int b2 = 0; b2 < 2 * n; b2++) f[10 + b2] = 0;
-    }
-  }
   int done = e->timesteps == (int)o->cfg.horizon;
 
   /* ---- contract + SeparateContractEnv.step two_stage_train.py:62-121 ---- */
@@ -1115,12 +1127,14 @@ static void sd_write_obs(orc_t* o, env_t* e, int ei, const int* active, const do
   }
 }
 
-static void sd_seed_construct(orc_t* o, int ei, uint64_t seed, int replay_constructor) {
+static void sd_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
   env_t* e = &o->envs[ei];
-  mt_init_genrand(&e->np_rng, (uint32_t)seed);
-  uint32_t k32 = (uint32_t)seed;
-  mt_init_by_array(&e->py_rng, &k32, 1);
-  if (!replay_constructor) return;
+  if (mode & CE_SEED_RESEED) {
+    mt_init_genrand(&e->np_rng, (uint32_t)seed);
+    uint32_t k32 = (uint32_t)seed;
+    mt_init_by_array(&e->py_rng, &k32, 1);
+  }
+  if (!(mode & CE_SEED_CONSTRUCT)) return;
   for (int a = 0; a < o->n; a++) { /* __init__ :29-35 (no RNG use) */
     e->sd_pos[a] = o->cfg.low_bound;
     e->sd_vel[a] = o->cfg.start_vel;
@@ -1158,6 +1172,7 @@ static void sd_reset(orc_t* o, int ei) {
   sd_write_obs(o, e, ei, active, e->sd_pos, 0.0);
   for (int a = 0; a < n; a++) {
     o->b.reward[(size_t)ei * n + a] = 0;
+    o->b.base_reward[(size_t)ei * n + a] = 0;
     o->b.info[((size_t)ei * n + a) * 2] = 0;
     o->b.info[((size_t)ei * n + a) * 2 + 1] = 0;
     o->b.done_agents[(size_t)ei * n + a] = 0;
@@ -1263,7 +1278,7 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
     e->sd_done_all = all_done;
     sd_write_obs(o, e, ei, active, e->sd_pos, 0.0);
   }
-  for (int k = 0; k < n; k++) o->b.base_reward[(size_t)ei * n + k] = 0;
+  for (int k = 0; k < n; k++) o->b.base_reward[(size_t)ei * n + k] = active[k] ? (int32_t)rews[k] : 0;
   double base[MAXN];
   memcpy(base, rews, sizeof(base));
   /* SelfdriveContractDistprop.compute_transfer contract_list.py:69-102 on a0's base obs */
@@ -1428,16 +1443,16 @@ int orc_destroy(orc_t* o) {
   return CE_OK;
 }
 
-int orc_seed(orc_t* o, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int replay_constructor) {
+int orc_seed(orc_t* o, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int mode) {
   if (!o) return CE_EINVAL;
 #pragma omp parallel for schedule(static)
   for (long ei = 0; ei < (long)o->cfg.num_envs; ei++) {
     if (mask && !mask[ei]) continue;
     uint64_t s = seeds ? seeds[ei] : seed0 + o->cfg.env_index_base + (uint64_t)ei;
     if (o->kind == CE_KIND_SELFDRIVE)
-      sd_seed_construct(o, (int)ei, s, replay_constructor);
+      sd_seed_construct(o, (int)ei, s, mode);
     else
-      grid_seed_construct(o, (int)ei, s, replay_constructor);
+      grid_seed_construct(o, (int)ei, s, mode);
     export_state(o, (int)ei);
   }
   return CE_OK;

@@ -181,8 +181,13 @@ class Oracle:
         s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         rc = lib().orc_seed(self._h, None if s is None else s.ctypes.data, seed0, None if m is None else m.ctypes.data,
-                            int(replay_constructor))
+                            3 if replay_constructor else 1)
         assert rc == 0, rc
+
+    def construct(self, mask=None):
+        """constructor RNG replay on the current generator state (no re-seed)"""
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        assert lib().orc_seed(self._h, None, 0, None if m is None else m.ctypes.data, 2) == 0
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

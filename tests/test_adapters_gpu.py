@@ -1,0 +1,141 @@
+"""GPU: the drop-in adapters, driven exactly like the reference's own classes
+(`np.random.seed(s); env = CleanupEnv(num_agents=n); wrapper = SeparateContractSubgameStage(...);
+reset(); step({agent: action})`), against the traces the reference produced (tests/golden)."""
+import hashlib
+import pickle
+import random
+
+import numpy as np
+import pytest
+
+import golden_check as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def _mt_fp():
+    st = np.random.get_state()
+    return (int(st[2]), int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16))
+
+
+@pytest.mark.parametrize("name,steps", [("g1_cleanup_n4", 1150), ("g3c_cleanup_n4_cleaner", 250), ("g2_harvest_n8", 300),
+                                        ("g4_cleanup_n8_fire", 120), ("g6_harvest_n1_nocontract", 100)])
+def test_grid_adapter_trace(name, steps):
+    from contracts_amd.contract import contract_list as cl
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    g = gc.load(name)
+    kind, n, seed = str(g["kind"]), int(g["n"]), int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    cls = CleanupEnv if kind == "cleanup" else HarvestEnv
+    env = cls(num_agents=n, disable_firing=not bool(int(g["firing"])))
+    assert _mt_fp() == tuple(int(x) for x in g["ctor_mt"])  # the constructor consumed the global stream
+    contract = bool(int(g["contract"]))
+    if contract:
+        con = cl.CleanupContract(n) if kind == "cleanup" else cl.HarvestFeaturemodLocalContract(n)
+        top = SeparateContractSubgameStage(env, con, n, True)
+    else:
+        top = env
+    keys = ["a%d" % i for i in range(n)]
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    t = 0
+    for ep in range(len(g["ep_start"])):
+        o = top.reset()
+        assert _mt_fp() == tuple(int(x) for x in g["reset_mt"][ep])
+        for i, k in enumerate(keys):
+            assert o[k]["image"].dtype == np.float64
+            assert np.array_equal(o[k]["image"], g["reset_obs"][ep][i] / 255)
+            if contract:
+                assert np.array_equal(o[k]["contract"], np.array([g["theta"][ep], 0.0]))
+        for t in range(ep_start[ep], min(ep_start[ep + 1], steps)):
+            acts = {k: int(g["actions"][t][i]) for i, k in enumerate(keys)}
+            o, r, d, info = top.step(acts)
+            assert set(d.keys()) == {"__all__", "a0", "a1"} and d["__all__"] == bool(g["done"][t])
+            for i, k in enumerate(keys):
+                if t < len(g["obs"]):
+                    assert np.array_equal(o[k]["image"], g["obs"][t][i] / 255), (t, k)
+                assert abs(float(r[k]) - g["rew"][t][i]) < 1e-9, (t, k)
+                assert info[k]["eaten_apples"] == g["eaten"][t][i]
+                second = "cleaned_squares" if kind == "cleanup" else "eaten_close_apples"
+                assert info[k][second] == (g["cleaned"] if kind == "cleanup" else g["eaten_close"])[t][i]
+                assert np.array_equal(info[k]["feature_obs"], g["feature_obs"][t][i])
+                if contract:
+                    assert info[k]["contract_param"][0] == g["theta"][ep]
+            assert _mt_fp() == tuple(int(x) for x in g["mt"][t]), "global np.random diverged at step %d" % t
+        if min(ep_start[ep + 1], steps) == ep_start[ep + 1]:
+            mk = str(g["metrics_keys_ep%d" % ep]).split(",")
+            assert set(mk) == set(env.metrics.keys()), (set(mk) ^ set(env.metrics.keys()))
+            for k, v in zip(mk, g["metrics_vals_ep%d" % ep]):
+                assert abs(float(env.metrics[k]) - v) < 1e-9 * max(1.0, abs(v)), k
+    env.close()
+
+
+def test_selfdrive_adapter_trace():
+    from contracts_amd.contract import contract_list as cl
+    from contracts_amd.environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    g = gc.load("g5_selfdrive_n4")
+    n, seed = 4, int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    env = SelfAcceleratingCarEnv(num_agents=n)
+    top = SeparateContractSubgameStage(env, cl.SelfdriveContractDistprop(n), n, False)
+    keys = ["a%d" % i for i in range(n)]
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    for ep in range(len(g["ep_start"])):
+        o = top.reset()
+        for i, k in enumerate(keys):
+            np.testing.assert_allclose(o[k], g["reset_obs"][ep][i], rtol=0, atol=1e-9)
+        for t in range(ep_start[ep], ep_start[ep + 1]):
+            act = g["active"][t].astype(bool)
+            acts = {k: np.array([float(g["actions"][t][i])]) for i, k in enumerate(keys) if act[i]}
+            o, r, d, info = top.step(acts)
+            assert list(o.keys()) == [k for i, k in enumerate(keys) if act[i]]
+            for i, k in enumerate(keys):
+                if act[i]:
+                    np.testing.assert_allclose(o[k], g["obs"][t][i], rtol=0, atol=1e-9)
+                    assert abs(r[k] - g["rew"][t][i]) < 1e-6
+                    assert info[k]["just_passed"] == bool(g["just_passed"][t][i])
+                assert d[k] == bool(g["done"][t][i])
+            assert d["__all__"] == bool(g["done"][t][n])
+            assert abs(env.metrics["transfers"] - g["transfers_metric"][t]) < 1e-6
+        with pytest.raises(AttributeError):  # the reference raises when stepped after __all__ (…accelerate.py:160)
+            top.step({"a0": np.array([0.0])})
+    env.close()
+
+
+def test_adapter_pickle_roundtrip_and_options():
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    np.random.seed(5)
+    env = CleanupEnv(num_agents=3, one_hot_id=True)
+    o = env.reset()
+    assert set(o["a1"].keys()) == {"image", "features"} and np.array_equal(o["a1"]["features"], [0, 1, 0])
+    rs = np.random.RandomState(0)
+    for _ in range(10):
+        env.step({k: int(rs.randint(8)) for k in ("a0", "a1", "a2")})
+    st = np.random.get_state()
+    clone = pickle.loads(pickle.dumps(env))  # shipped inside env_config (ray_config_utils.py:198-202)
+    acts = [{k: int(rs.randint(8)) for k in ("a0", "a1", "a2")} for _ in range(15)]
+    outs = []
+    for e in (env, clone):
+        np.random.set_state(st)
+        outs.append([e.step(a) for a in acts])
+    for (o1, r1, d1, i1), (o2, r2, d2, i2) in zip(*outs):
+        assert r1 == r2 and d1 == d2
+        for k in o1:
+            assert np.array_equal(o1[k]["image"], o2[k]["image"])
+            assert np.array_equal(i1[k]["feature_obs"], i2[k]["feature_obs"])
+    with pytest.raises(KeyError):
+        env.step({"a0": 11, "a1": 0, "a2": 0})
+    # feature-vector mode (image_obs=False): obs is the 12+n feature vector, also at reset
+    np.random.seed(6)
+    fenv = CleanupEnv(num_agents=2, image_obs=False)
+    fo = fenv.reset()
+    assert fo["a0"].shape == (14,) and fo["a0"][11] == 56.0 and fenv.observation_space.shape == (14,)
+    fo2, _, _, info = fenv.step({"a0": 4, "a1": 4})
+    assert np.array_equal(fo2["a1"], info["a1"]["feature_obs"])
+    env.close()
+    clone.close()
+    fenv.close()

@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads, exports every function include/contracts_engine.h declares, its
+structs have the layout the ctypes mirrors assume, and it fails LOUDLY without a GPU (no CPU path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "contracts_engine.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ce_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_functions_exported():
+    from contracts_amd import _lib
+    L = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(L, name), "library does not export %s" % name
+        assert name in _lib.EXPORTS, "ctypes table misses %s" % name
+    assert L.ce_abi_version() == 1
+
+
+def test_struct_layout_matches_ctypes():
+    from contracts_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "contracts_engine.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ce_config), offsetof(ce_config, env_index_base),
+         offsetof(ce_config, contract_low), offsetof(ce_config, start_vel_ambulance), sizeof(ce_buffers),
+         offsetof(ce_buffers, grid), offsetof(ce_buffers, error_flags));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    cfg, buf = _lib.CeConfig, _lib.CeBuffers
+    want = [C.sizeof(cfg), cfg.env_index_base.offset, cfg.contract_low.offset, cfg.start_vel_ambulance.offset,
+            C.sizeof(buf), buf.grid.offset, buf.error_flags.offset]
+    assert got == want
+
+
+def test_no_gpu_fails_loudly():
+    """without a gfx950 device engine creation must raise — never fall back to a CPU path"""
+    from contracts_amd import _lib
+    from contracts_amd.engine import BatchedEnv
+    if _lib.load().ce_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.EngineError) as ei:
+        BatchedEnv("cleanup", 4, 2)
+    assert "CE_ENODEV" in str(ei.value)
+
+
+def test_bad_config_rejected():
+    from contracts_amd import _lib
+    from contracts_amd.engine import make_config
+    L = _lib.load()
+    h = C.c_void_p()
+    for bad in (dict(kind="cleanup", num_envs=0, num_agents=2), dict(kind="cleanup", num_envs=4, num_agents=10),
+                dict(kind="harvest", num_envs=4, num_agents=2, contract="cleanup"),
+                dict(kind="selfdrive", num_envs=4, num_agents=11)):
+        cfg = make_config(**bad)
+        assert L.ce_create(C.byref(cfg), C.byref(h)) == -22, bad
+    assert L.ce_create(None, C.byref(h)) == -22
+
+
+def test_product_never_touches_oracle():
+    """the product package must not import, link or mention oracle/ (the oracle is the checker)"""
+    pkg = os.path.join(ROOT, "contracts_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "orc_" not in txt, f
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "csrc", "libcontracts_engine.so")]).decode()
+    assert "oracle" not in out
+
+
+def test_synth_action_host_is_deterministic_and_uniform():
+    from contracts_amd import _lib
+    L = _lib.load()
+    import numpy as np
+    a = [L.ce_synth_action_host(7, e, t, k, 8) for e in range(40) for t in range(20) for k in range(8)]
+    b = [L.ce_synth_action_host(7, e, t, k, 8) for e in range(40) for t in range(20) for k in range(8)]
+    assert a == b and min(a) == 0 and max(a) == 7
+    hist = np.bincount(a, minlength=8) / len(a)
+    assert np.all(np.abs(hist - 0.125) < 0.03)

@@ -1,0 +1,49 @@
+"""CPU: host-side mirror of the reference interface — registry tags, contract specs, spaces, sharding."""
+import numpy as np
+import pytest
+
+
+def test_registry_tags():
+    from contracts_amd.utils import env_creator_functions as ecf
+    assert ecf.get_base_env_tag({"environment": "cleanup_new"}) == "CleanupNew"
+    assert ecf.get_base_env_tag({"environment": "harvest_new"}) == "HarvestNew"
+    assert ecf.get_base_env_tag({"environment": "selfdrive"}) == "SelfDrive"
+    with pytest.raises(AssertionError):
+        ecf.get_base_env_tag({"environment": "nope"})
+    with pytest.raises(ValueError):
+        ecf.env_creator("Nope", {})
+    with pytest.raises(NotImplementedError):
+        ecf.env_creator("JointEnv", {})
+
+
+def test_contract_specs():
+    from contracts_amd.contract import contract_list as cl
+    c = cl.CleanupContract(4)
+    # gym Box semantics: float32 bounds, read back as float64 by the wrapper (two_stage_train.py:39-40)
+    assert c.contract_space.high.dtype == np.float32
+    assert float(c.contract_space.high[0]) == float(np.float32(0.2)) != 0.2
+    assert cl.HarvestFeaturemodLocalContract(8).contract_space.high[0] == 10.0
+    assert cl.SelfdriveContractDistprop(4).contract_space.high[0] == 100.0
+    assert c.engine_contract == "cleanup" and c.num_agents == 4 and c.default_contract[0] == 0.0
+    with pytest.raises(NotImplementedError):
+        c.compute_transfer({}, {}, {}, {}, {})
+
+
+def test_sharding():
+    from contracts_amd.parallel import env_shard, split_envs
+    assert env_shard(3, 8, 16384) == (3 * 16384, 16384)
+    with pytest.raises(ValueError):
+        env_shard(8, 8, 4)
+    parts = split_envs(131072, 8)
+    assert parts[0] == (0, 16384) and parts[-1] == (7 * 16384, 16384)
+    parts = split_envs(10, 4)
+    assert [c for _, c in parts] == [3, 3, 2, 2] and [b for b, _ in parts] == [0, 3, 6, 8]
+
+
+def test_spaces_standins():
+    from contracts_amd import spaces
+    b = spaces.Box(low=0, high=0.2, shape=(1,))
+    assert b.low.dtype == np.float32 and b.shape == (1,)
+    d = spaces.Dict({"image": spaces.Box(0, 1, (15, 15, 3), np.uint8)})
+    assert "image" in d.keys() and d["image"].shape == (15, 15, 3)
+    assert spaces.Discrete(8).n == 8
