@@ -973,7 +973,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridPara
     p.timestep[E.e] = 0;
     p.theta[E.e] = theta;
     p.done[E.e] = 0;
-    if (fault) p.error_flags[E.e] |= fault;
+    p.error_flags[E.e] = fault;  // a reset starts a clean episode (faults are sticky until then)
   }
 }
 

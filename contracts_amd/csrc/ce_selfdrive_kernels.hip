@@ -189,6 +189,7 @@ template <int N> __global__ void k_sd_reset(SdParams p) {
   sd_zero_metrics<N>(p, e);
   p.theta[e] = theta;
   p.done[e] = 0;
+  p.error_flags[e] = 0;  // a reset starts a clean episode (faults are sticky until then)
 #pragma unroll
   for (int a = 0; a < N; ++a) {
     p.reward[(size_t)e * N + a] = 0.0;

@@ -130,3 +130,8 @@ class SelfAcceleratingCarEnv(_Base):
 
     def render(self, mode="rgb"):
         return True
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None

@@ -133,7 +133,7 @@ typedef struct ce_buffers {
   double* f64_metrics;   /* [E][num_f64_metrics]  running episode                           */
   int64_t* final_int_metrics; /* same layout, latched at the step that returned done        */
   double* final_f64_metrics;
-  uint32_t* error_flags; /* [E] sticky per-env fault bits (CE_FAULT_*)                      */
+  uint32_t* error_flags; /* [E] per-env fault bits (CE_FAULT_*), sticky until the env is reset    */
 } ce_buffers;
 
 /* cell codes of `grid` (reference world_map chars) */

@@ -64,7 +64,9 @@ def test_grid_adapter_trace(name, steps):
                 if contract:
                     assert info[k]["contract_param"][0] == g["theta"][ep]
             assert _mt_fp() == tuple(int(x) for x in g["mt"][t]), "global np.random diverged at step %d" % t
-        if min(ep_start[ep + 1], steps) == ep_start[ep + 1]:
+        if steps < ep_start[ep + 1]:
+            break  # truncated replay: later episodes of the fixture depend on the full first one
+        if True:
             mk = str(g["metrics_keys_ep%d" % ep]).split(",")
             assert set(mk) == set(env.metrics.keys()), (set(mk) ^ set(env.metrics.keys()))
             for k, v in zip(mk, g["metrics_vals_ep%d" % ep]):
