@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libcontracts_engine.so")
+LIB_PATH = os.environ.get("CONTRACTS_AMD_LIB") or os.path.join(HERE, "csrc", "libcontracts_engine.so")
 
 CE_ABI_VERSION = 1
 KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2}

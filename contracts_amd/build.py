@@ -37,21 +37,26 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    stamps = os.environ.get("CE_PHASE_STAMPS") == "1"
+    lib, flags, suffix = LIB, list(FLAGS), ""
+    if stamps:  # diagnostic build: s_memtime stamps per phase, separate file, never benchmarked
+        flags.append("-DCE_PHASE_STAMPS")
+        lib, suffix, force = LIB.replace(".so", "_stamps.so"), "_stamps", True
     if not force and not needs_build():
         return LIB
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -110,6 +110,7 @@ struct ce_engine {
   uint8_t* d_mask;
   uint8_t* d_stage_actions;  // E*n*4 bytes
   uint8_t* d_stage_active;   // E*n
+  unsigned long long* d_debug;  // E*16 phase stamps (diagnostic builds)
   std::vector<std::pair<void**, size_t>> allocs;
   std::string err;
   // timing
@@ -175,6 +176,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->d_mask = nullptr;
   h->d_stage_actions = nullptr;
   h->d_stage_active = nullptr;
+  h->d_debug = nullptr;
   std::memset(&h->buf, 0, sizeof(h->buf));
   *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
 
@@ -255,6 +257,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (rc == CE_OK) rc = dalloc(h, &h->d_mask, E);
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_actions, E * n * 4);
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_active, E * n);
+  if (rc == CE_OK) rc = dalloc(h, &h->d_debug, E * 16);
 #undef A
   return rc;
 }
@@ -310,6 +313,7 @@ static GridParams grid_params(ce_engine* h) {
   p.final_int_metrics = b.final_int_metrics;
   p.final_f64_metrics = b.final_f64_metrics;
   p.error_flags = b.error_flags;
+  p.debug = h->d_debug;
   p.E = h->cfg.num_envs;
   p.n = h->cfg.num_agents;
   p.horizon = h->cfg.horizon;
@@ -528,6 +532,7 @@ static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
       {"final_int_metrics", b.final_int_metrics, (size_t)b.num_int_metrics * 8},
       {"final_f64_metrics", b.final_f64_metrics, (size_t)b.num_f64_metrics * 8},
       {"error_flags", b.error_flags, 4},
+      {"debug", h->d_debug, 128},
   };
   for (const FieldDesc& f : fields)
     if (std::strcmp(f.name, name) == 0) {

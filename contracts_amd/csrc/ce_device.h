@@ -64,6 +64,7 @@ struct GridParams {
   int64_t* final_int_metrics;
   double* final_f64_metrics;
   uint32_t* error_flags;
+  unsigned long long* debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
   // inputs
   const uint8_t* actions;  // [E][n]
   const uint8_t* mask;     // [E] or null (seed/reset)

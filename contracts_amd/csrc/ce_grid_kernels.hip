@@ -76,6 +76,22 @@ DEVINL u32 wave_min_u32(u32 v) {
   return rdl(v, 63);
 }
 
+// Diagnostic builds (-DCE_PHASE_STAMPS) record s_memtime at phase boundaries of the step kernel
+// into GridParams.debug; in the shipped build CE_STAMP expands to nothing.
+#ifdef CE_PHASE_STAMPS
+#define CE_STAMP(k)                                                                    \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
+  } while (0)
+#else
+#define CE_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+
 // ----------------------------------------------------------------------------------------
 // MT19937 in LDS (numpy legacy RandomState stream)
 // ----------------------------------------------------------------------------------------
@@ -126,38 +142,31 @@ struct Rng {
   u32 cache;   // lane k: tempered word cbase + k
   u32 cbase;   // uniform
   u32 ccount;  // uniform; 0 = cache invalid
+  u64 cvalid;  // lanes < ccount
 };
+
+// make the per-lane cache cover stream words [pos, pos + ccount)
+DEVINL void rng_refill(Rng& r, u32 lane) {
+  if (r.pos >= (u32)kMtN) {
+    mt_twist(r.mt, lane);
+    r.pos = 0;
+  }
+  r.cbase = r.pos;
+  const u32 left = (u32)kMtN - r.pos;
+  r.ccount = left < 64u ? left : 64u;
+  r.cvalid = left < 64u ? ((1ull << left) - 1ull) : ~0ull;
+  const u32 idx = r.pos + lane;
+  r.cache = mt_temper(r.mt[idx < (u32)kMtN ? idx : (u32)kMtN - 1]);
+}
 
 DEVINL u32 rng_next(Rng& r, u32 lane) {
   u32 off = r.pos - r.cbase;
   if (off >= r.ccount) {
-    if (r.pos >= (u32)kMtN) {
-      mt_twist(r.mt, lane);
-      r.pos = 0;
-    }
-    r.cbase = r.pos;
-    u32 left = (u32)kMtN - r.pos;
-    r.ccount = left < 64u ? left : 64u;
-    u32 idx = r.pos + lane;
-    r.cache = mt_temper(r.mt[idx < (u32)kMtN ? idx : (u32)kMtN - 1]);
+    rng_refill(r, lane);
     off = 0;
   }
   r.pos += 1;
   return rdl(r.cache, off);
-}
-
-// legacy random_interval(max): masked rejection sampling, one word per attempt (max >= 1)
-DEVINL u32 rng_interval(Rng& r, u32 max, u32 lane) {
-  u32 mask = max;
-  mask |= mask >> 1;
-  mask |= mask >> 2;
-  mask |= mask >> 4;
-  mask |= mask >> 8;
-  u32 v;
-  do {
-    v = rng_next(r, lane) & mask;
-  } while (v > max);
-  return v;
 }
 
 // `count` tempered words of the stream into LDS (the rand(k) call of the spawn models)
@@ -191,28 +200,66 @@ DEVINL double rng_double(Rng& r, u32 lane) {
   return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
-// Fisher-Yates over a list held across lanes: element k (k < 64) in lane k of L0, element 64+k
-// in lane k of L1 (np.random.shuffle's untyped path: for i = len-1..1: j = interval(i); swap).
-DEVINL void shuffle_lanes(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
-  for (u32 i = len - 1; i >= 1 && len > 1; --i) {
-    u32 j = rng_interval(r, i, lane);
-    if (j != i) {
-      u32 vi = i < 64 ? rdl(L0, i) : rdl(L1, i - 64);
-      u32 vj = j < 64 ? rdl(L0, j) : rdl(L1, j - 64);
-      if (i < 64) L0 = wrl(vj, i, L0); else L1 = wrl(vj, i - 64, L1);
-      if (j < 64) L0 = wrl(vi, j, L0); else L1 = wrl(vi, j - 64, L1);
+// np.random.shuffle (untyped path): for i = len-1 .. 1: j = random_interval(i); swap(x[i], x[j]), over a
+// list held across lanes (element k < 64 in lane k of L0, element 64 + k in lane k of L1).
+// random_interval is masked rejection sampling, one stream word per attempt.  All cached words are tested
+// at once: the draw for index i is the first unread cached word whose masked value is <= i (one ballot +
+// find-first-set), the words before it are the rejected attempts.  The hot inner loop never leaves
+// registers; only the outer loop may refill the cache (and call the twist).
+template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
+  if (len < 2) return;
+  u32 i = len - 1;
+  u32 pos = r.pos, cbase = r.cbase, ccount = r.ccount, cache = r.cache;
+  u64 cvalid = r.cvalid;
+  u32 l0 = L0, l1 = L1;
+  while (i >= 1) {
+    u32 off = pos - cbase;
+    if (off >= ccount) {
+      r.pos = pos;
+      rng_refill(r, lane);
+      pos = r.pos;
+      cbase = r.cbase;
+      ccount = r.ccount;
+      cvalid = r.cvalid;
+      cache = r.cache;
+      off = 0;
+    }
+    u64 avail = cvalid & (~0ull << off);
+    while (i >= 1) {
+      const u32 mask = 0xffffffffu >> __builtin_clz(i);
+      const u32 v = cache & mask;
+      const u64 hit = ballot(v <= i) & avail;
+      if (hit == 0) {  // every remaining cached word is a rejected attempt for this i
+        pos = cbase + ccount;
+        break;
+      }
+      const u32 k = ctz64(hit);
+      const u32 j = rdl(v, k);
+      avail &= (~1ull << k);
+      pos = cbase + k + 1;
+      if (TWO) {
+        const u32 vi = rdl(i < 64 ? l0 : l1, i & 63);
+        const u32 vj = rdl(j < 64 ? l0 : l1, j & 63);
+        l0 = lane == i ? vj : l0;
+        l1 = lane + 64 == i ? vj : l1;
+        l0 = lane == j ? vi : l0;
+        l1 = lane + 64 == j ? vi : l1;
+      } else {
+        const u32 vi = rdl(l0, i), vj = rdl(l0, j);
+        l0 = lane == i ? vj : l0;
+        l0 = lane == j ? vi : l0;
+      }
+      --i;
     }
   }
+  r.pos = pos;
+  L0 = l0;
+  L1 = l1;
 }
+DEVINL void shuffle_lanes(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) { shuffle_core<true>(r, L0, L1, len, lane); }
 DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
-  for (u32 i = len - 1; i >= 1 && len > 1; --i) {
-    u32 j = rng_interval(r, i, lane);
-    if (j != i) {
-      u32 vi = rdl(L0, i), vj = rdl(L0, j);
-      L0 = wrl(vj, i, L0);
-      L0 = wrl(vi, j, L0);
-    }
-  }
+  u32 dummy = 0;
+  shuffle_core<false>(r, L0, dummy, len, lane);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -295,6 +342,7 @@ template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
   E.rng.pos = rfl(p.rng[(size_t)E.e * kRngStride + kMtN]);
   E.rng.cbase = 0;
   E.rng.ccount = 0;
+  E.rng.cvalid = 0;
   E.rng.cache = 0;
   wave_sync();
 }
@@ -378,6 +426,77 @@ template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, b
     wp[E.lane] = (uint8_t)E.WP0;
     if (E.lane + 64 < 119) wp[E.lane + 64] = (uint8_t)E.WP1;
   }
+}
+
+// All of an env's state in one go: every global load is issued first (they overlap in flight), then the
+// LDS image (MT words, padded map) is built.  Used by the step kernel.
+template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  const u32 lane = E.lane;
+  constexpr u32 NDW = (G::CELLS + 3) / 4;
+  const uint4* rsrc = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
+  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64];
+  uint4 r2 = make_uint4(0, 0, 0, 0);
+  if (lane + 128 < kMtN / 4) r2 = rsrc[lane + 128];
+  const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
+  const u32* gsrc = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
+  u32 gw[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) gw[r] = lane + 64 * r < NDW ? gsrc[lane + 64 * r] : 0u;
+  u32 aw = 0;
+  if (E.is_agent) aw = ((const u32*)p.agents)[(size_t)E.e * E.n + lane];
+  E.SP = lane < 20 ? p.spawn_perm[(size_t)E.e * 20 + lane] : 0;
+  E.WP0 = E.WP1 = 0;
+  if (KIND == CE_KIND_CLEANUP) {
+    const uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
+    E.WP0 = wp[lane];
+    E.WP1 = lane + 64 < 119 ? wp[lane + 64] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const u32 idx = lane + 64 * r;
+    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const u32 idx = lane + 64 * r;
+    E.WS[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+  }
+  const u32 rgbv = c_rgb[lane & 15];
+  // ---- LDS image ----
+  u32* pm32 = (u32*)E.L->pmap;
+  for (u32 k = lane; k < (u32)G::PCELLS / 4; k += 64) pm32[k] = 0;
+  if (lane < 16) E.L->rgb[lane] = rgbv;
+  uint4* mt4 = (uint4*)E.L->mt;
+  mt4[lane] = r0;
+  mt4[lane + 64] = r1;
+  if (lane + 128 < kMtN / 4) mt4[lane + 128] = r2;
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (64 * r < (int)NDW) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const u32 idx = 4 * (lane + 64 * r) + bb;
+        if (idx < (u32)G::CELLS) {
+          const u32 row = idx / G::W, col = idx - row * G::W;
+          E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((gw[r] >> (8 * bb)) & 0xff);
+        }
+      }
+    }
+  }
+  E.rng.mt = E.L->mt;
+  E.rng.pos = rfl(rpos);
+  E.rng.cbase = 0;
+  E.rng.ccount = 0;
+  E.rng.cvalid = 0;
+  E.rng.cache = 0;
+  E.P = pad_of<KIND>(aw & 0xff, (aw >> 8) & 0xff);
+  E.O = (aw >> 16) & 3;
+  E.RW = 0;
+  if (!E.is_agent) E.P = 0xffffu;
+  wave_sync();
 }
 
 // ----------------------------------------------------------------------------------------
@@ -665,19 +784,31 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   const u32 units = (npix + 3) / 4;
   uint8_t* dst_env = p.obs + (size_t)E.e * p.obs_env_stride;
   for (u32 u = lane; u < units; u += 64) {
-    const uint2 ent2 = *(const uint2*)(c_pix + 4 * u);
+    // env-wide pixel q -> (agent, i, j): q = 225 a + 15 i + j (exact multiply-shift divisions for q < 2032)
+    const u32 q0 = 4 * u;
+    u32 a = (q0 * 4661u) >> 20;
+    const u32 pq = q0 - 225u * a;
+    u32 i = (pq * 2185u) >> 15;
+    u32 j = pq - 15u * i;
     u32 col[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const u32 ent = (k < 2 ? ent2.x : ent2.y) >> (16 * (k & 1)) & 0xffffu;
-      const u32 a = ent >> 8, i = (ent >> 4) & 15u, j = ent & 15u;
       u32 c = 0;
-      if (4 * u + k < npix) {
+      if (q0 + k < npix) {
         const u32 vw = E.L->view[a];
         const i32 off = (i32)(vw & 0xffffu) + (i32)i * ((i32)(vw << 8) >> 24) + (i32)j * ((i32)vw >> 24);
         c = E.L->rgb[pm[off]];
       }
       col[k] = c;
+      j += 1;
+      if (j == 15) {
+        j = 0;
+        i += 1;
+        if (i == 15) {
+          i = 0;
+          a += 1;
+        }
+      }
     }
     const u32 d0 = (col[0] & 0xffffffu) | (col[1] << 24);
     const u32 d1 = ((col[1] >> 8) & 0xffffu) | (col[2] << 16);
@@ -833,16 +964,15 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       for (int r = 0; r < 3; ++r) {
         if (64 * r < G::NAPPLE) {
           const i32 d = abs((i32)cell_row(E.AP[r]) - ar) + abs((i32)cell_col(E.AP[r]) - ac);
-          const u32 k2 = aflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
-          key = k2 < key ? k2 : key;
+          const u32 k2 = aflag[r] ? ((u32)d << 11 | cell_row(E.AP[r]) << 6 | cell_col(E.AP[r])) : 0xffffffffu;
+          key = k2 < key ? k2 : key;  // ties: smallest (row, col) == first in the row-major list (np.argmin)
         }
       }
       const u32 best = wave_min_u32(key);
       u32 br = 0, bc = 0;
       if (best != 0xffffffffu) {
-        const u32 cellp = T.apple[best & 0xffu];
-        br = cell_row(cellp);
-        bc = cell_col(cellp);
+        br = (best >> 6) & 31u;
+        bc = best & 63u;
       }
       if (lane == a) { ca_r = br; ca_c = bc; }
       if (KIND == CE_KIND_CLEANUP) {
@@ -850,15 +980,14 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const i32 d = abs((i32)cell_row(E.WS[r]) - ar) + abs((i32)cell_col(E.WS[r]) - ac);
-          const u32 k2 = wflag[r] ? ((u32)d << 8 | (lane + 64 * r)) : 0xffffffffu;
+          const u32 k2 = wflag[r] ? ((u32)d << 11 | cell_row(E.WS[r]) << 6 | cell_col(E.WS[r])) : 0xffffffffu;
           keyw = k2 < keyw ? k2 : keyw;
         }
         const u32 bw = wave_min_u32(keyw);
         u32 wr = 0, wc = 0;
         if (bw != 0xffffffffu) {
-          const u32 cellp = T.waste[bw & 0xffu];
-          wr = cell_row(cellp);
-          wc = cell_col(cellp);
+          wr = (bw >> 6) & 31u;
+          wc = bw & 63u;
         }
         if (lane == a) { cw_r = wr; cw_c = wc; }
       } else {
@@ -977,7 +1106,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridPara
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(256, 7) void k_grid_step(GridParams p) {
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
@@ -992,11 +1121,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
     if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
     return;
   }
-  load_static(E);
-  load_rng(E, p);
-  load_grid(E, p);
-  load_agents(E, p);
-  load_perms(E, p);
+  CE_STAMP(0);
+  load_env_state(E, p);
   u32 t = (u32)p.timestep[E.e];
   double theta = p.theta[E.e];
   u32 fault = 0;
@@ -1004,7 +1130,9 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
 
   // ---------------- MapEnv.step ----------------
   t += 1;
+  CE_STAMP(1);
   update_moves(E, ACT);
+  CE_STAMP(2);
   if (!E.is_agent) E.P = 0xffffu;
 
   // eaten_apples: final position held an apple when the step was entered (nothing has touched
@@ -1049,7 +1177,9 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
       }
     }
   }
+  CE_STAMP(3);
   custom_map_update(E);
+  CE_STAMP(4);
 
   // ---------------- rewards ----------------
   i32 base_rew = E.is_agent ? E.RW : 0;
@@ -1072,9 +1202,19 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
   }
 
   // ---------------- infos, metrics, feature obs ----------------
+  // metric accumulators: loads are issued here and consumed after the feature pass (latency hidden)
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
   int64_t* mi = p.int_metrics + (size_t)E.e * nmi;
   double* mf = p.f64_metrics + (size_t)E.e * nmf;
+  const u32 la = E.is_agent ? lane : 0;
+  long long m_a = mi[CE_MI_AGENT(n, CE_MIA_A, la)], m_b = mi[CE_MI_AGENT(n, CE_MIA_B, la)];
+  long long m_sr = mi[CE_MI_AGENT(n, CE_MIA_SUM_R, la)], m_str = mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, la)];
+  double f_sr = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, la)], f_str = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, la)];
+  long long g_m = lane < 4 ? mi[lane < 4 ? lane : 0] : 0;  // lane k < 4 holds global metric k
+  double f_transfers = mf[CE_MF_TRANSFERS];
+  CE_STAMP(5);
+  const u32 feat8 = compute_features(E, p, cleaned);
+  CE_STAMP(6);
   {
     u32 sum_eaten = 0, sum_clean = 0, sum_close = 0;
     i32 sum_rew = 0;
@@ -1084,20 +1224,15 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
       sum_close += rdl(eaten_close, b);
       sum_rew += shfl_i32(base_rew, b);
     }
-    if (lane == 0) {
-      mi[CE_MI_TOTAL_APPLES_EATEN] += sum_eaten;
-      mi[CE_MI_RAW_ENV_REWARDS] += sum_rew;
-      if (KIND == CE_KIND_CLEANUP) mi[CE_MI_DIRT_CLEANED] += sum_clean;
-      else mi[CE_MI_LOW_DENSITY_APPLES] += sum_close;
-    }
-    if (E.is_agent) {
-      mi[CE_MI_AGENT(n, CE_MIA_A, lane)] += KIND == CE_KIND_CLEANUP ? cleaned : eaten;
-      if (KIND == CE_KIND_HARVEST) mi[CE_MI_AGENT(n, CE_MIA_B, lane)] += eaten_close;
-      mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] += base_rew;
-      mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] += (long long)(t - 1) * base_rew;
-    }
+    if (lane == CE_MI_TOTAL_APPLES_EATEN) g_m += sum_eaten;
+    if (lane == CE_MI_RAW_ENV_REWARDS) g_m += sum_rew;
+    if (lane == CE_MI_DIRT_CLEANED && KIND == CE_KIND_CLEANUP) g_m += sum_clean;
+    if (lane == CE_MI_LOW_DENSITY_APPLES && KIND == CE_KIND_HARVEST) g_m += sum_close;
+    m_a += KIND == CE_KIND_CLEANUP ? cleaned : eaten;
+    if (KIND == CE_KIND_HARVEST) m_b += eaten_close;
+    m_sr += base_rew;
+    m_str += (long long)(t - 1) * base_rew;
   }
-  const u32 feat8 = compute_features(E, p, cleaned);
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   if (p.contract != CE_CONTRACT_NONE) {
     double tr;
@@ -1111,13 +1246,22 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
       else rew += ti / nm1;
       total += ti;
     }
-    if (lane == 0) mf[CE_MF_TRANSFERS] += total;
-    if (E.is_agent) {
-      mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] += rew;
-      mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] += (double)(t - 1) * rew;
-    }
+    f_transfers += total;
+    f_sr += rew;
+    f_str += (double)(t - 1) * rew;
   }
   const bool done = t == p.horizon;
+  // running metrics back to HBM
+  if (lane < 4) mi[lane] = g_m;
+  if (lane == 0) mf[CE_MF_TRANSFERS] = f_transfers;
+  if (E.is_agent) {
+    mi[CE_MI_AGENT(n, CE_MIA_A, lane)] = m_a;
+    mi[CE_MI_AGENT(n, CE_MIA_B, lane)] = m_b;
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] = m_sr;
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] = m_str;
+    mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] = f_sr;
+    mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] = f_str;
+  }
   if (E.is_agent) {
     p.base_reward[ia] = base_rew;
     p.reward[ia] = rew;
@@ -1128,9 +1272,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
   bool did_reset = false;
   if (done) {
     // equality / sustainability (cleanup_new.py:422-445) and their transferred versions
-    __threadfence_block();
-    const long long sr = E.is_agent ? mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane < n ? lane : 0)] : 0;
-    const long long str_ = E.is_agent ? mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane < n ? lane : 0)] : 0;
+    const long long sr = E.is_agent ? m_sr : 0;
+    const long long str_ = E.is_agent ? m_str : 0;
     long long eq = 0, total = 0;
     for (u32 i = 0; i < n; ++i) {
       const long long ri = shfl_i64(sr, i);
@@ -1146,8 +1289,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
     const double sust = np_sum_lanes((double)str_ / (double)den, n) / (double)n;
     double teq = 0.0, tsust = 0.0;
     if (p.contract != CE_CONTRACT_NONE) {
-      const double fr = E.is_agent ? mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane < n ? lane : 0)] : 0.0;
-      const double ftr = E.is_agent ? mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane < n ? lane : 0)] : 0.0;
+      const double fr = E.is_agent ? f_sr : 0.0;
+      const double ftr = E.is_agent ? f_str : 0.0;
       double e2 = 0.0, tot = 0.0;
       for (u32 i = 0; i < n; ++i) {
         const double ri = shfl_f64(fr, i);
@@ -1175,6 +1318,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
     }
   }
 
+  CE_STAMP(7);
   // ---------------- state out, then the observation ----------------
   store_grid(E, p);
   store_agents(E, p);
@@ -1186,7 +1330,9 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_step(GridParam
     if (did_reset) p.theta[E.e] = theta;
     if (fault) p.error_flags[E.e] |= fault;
   }
+  CE_STAMP(8);
   write_obs(E, p, !did_reset);
+  CE_STAMP(9);
 }
 
 // ----------------------------------------------------------------------------------------

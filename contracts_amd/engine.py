@@ -25,7 +25,7 @@ _FIELD_DTYPES = {
     "timestep": np.int32, "theta": np.float64, "sd_state": np.float64, "obs": np.uint8, "obs_f64": np.float64,
     "base_reward": np.int32, "reward": np.float64, "done": np.uint8, "done_agents": np.uint8, "info": np.uint8,
     "features": np.int16, "int_metrics": np.int64, "f64_metrics": np.float64, "final_int_metrics": np.int64,
-    "final_f64_metrics": np.float64, "error_flags": np.uint32,
+    "final_f64_metrics": np.float64, "error_flags": np.uint32, "debug": np.uint64,
 }
 
 
@@ -156,7 +156,7 @@ class BatchedEnv:
             "obs": (b.obs_env_stride,), "obs_f64": (n, 2 * n + 7), "base_reward": (n,), "reward": (n,), "done": (),
             "done_agents": (n,), "info": (n, 2), "features": (n, b.num_features), "int_metrics": (b.num_int_metrics,),
             "f64_metrics": (b.num_f64_metrics,), "final_int_metrics": (b.num_int_metrics,),
-            "final_f64_metrics": (b.num_f64_metrics,), "error_flags": (),
+            "final_f64_metrics": (b.num_f64_metrics,), "error_flags": (), "debug": (16,),
         }[field]
 
     def download(self, field, env_begin=0, env_count=None, raw=False):

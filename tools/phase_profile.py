@@ -1,0 +1,30 @@
+"""Diagnostic: per-phase cycle shares of k_grid_step from an instrumented build
+(CE_PHASE_STAMPS=1 python -m contracts_amd.build --force).  Never used for reported numbers."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+from contracts_amd.engine import BatchedEnv
+
+E, n = 16384, 8
+env = BatchedEnv("cleanup", E, n, contract="cleanup", auto_reset=True)
+env.seed(seed0=73907)
+env.reset()
+T = 260
+acts = torch.empty((T, E, n), dtype=torch.uint8, device="cuda")
+env.synth_actions(73908, 0, T, acts.data_ptr())
+names = ["load", "moves", "consume+beams", "spawn", "rewards+metrics", "features", "contract+done", "store", "obs"]
+acc = np.zeros(9)
+cnt = 0
+for t in range(T):
+    env.step_device(acts.data_ptr() + t * E * n)
+    if t >= 200:
+        d = env.download("debug").astype(np.int64)
+        acc += np.diff(d[:, :10], axis=1).mean(axis=0)
+        tot = (d[:, 9] - d[:, 0])
+        cnt += 1
+acc /= cnt
+print("mean cycles per wave per phase (s_memtime ticks):")
+for k, v in zip(names, acc):
+    print("  %-18s %9.0f  %5.1f%%" % (k, v, 100 * v / acc.sum()))
+print("  total %.0f ; p50/p90/max of last step %s" % (acc.sum(), np.percentile(tot, [50, 90, 100])))
