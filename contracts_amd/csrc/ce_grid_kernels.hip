@@ -200,12 +200,21 @@ DEVINL double rng_double(Rng& r, u32 lane) {
   return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
+// clang exposes no builtin for v_writelane_b32, but the LLVM intrinsic can be declared directly; the
+// compiler then manages M0 (gfx9 needs the lane select in M0 when the value is an SGPR too) and the
+// VALU-writes-SGPR -> lane-select hazard.  `val` and `sel` must be wave-uniform.
+extern "C" __device__ int ce_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) {
+  return (u32)ce_llvm_writelane((int)val, (int)sel, (int)old);
+}
+
 // np.random.shuffle (untyped path): for i = len-1 .. 1: j = random_interval(i); swap(x[i], x[j]), over a
 // list held across lanes (element k < 64 in lane k of L0, element 64 + k in lane k of L1).
 // random_interval is masked rejection sampling, one stream word per attempt.  All cached words are tested
 // at once: the draw for index i is the first unread cached word whose masked value is <= i (one ballot +
-// find-first-set), the words before it are the rejected attempts.  The hot inner loop never leaves
-// registers; only the outer loop may refill the cache (and call the twist).
+// find-first-set), the words before it are the rejected attempts.  Indices are walked in segments that
+// share a mask (2^k .. 2^(k+1)-1) so the masked words are computed once per segment; the hot inner loop
+// is ~16 instructions, all in registers; only the outermost loop may refill the cache (and call the twist).
 template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
   if (len < 2) return;
   u32 i = len - 1;
@@ -213,43 +222,61 @@ template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, 
   u64 cvalid = r.cvalid;
   u32 l0 = L0, l1 = L1;
   while (i >= 1) {
-    u32 off = pos - cbase;
-    if (off >= ccount) {
-      r.pos = pos;
-      rng_refill(r, lane);
-      pos = r.pos;
-      cbase = r.cbase;
-      ccount = r.ccount;
-      cvalid = r.cvalid;
-      cache = r.cache;
-      off = 0;
-    }
-    u64 avail = cvalid & (~0ull << off);
-    while (i >= 1) {
-      const u32 mask = 0xffffffffu >> __builtin_clz(i);
+    const u32 lo = 1u << (31 - __builtin_clz(i));  // segment [lo, i] shares mask 2*lo - 1
+    const u32 mask = 2 * lo - 1;
+    while (i >= lo) {
+      u32 off = pos - cbase;
+      if (off >= ccount) {
+        r.pos = pos;
+        rng_refill(r, lane);
+        pos = r.pos;
+        cbase = r.cbase;
+        ccount = r.ccount;
+        cvalid = r.cvalid;
+        cache = r.cache;
+        off = 0;
+      }
+      u64 avail = cvalid & (~0ull << off);
       const u32 v = cache & mask;
-      const u64 hit = ballot(v <= i) & avail;
-      if (hit == 0) {  // every remaining cached word is a rejected attempt for this i
-        pos = cbase + ccount;
-        break;
-      }
-      const u32 k = ctz64(hit);
-      const u32 j = rdl(v, k);
-      avail &= (~1ull << k);
-      pos = cbase + k + 1;
-      if (TWO) {
-        const u32 vi = rdl(i < 64 ? l0 : l1, i & 63);
-        const u32 vj = rdl(j < 64 ? l0 : l1, j & 63);
-        l0 = lane == i ? vj : l0;
-        l1 = lane + 64 == i ? vj : l1;
-        l0 = lane == j ? vi : l0;
-        l1 = lane + 64 == j ? vi : l1;
+      if (TWO && lo >= 64) {
+        for (;;) {  // x[i] lives in L1, x[j] in either register
+          const u64 hit = ballot(v <= i) & avail;
+          if (hit == 0) {  // every remaining cached word is a rejected attempt for this i
+            pos = cbase + ccount;
+            break;
+          }
+          const u32 k = ctz64(hit);
+          const u32 j = rdl(v, k);
+          avail &= (~1ull << k);
+          pos = cbase + k + 1;
+          const u32 jm = j & 63, im = i - 64;
+          const u32 vi = rdl(l1, im), a0 = rdl(l0, jm), b0 = rdl(l1, jm);
+          const bool jlow = j < 64;
+          const u32 vj = jlow ? a0 : b0;
+          l0 = writelane<2>(jlow ? vi : a0, jm, l0);
+          l1 = writelane<0>(jlow ? b0 : vi, jm, l1);
+          l1 = writelane<0>(vj, im, l1);  // last: wins when jm == im with j < 64
+          --i;
+          if (i < lo) break;
+        }
       } else {
-        const u32 vi = rdl(l0, i), vj = rdl(l0, j);
-        l0 = lane == i ? vj : l0;
-        l0 = lane == j ? vi : l0;
+        for (;;) {
+          const u64 hit = ballot(v <= i) & avail;
+          if (hit == 0) {
+            pos = cbase + ccount;
+            break;
+          }
+          const u32 k = ctz64(hit);
+          const u32 j = rdl(v, k);
+          avail &= (~1ull << k);
+          pos = cbase + k + 1;
+          const u32 vi = rdl(l0, i), vj = rdl(l0, j);
+          l0 = writelane<0>(vj, i, l0);
+          l0 = writelane<2>(vi, j, l0);
+          --i;
+          if (i < lo) break;
+        }
       }
-      --i;
     }
   }
   r.pos = pos;
