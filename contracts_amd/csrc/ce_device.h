@@ -23,11 +23,15 @@ template <int KIND> struct Geo;
 template <> struct Geo<CE_KIND_CLEANUP> {
   static constexpr int H = 25, W = 18, CELLS = 450, PW = 32, PH = 39, PCELLS = PW * PH;
   static constexpr int NAPPLE = 103, NWASTE = 119, RANDW = 2 * (103 + 119), NSPAWN_CTOR = 10;
+  // LDS keeps the words of the apple doubles only; of a waste double only "u < 0.5" matters, which is
+  // bit 31 of its first word (kept as one byte per double)
+  static constexpr int UWORDS = 2 * 103, SBYTES = 224;
   static constexpr int GRID_STRIDE = 464;  // bytes per env row in HBM (CELLS rounded up to 16)
 };
 template <> struct Geo<CE_KIND_HARVEST> {
   static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
   static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
+  static constexpr int UWORDS = 2 * 155, SBYTES = 16;
   static constexpr int GRID_STRIDE = 608;
 };
 

@@ -19,6 +19,7 @@
 //   numpy legacy RandomState shuffle / random_sample / randint / uniform (MT19937)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ce_device.h"
 
@@ -86,9 +87,19 @@ DEVINL u32 wave_min_u32(u32 v) {
     __builtin_amdgcn_sched_barrier(0);                                                 \
     if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
   } while (0)
+#define CE_SUBSTAMP(k)                                                                 \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (lane == 0 && E.dbg) E.dbg[(k)] = t_;                                           \
+  } while (0)
 #else
 #define CE_STAMP(k) \
   do {              \
+  } while (0)
+#define CE_SUBSTAMP(k) \
+  do {                 \
   } while (0)
 #endif
 
@@ -169,8 +180,10 @@ DEVINL u32 rng_next(Rng& r, u32 lane) {
   return rdl(r.cache, off);
 }
 
-// `count` tempered words of the stream into LDS (the rand(k) call of the spawn models)
-DEVINL void rng_bulk(Rng& r, u32* U, u32 count, u32 lane) {
+// The rand(k) call of the spawn models: `count` stream words are consumed.  The first `keep` tempered words
+// go to U (the doubles that are compared against a real threshold); for every double d the byte S[d] records
+// "u_d < 0.5", i.e. bit 31 of its first word is clear (X < 2^52 <=> (a >> 5) < 2^26 <=> a < 2^31).
+DEVINL void rng_bulk(Rng& r, u32* U, uint8_t* S, u32 count, u32 keep, bool want_s, u32 lane) {
   u32 done = 0;
   while (done < count) {
     if (r.pos >= (u32)kMtN) {
@@ -179,7 +192,12 @@ DEVINL void rng_bulk(Rng& r, u32* U, u32 count, u32 lane) {
     }
     u32 chunk = (u32)kMtN - r.pos;
     if (chunk > count - done) chunk = count - done;
-    for (u32 k = lane; k < chunk; k += 64) U[done + k] = mt_temper(r.mt[r.pos + k]);
+    for (u32 k = lane; k < chunk; k += 64) {
+      const u32 w = mt_temper(r.mt[r.pos + k]);
+      const u32 sidx = done + k;
+      if (sidx < keep) U[sidx] = w;
+      if (want_s && (sidx & 1u) == 0) S[sidx >> 1] = (uint8_t)((w >> 31) ^ 1u);
+    }
     r.pos += chunk;
     done += chunk;
   }
@@ -238,17 +256,19 @@ template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, 
       }
       u64 avail = cvalid & (~0ull << off);
       const u32 v = cache & mask;
+      u32 lastk = 0xffffffffu;  // last accepted cached word of this run (pos is derived at exit)
+      bool exhausted = false;
       if (TWO && lo >= 64) {
-        for (;;) {  // x[i] lives in L1, x[j] in either register
+        do {  // x[i] lives in L1, x[j] in either register
           const u64 hit = ballot(v <= i) & avail;
           if (hit == 0) {  // every remaining cached word is a rejected attempt for this i
-            pos = cbase + ccount;
+            exhausted = true;
             break;
           }
           const u32 k = ctz64(hit);
           const u32 j = rdl(v, k);
           avail &= (~1ull << k);
-          pos = cbase + k + 1;
+          lastk = k;
           const u32 jm = j & 63, im = i - 64;
           const u32 vi = rdl(l1, im), a0 = rdl(l0, jm), b0 = rdl(l1, jm);
           const bool jlow = j < 64;
@@ -257,26 +277,26 @@ template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, 
           l1 = writelane<0>(jlow ? b0 : vi, jm, l1);
           l1 = writelane<0>(vj, im, l1);  // last: wins when jm == im with j < 64
           --i;
-          if (i < lo) break;
-        }
+        } while (i >= lo);
       } else {
-        for (;;) {
+        do {
           const u64 hit = ballot(v <= i) & avail;
           if (hit == 0) {
-            pos = cbase + ccount;
+            exhausted = true;
             break;
           }
           const u32 k = ctz64(hit);
           const u32 j = rdl(v, k);
           avail &= (~1ull << k);
-          pos = cbase + k + 1;
+          lastk = k;
           const u32 vi = rdl(l0, i), vj = rdl(l0, j);
           l0 = writelane<0>(vj, i, l0);
           l0 = writelane<2>(vi, j, l0);
           --i;
-          if (i < lo) break;
-        }
+        } while (i >= lo);
       }
+      if (exhausted) pos = cbase + ccount;
+      else if (lastk != 0xffffffffu) pos = cbase + lastk + 1;
     }
   }
   r.pos = pos;
@@ -294,12 +314,18 @@ DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
 // ----------------------------------------------------------------------------------------
 template <int KIND> struct alignas(16) WaveLds {
   u32 mt[kMtN];
-  u32 U[Geo<KIND>::RANDW];
+  u32 U[Geo<KIND>::UWORDS];
+  uint8_t S[Geo<KIND>::SBYTES];
   uint8_t pmap[Geo<KIND>::PCELLS];
   u32 view[12];  // per agent: o0 | A << 16 | B << 24 of the crop address off = o0 + i*A + j*B
   u32 rgb[16];
 };
 
+// While a step is in flight, bit 7 of a padded-map byte marks "an agent stands here" (set right after
+// update_moves / setup_agents); the cell code is the low 7 bits.  It turns every "is an agent on this
+// cell" query of the beam / spawn code into the LDS read that is needed anyway.
+constexpr uint8_t kAgentBit = 0x80;
+constexpr u32 kCodeMask = 0x7fu;
 constexpr u32 kCellPadMask = 0x7ffu;
 DEVINL u32 cell_pad(u32 packed) { return packed & kCellPadMask; }
 DEVINL u32 cell_row(u32 packed) { return (packed >> 11) & 31u; }
@@ -322,6 +348,7 @@ template <int KIND> struct Env {
   // static lane data: packed cells handled by this lane in round r
   u32 AP[3];
   u32 WS[2];
+  unsigned long long* dbg;  // diagnostic builds only
 };
 
 DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-index deltas
@@ -333,6 +360,11 @@ template <int KIND> DEVINL u32 row_of(u32 pad) { return pad / Geo<KIND>::PW - kV
 template <int KIND> DEVINL u32 col_of(u32 pad) { return pad % Geo<KIND>::PW - kView; }
 
 // is some agent standing on padded cell `cell` (per-lane query); returns highest agent id + 1 or 0
+template <int KIND> DEVINL void mark_agents(Env<KIND>& E) {
+  wave_sync();
+  if (E.is_agent) E.L->pmap[E.P] = (uint8_t)(E.L->pmap[E.P] | kAgentBit);
+  wave_sync();
+}
 template <int KIND> DEVINL u32 agent_on(const Env<KIND>& E, u32 cell) {
   u32 hit = 0;
   for (u32 b = 0; b < E.n; ++b) {
@@ -416,7 +448,7 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
       u32 idx = 4 * k + bb;
       if (idx < (u32)G::CELLS) {
         u32 row = idx / G::W, col = idx - row * G::W;
-        w |= (u32)E.L->pmap[pad_of<KIND>(row, col)] << (8 * bb);
+        w |= (u32)(E.L->pmap[pad_of<KIND>(row, col)] & kCodeMask) << (8 * bb);
       }
     }
     dst[k] = w;
@@ -660,10 +692,11 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean)
   if (ray == 1) start += rr - dd;
   if (ray == 2) start += -rr - dd;
   const u32 cell = in_beam ? (u32)(start + (i32)(step + 1) * dd) : 0u;
-  const u32 code = E.L->pmap[cell];
+  const u32 raw = E.L->pmap[cell];
+  const u32 code = raw & kCodeMask;
   const bool invalid = code == CE_CELL_WALL;
-  const u32 hit = agent_on(E, cell);  // highest agent id on the cell + 1 (agent_by_pos: later wins)
-  const bool stopper = invalid || hit != 0 || (is_clean && code == CE_CELL_WASTE);
+  const bool agent_here = in_beam && (raw & kAgentBit) != 0;
+  const bool stopper = invalid || agent_here || (is_clean && code == CE_CELL_WASTE);
   const u64 S = ballot(in_beam && stopper);
   const u32 rb = (u32)(S >> (5 * ray)) & 31u;
   const u32 f = rb ? (u32)__builtin_ctz(rb) : 5u;  // first stopping cell of this ray
@@ -673,12 +706,16 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean)
     const bool upd = processed && code == CE_CELL_WASTE;
     cleaned = popc64(ballot(upd));
     wave_sync();
-    if (upd) E.L->pmap[cell] = CE_CELL_RIVER;
+    if (upd) E.L->pmap[cell] = (uint8_t)(CE_CELL_RIVER | (raw & kAgentBit));
     wave_sync();
   } else {
-    for (u64 hm = ballot(processed && hit != 0); hm; hm &= hm - 1) {
-      const u32 hid = rdl(hit, ctz64(hm)) - 1;
-      if (lane == hid) E.RW -= 50;  // Agent.hit(b"F")
+    const u64 hm0 = ballot(processed && agent_here);
+    if (hm0) {
+      const u32 hit = agent_on(E, cell);  // highest agent id on the cell + 1 (agent_by_pos: later wins)
+      for (u64 hm = hm0; hm; hm &= hm - 1) {
+        const u32 hid = rdl(hit, ctz64(hm)) - 1;
+        if (lane == hid) E.RW -= 50;  // Agent.hit(b"F")
+      }
     }
   }
   return cleaned;
@@ -699,19 +736,20 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
-      nH += popc64(ballot(v && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE));
+      nH += popc64(ballot(v && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE));
     }
     const u64 thr = T.apple_thresh[nH];
     const bool waste_on = T.waste_on[nH] != 0;
-    rng_bulk(E.rng, E.L->U, (u32)G::RANDW, lane);
+    CE_SUBSTAMP(10);
+    rng_bulk(E.rng, E.L->U, E.L->S, (u32)G::RANDW, (u32)G::UWORDS, true, lane);
+    CE_SUBSTAMP(11);
     u32 rbase = 0;
     bool spawnA[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NAPPLE;
       const u32 cell = cell_pad(E.AP[r]);
-      const u32 occupied = agent_on(E, cell);
-      const bool elig = v && pm[cell] != CE_CELL_APPLE && occupied == 0;
+      const bool elig = v && pm[cell] == CE_CELL_EMPTY;  // apple cell, no apple, no agent (bit 7)
       const u64 eb = ballot(elig);
       const u32 ri = rbase + popc64(eb & lt);
       const u64 x = u53(E.L->U, elig ? ri : 0);
@@ -720,25 +758,39 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
     u32 waste_cell = 0;
     bool waste_found = false;
+    CE_SUBSTAMP(12);
     if (waste_on) {
       shuffle_lanes(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+      CE_SUBSTAMP(13);
+      // The walk over the shuffled list hands double rbase + t to the t-th non-waste cell and stops at the
+      // first u < 0.5: t* = first set byte of S from rbase on, independent of the permutation.
+      const u32 ncand = (u32)G::NWASTE - nH;
+      u32 tstar = 0xffffffffu;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (!waste_found) {
-          const bool v = lane + 64 * r < (u32)G::NWASTE;
-          const u32 widx = r == 0 ? E.WP0 : E.WP1;
-          const u32 cell = cell_pad(T.waste[v ? widx : 0]);
-          const bool cand = v && pm[cell] != CE_CELL_WASTE;
-          const u64 cb = ballot(cand);
-          const u32 ri = rbase + popc64(cb & lt);
-          const u64 x = u53(E.L->U, cand ? ri : 0);
-          const bool ok = cand && x < (1ull << 52);  // u < 0.5
-          const u64 ob = ballot(ok);
-          if (ob) {
-            waste_found = true;
-            waste_cell = rdl(cell, ctz64(ob));
+        if (tstar == 0xffffffffu && (u32)(64 * r) < ncand) {
+          const u32 t = lane + 64 * r;
+          const u64 sb = ballot(t < ncand && E.L->S[rbase + (t < ncand ? t : 0)] != 0);
+          if (sb) tstar = ctz64(sb) + 64 * r;
+        }
+      }
+      if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
+        u32 seen = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          if (!waste_found) {
+            const bool v = lane + 64 * r < (u32)G::NWASTE;
+            const u32 widx = r == 0 ? E.WP0 : E.WP1;
+            const u32 cell = cell_pad(T.waste[v ? widx : 0]);
+            const bool cand = v && (pm[cell] & kCodeMask) != CE_CELL_WASTE;
+            const u64 cb = ballot(cand);
+            const u64 sel = ballot(cand && seen + popc64(cb & lt) == tstar);
+            if (sel) {
+              waste_found = true;
+              waste_cell = rdl(cell, ctz64(sel));
+            }
+            seen += popc64(cb);
           }
-          rbase += popc64(cb);
         }
       }
     }
@@ -746,18 +798,17 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
       if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
-    if (waste_found && lane == 0) pm[waste_cell] = CE_CELL_WASTE;
+    if (waste_found && lane == 0) pm[waste_cell] = (uint8_t)(CE_CELL_WASTE | (pm[waste_cell] & kAgentBit));
     wave_sync();
   } else {
-    rng_bulk(E.rng, E.L->U, (u32)G::RANDW, lane);
+    rng_bulk(E.rng, E.L->U, E.L->S, (u32)G::RANDW, (u32)G::UWORDS, false, lane);
     u32 rbase = 0;
     bool spawnA[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const bool v = lane + 64 * r < (u32)G::NAPPLE;
       const u32 cell = cell_pad(E.AP[r]);
-      const u32 occupied = agent_on(E, cell);
-      const bool elig = v && pm[cell] != CE_CELL_APPLE && occupied == 0;
+      const bool elig = v && pm[cell] == CE_CELL_EMPTY;  // apple cell, no apple, no agent (bit 7)
       // apples in the 3x3 block around the cell (j^2 + k^2 <= APPLE_RADIUS = 2), pre-update map
       u32 num = 0;
       if (elig) {
@@ -796,6 +847,9 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
       if (lane == 0) pm[pa] = (uint8_t)(6 + a);
       wave_sync();
     }
+  } else {
+    if (E.is_agent) pm[E.P] = (uint8_t)(pm[E.P] & kCodeMask);  // reset(): agents are not on the colour map
+    wave_sync();
   }
   if (E.is_agent) {
     const i32 base = (i32)E.P - kView * G::PW - kView;
@@ -942,7 +996,7 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
     u32* dst = (u32*)E.L->pmap;
     for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k];
   }
-  wave_sync();
+  mark_agents(E);
   zero_metrics(E, p);
   custom_map_update(E);
   t = 0;
@@ -978,7 +1032,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        wflag[r] = lane + 64 * r < (u32)G::NWASTE && pm[cell_pad(E.WS[r])] == CE_CELL_WASTE;
+        wflag[r] = lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE;
         nwaste += popc64(ballot(wflag[r]));
       }
     }
@@ -1056,7 +1110,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 // ----------------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------------
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 1;
 
 template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds) {
   const u32 wave = threadIdx.x >> 6;
@@ -1065,11 +1119,16 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
+#ifdef CE_PHASE_STAMPS
+  E.dbg = p.debug ? p.debug + (size_t)E.e * 16 : nullptr;
+#else
+  E.dbg = nullptr;
+#endif
   return E.e < p.E;
 }
 
 // --- seed + "construct": replay the RNG use of MapEnv.__init__ (map_env.py:122-131) ---
-template <int KIND> __global__ __launch_bounds__(256) void k_grid_construct(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(GridParams p) {
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
@@ -1106,7 +1165,7 @@ template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParam
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(GridParams p) {
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
@@ -1133,7 +1192,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k_grid_reset(GridPara
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(256, 7) void k_grid_step(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? 8 : 7) void k_grid_step(GridParams p) {
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
@@ -1184,7 +1243,7 @@ template <int KIND> __global__ __launch_bounds__(256, 7) void k_grid_step(GridPa
     if (onA && first) E.RW += 1;
     wave_sync();
     if (onA) pm[E.P] = CE_CELL_EMPTY;
-    wave_sync();
+    mark_agents(E);
   }
   {  // update_custom_moves: always shuffles the n ids, then fires in that order
     u32 IDS = lane;
@@ -1479,13 +1538,22 @@ void launch_mt_seed(u32* rng, u32 stride_words, u32 block_offset_words, const u6
                      block_offset_words, seeds_dev, mask_dev, E, python_seeding);
 }
 
+// CE_EXTRA_LDS (bytes of unused dynamic LDS per workgroup) is an occupancy-sweep knob for experiments
+static unsigned extra_lds() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CE_EXTRA_LDS");
+    v = e ? atoi(e) : 0;
+  }
+  return (unsigned)v;
+}
 #define CE_LAUNCH_GRID(kern)                                                                          \
   do {                                                                                                \
     dim3 grid((p.E + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);               \
     if (kind == CE_KIND_CLEANUP)                                                                      \
-      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, 0, (hipStream_t)stream, p);              \
+      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, p);    \
     else                                                                                              \
-      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, 0, (hipStream_t)stream, p);              \
+      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, p);    \
   } while (0)
 
 void launch_grid_construct(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
