@@ -81,7 +81,7 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
 
     rec = {k: [] for k in ("actions", "grid", "agents", "base_rew", "rew", "eaten", "cleaned", "eaten_close",
                            "feature_obs", "done", "obs", "obs_sha", "mt", "theta", "waste_perm", "spawn_perm",
-                           "ep_start", "reset_grid", "reset_agents", "reset_obs", "reset_mt")}
+                           "ep_start", "reset_grid", "reset_agents", "reset_obs", "reset_mt", "reset_features")}
     static_waste = None
     if kind == "cleanup":
         static_waste = [[r, c] for r in range(env.base_map.shape[0]) for c in range(env.base_map.shape[1])
@@ -96,8 +96,11 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
         rec["ep_start"].append(step_idx)
         rec["reset_grid"].append(grid_codes(env))
         rec["reset_agents"].append(np.array([[a.pos[0], a.pos[1], ORIENT2INT[a.orientation]] for a in env.agents.values()], np.uint8))
-        rec["reset_obs"].append(np.stack([obs_u8(o[k]["image"]) for k in keys]))
+        if env.image_obs:
+            rec["reset_obs"].append(np.stack([obs_u8(o[k]["image"]) for k in keys]))
         rec["reset_mt"].append(mt_fingerprint())
+        if not env.image_obs:
+            rec["reset_features"].append(np.stack([o[k] if not contract else o[k] for k in keys])[:, :nfeat])
         rec["theta"].append(float(top.params["a0"][0]) if contract else 0.0)
         steps_this_ep = T if isinstance(T, int) else T[ep]
         for t in range(steps_this_ep):
@@ -111,7 +114,7 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
             rec["actions"].append(a.astype(np.uint8))
             rec["grid"].append(grid_codes(env))
             rec["agents"].append(np.array([[ag.pos[0], ag.pos[1], ORIENT2INT[ag.orientation]] for ag in env.agents.values()], np.uint8))
-            rec["base_rew"].append(np.array([base[k][-1] for k in keys], np.int32))
+            rec["base_rew"].append(np.array([base[k][-1] for k in keys], np.float64))
             rec["rew"].append(np.array([float(r[k]) for k in keys], np.float64))
             rec["eaten"].append(np.array([info[k]["eaten_apples"] for k in keys], np.uint8))
             rec["cleaned"].append(np.array([info[k].get("cleaned_squares", 0) for k in keys], np.uint8))
@@ -119,7 +122,11 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
             rec["feature_obs"].append(np.stack([info[k]["feature_obs"] for k in keys]).astype(np.float64))
             assert rec["feature_obs"][-1].shape == (n, nfeat)
             rec["done"].append(np.uint8(d["__all__"]))
-            ob = np.stack([obs_u8(o[k]["image"]) for k in keys])
+            if env.image_obs:
+                ob = np.stack([obs_u8(o[k]["image"]) for k in keys])
+            else:
+                assert all(np.array_equal(o[k][:nfeat], info[k]["feature_obs"]) for k in keys)
+                ob = np.zeros((n, 15, 15, 3), np.uint8)
             if step_idx < store_obs_steps:
                 rec["obs"].append(ob)
             rec["obs_sha"].append(np.frombuffer(hashlib.sha256(ob.tobytes()).digest(), np.uint8))
@@ -135,7 +142,10 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
         sp = [static_spawn.index(tuple(p)) for p in env.spawn_points]
         rec["spawn_perm"].append(np.array(sp, np.int16))
 
+    ek = extra_env_kwargs or {}
     out = {"kind": kind, "n": n, "seed": seed, "firing": int(firing), "contract": int(contract), "horizon": horizon,
+           "collective": int(bool(ek.get("use_collective_reward"))), "inequity": int(bool(ek.get("inequity_averse_reward"))),
+           "alpha": float(ek.get("alpha", 0.0)), "beta": float(ek.get("beta", 0.0)), "image_obs": int(ek.get("image_obs", True)),
            "static_spawn": np.array(static_spawn, np.int16)}
     for k, v in rec.items():
         if isinstance(v, list):
@@ -227,6 +237,17 @@ def main():
         "g6_harvest_n1_nocontract": dict(kind="harvest", n=1, seed=S0 + 10, T=200, store_obs_steps=30, contract=False),
         "g8_cleanup_n9": dict(kind="cleanup", n=9, seed=S0 + 11, T=200, store_obs_steps=20, firing=True),
     }
+    jobs["g9_cleanup_n4_collective_fire"] = dict(kind="cleanup", n=4, seed=S0 + 30, T=250, firing=True, contract=False,
+                                                 store_obs_steps=10, extra_env_kwargs=dict(use_collective_reward=True))
+    jobs["g9_cleanup_n4_inequity_fire"] = dict(kind="cleanup", n=4, seed=S0 + 31, T=250, firing=True, contract=False,
+                                               store_obs_steps=10,
+                                               extra_env_kwargs=dict(inequity_averse_reward=True, alpha=5.0, beta=0.05))
+    jobs["g9_harvest_n3_inequity_contract"] = dict(kind="harvest", n=3, seed=S0 + 32, T=250, store_obs_steps=10,
+                                                   extra_env_kwargs=dict(inequity_averse_reward=True, alpha=0.5, beta=0.25))
+    jobs["g9_cleanup_n3_features"] = dict(kind="cleanup", n=3, seed=S0 + 33, T=200, store_obs_steps=0, contract=False,
+                                          action_p=[.1, .1, .15, .1, .05, .1, .1, .3], extra_env_kwargs=dict(image_obs=False))
+    jobs["g9_harvest_n4_features"] = dict(kind="harvest", n=4, seed=S0 + 34, T=200, store_obs_steps=0, contract=False,
+                                          extra_env_kwargs=dict(image_obs=False))
     for s in range(6):  # short multi-seed traces (RNG / reset variety)
         jobs["g7_cleanup_n8_s%d" % s] = dict(kind="cleanup", n=8, seed=1000 + 17 * s, T=120, store_obs_steps=8,
                                              action_p=[.1, .1, .15, .1, .05, .1, .1, .3] if s % 2 else None)
