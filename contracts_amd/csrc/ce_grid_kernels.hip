@@ -303,7 +303,87 @@ template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, 
   L0 = l0;
   L1 = l1;
 }
-DEVINL void shuffle_lanes(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) { shuffle_core<true>(r, L0, L1, len, lane); }
+// Lanes below `lane` that are set in a wave-uniform 64-bit mask (v_mbcnt)
+DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+// The 118 draws of the waste-list shuffle, vectorised.  For one mask segment [lo, i0] and the cached words
+// k = off.. (v_k = word_k & mask), sequential rejection sampling accepts word k iff v_k <= i0 - a_k, where a_k
+// is the number of words accepted before k.  That self-referential predicate is solved by monotone bounds:
+// L (surely accepted) grows and U (possibly accepted) shrinks until they meet —
+//   L' = { v_k <= i0 - |U below k| },  U' = { v_k <= i0 - |L below k| }
+// (the lowest undecided lane always resolves, so it terminates; in practice 2-4 rounds per 64 words).
+// Accepted word with rank a is the draw for index i0 - a; draws are scattered to J[index] in LDS.
+// Returns with r advanced past every consumed word.
+DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
+  u32 i0 = len - 1;
+  const u64 lt = (1ull << lane) - 1ull;
+  (void)lt;
+  while (i0 >= 1) {
+    const u32 lo = 1u << (31 - __builtin_clz(i0));  // segment [lo, i0] shares mask 2*lo - 1
+    const u32 mask = 2 * lo - 1;
+    u32 off = r.pos - r.cbase;
+    if (off >= r.ccount) {
+      rng_refill(r, lane);
+      off = 0;
+    }
+    const u64 A = r.cvalid & (~0ull << off);
+    const u32 v = r.cache & mask;
+    const bool inA = bit(A, lane);
+    u64 Lm = 0, Um = A;
+    for (;;) {
+      const i32 aL = (i32)rank_in(Lm, lane), aU = (i32)rank_in(Um, lane);
+      const u64 nL = ballot(inA && (i32)v <= (i32)i0 - aU);
+      const u64 nU = ballot(inA && (i32)v <= (i32)i0 - aL);
+      Lm = nL;
+      Um = nU;
+      if (nL == nU) break;
+    }
+    const u32 a = rank_in(Lm, lane);
+    const u32 need = i0 - lo + 1;  // draws left in this segment
+    const u32 total = popc64(Lm);
+    u32 used;
+    if (total >= need) {  // the segment completes inside this batch: stop after its last accepted word
+      const u64 last = ballot(bit(Lm, lane) && a == need - 1);
+      used = need;
+      r.pos = r.cbase + ctz64(last) + 1;
+    } else {  // every cached word is consumed (accepted or rejected)
+      used = total;
+      r.pos = r.cbase + r.ccount;
+    }
+    if (bit(Lm, lane) && a < used) J[i0 - a] = v;
+    i0 -= used;
+  }
+  wave_sync();
+}
+
+// Applies swap(x[i], x[J[i]]) for i = len-1 .. 1 to the list held across lanes (L0: elements 0..63, L1: 64..)
+DEVINL void shuffle_apply(u32& L0, u32& L1, u32 len, const u32* J, u32 lane) {
+  const u32 J0 = J[lane], J1 = J[64 + lane];
+  u32 l0 = L0, l1 = L1;
+  u32 i = len - 1;
+  for (; i >= 64; --i) {  // x[i] lives in L1, x[j] in either register
+    const u32 j = rdl(J1, i - 64);
+    const u32 jm = j & 63, im = i - 64;
+    const u32 vi = rdl(l1, im), a0 = rdl(l0, jm), b0 = rdl(l1, jm);
+    const bool jlow = j < 64;
+    const u32 vj = jlow ? a0 : b0;
+    l0 = (lane == jm && jlow) ? vi : l0;
+    l1 = (lane == jm && !jlow) ? vi : l1;
+    l1 = lane == im ? vj : l1;  // last: wins when jm == im with j < 64
+  }
+#pragma unroll 4
+  for (; i >= 1; --i) {
+    const u32 j = rdl(J0, i);
+    const u32 vi = rdl(l0, i), vj = rdl(l0, j);
+    l0 = lane == i ? vj : l0;
+    l0 = lane == j ? vi : l0;
+  }
+  L0 = l0;
+  L1 = l1;
+}
+
 DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
   u32 dummy = 0;
   shuffle_core<false>(r, L0, dummy, len, lane);
@@ -760,7 +840,9 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     bool waste_found = false;
     CE_SUBSTAMP(12);
     if (waste_on) {
-      shuffle_lanes(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+      // the apple doubles in U are dead by now: U doubles as the draw list J[0..118]
+      shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
+      shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
       CE_SUBSTAMP(13);
       // The walk over the shuffled list hands double rbase + t to the t-th non-waste cell and stops at the
       // first u < 0.5: t* = first set byte of S from rbase on, independent of the permutation.

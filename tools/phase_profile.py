@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import torch
 from contracts_amd.engine import BatchedEnv
 
-E, n = 16384, 8
+E, n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 8
 env = BatchedEnv("cleanup", E, n, contract="cleanup", auto_reset=True)
 env.seed(seed0=73907)
 env.reset()
