@@ -1,15 +1,40 @@
-"""Contract base class — same constructor and attributes as the reference's contract/contract.py:1-9."""
+"""Contract specification base class.
+
+Interface parity with the reference's `contract/contract.py:1-9`: a contract object exposes
+`contract_space`, `default_contract`, `num_agents`, `features_compute` and a `compute_transfer` hook.
+In this package a contract is a *specification* consumed by the engine (which fused epilogue to run, over
+which parameter interval); the arithmetic itself lives in the HIP step kernels.
+"""
+import numpy as np
 
 
 class Contract:
-    #: which fused epilogue of the engine implements `compute_transfer` (None = not accelerated)
+    #: name of the engine's fused epilogue implementing this contract (None = not accelerated)
     engine_contract = None
 
     def __init__(self, contract_space, default_contract, num_agents, features_compute=None):
+        if num_agents is None or int(num_agents) < 1:
+            raise ValueError("a contract needs the number of agents, got %r" % (num_agents,))
+        low, high = np.asarray(contract_space.low), np.asarray(contract_space.high)
+        if low.shape != high.shape or np.any(high < low):
+            raise ValueError("malformed contract space: low=%r high=%r" % (low, high))
+        self.num_agents = int(num_agents)
         self.contract_space = contract_space
-        self.default_contract = default_contract
+        self.default_contract = np.asarray(default_contract, dtype=np.float64)
         self.features_compute = features_compute
-        self.num_agents = num_agents
+
+    # ---- what the engine needs -------------------------------------------------------
+    def engine_spec(self, null_prob=0.0):
+        """(epilogue name, low, high, null_prob) with the Box's float32 bounds read back as float64 —
+        the values `np.random.uniform(low=contract_low, high=contract_high)` sees in the reference
+        (environments/two_stage_train.py:39-40,164)."""
+        return (self.engine_contract, float(self.contract_space.low[0]), float(self.contract_space.high[0]),
+                float(null_prob))
 
     def compute_transfer(self, obs, acts, params, infos=None):
         raise NotImplementedError
+
+    def __repr__(self):
+        return "%s(num_agents=%d, theta in [%g, %g], epilogue=%r)" % (
+            type(self).__name__, self.num_agents, float(self.contract_space.low[0]),
+            float(self.contract_space.high[0]), self.engine_contract)

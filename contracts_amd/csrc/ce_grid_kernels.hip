@@ -122,25 +122,52 @@ DEVINL u32 mt_mix(u32 a, u32 b, u32 c) {  // new = c ^ twist(a,b)
 // words, 227..453 read chunk-1 results, 454..622 read chunk-2 results), then word 623.
 __device__ __noinline__ void mt_twist(u32* mt, u32 lane) {
   wave_sync();
-  for (u32 b = 0; b < 227; b += 64) {
-    const u32 i = b + lane, ic = i < 227 ? i : 0;
-    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic + kMtM]);
+  // chunk 1: words 0..226 (4 lane rounds) read only old words -> all reads first, then all writes
+  {
+    u32 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = 64 * r + lane, ic = i < 227 ? i : 0;
+      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic + kMtM]);
+    }
     wave_sync();
-    if (i < 227) mt[i] = v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = 64 * r + lane;
+      if (i < 227) mt[i] = v[r];
+    }
     wave_sync();
   }
-  for (u32 b = 227; b < 454; b += 64) {
-    const u32 i = b + lane, ic = i < 454 ? i : 227;
-    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+  // chunk 2: words 227..453 read old words and chunk-1 results
+  {
+    u32 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = 227 + 64 * r + lane, ic = i < 454 ? i : 227;
+      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+    }
     wave_sync();
-    if (i < 454) mt[i] = v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 i = 227 + 64 * r + lane;
+      if (i < 454) mt[i] = v[r];
+    }
     wave_sync();
   }
-  for (u32 b = 454; b < 623; b += 64) {
-    const u32 i = b + lane, ic = i < 623 ? i : 454;
-    const u32 v = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+  // chunk 3: words 454..622 read old words and chunk-2 results
+  {
+    u32 v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const u32 i = 454 + 64 * r + lane, ic = i < 623 ? i : 454;
+      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+    }
     wave_sync();
-    if (i < 623) mt[i] = v;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const u32 i = 454 + 64 * r + lane;
+      if (i < 623) mt[i] = v[r];
+    }
     wave_sync();
   }
   if (lane == 0) mt[623] = mt_mix(mt[623], mt[0], mt[396]);
@@ -1407,11 +1434,11 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;  // contract_list.py:26
     else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
     double total = 0.0;
-    const double nm1 = (double)(n - 1);
+    const double share = tr / (double)(n - 1);  // t_i / (len(acts) - 1), one division per agent
     for (u32 i = 0; i < n; ++i) {
-      const double ti = shfl_f64(tr, i);
+      const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
       if (lane == i) rew -= ti;
-      else rew += ti / nm1;
+      else rew += qi;
       total += ti;
     }
     f_transfers += total;

@@ -26,9 +26,7 @@ class SeparateContractEnv(_Base):
         self.null_prob = null_prob
         if getattr(contract, "engine_contract", None) is None:
             raise NotImplementedError("contract %r has no fused engine epilogue" % type(contract).__name__)
-        # float32 Box bounds read back as float64, exactly as np.random.uniform(low=contract_low, ...) sees them
-        base_env._contract = (contract.engine_contract, float(self.contract_low[0]), float(self.contract_high[0]),
-                              float(null_prob))
+        base_env._contract = contract.engine_spec(null_prob)
         if base_env._engine is not None:
             base_env._engine.set_contract(*base_env._contract)
         if self.convolutional:
