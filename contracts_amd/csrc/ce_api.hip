@@ -111,6 +111,7 @@ struct ce_engine {
   uint8_t* d_stage_actions;  // E*n*4 bytes
   uint8_t* d_stage_active;   // E*n
   unsigned long long* d_debug;  // E*16 phase stamps (diagnostic builds)
+  GridParams* d_gparams;        // device copy of the grid kernels' parameter block
   std::vector<std::pair<void**, size_t>> allocs;
   std::string err;
   // timing
@@ -153,6 +154,9 @@ extern "C" int ce_device_count(void) {
   return ok;
 }
 
+struct ce_engine;
+static int sync_device_params(ce_engine* h);
+
 static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.kind == CE_KIND_HARVEST; }
 
 extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
@@ -177,6 +181,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->d_stage_actions = nullptr;
   h->d_stage_active = nullptr;
   h->d_debug = nullptr;
+  h->d_gparams = nullptr;
   std::memset(&h->buf, 0, sizeof(h->buf));
   *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
 
@@ -258,6 +263,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_actions, E * n * 4);
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_active, E * n);
   if (rc == CE_OK) rc = dalloc(h, &h->d_debug, E * 16);
+  if (rc == CE_OK && is_grid(*cfg)) rc = dalloc(h, &h->d_gparams, 1);
+  if (rc == CE_OK && is_grid(*cfg)) rc = sync_device_params(h);
 #undef A
   return rc;
 }
@@ -288,7 +295,8 @@ extern "C" int ce_set_contract(ce_handle h, uint32_t contract, double contract_l
   h->cfg.contract_low = contract_low;
   h->cfg.contract_high = contract_high;
   h->cfg.null_prob = null_prob;
-  return CE_OK;
+  (void)hipSetDevice(h->cfg.device);
+  return sync_device_params(h);
 }
 
 static GridParams grid_params(ce_engine* h) {
@@ -327,6 +335,16 @@ static GridParams grid_params(ce_engine* h) {
   p.alpha = h->cfg.alpha;
   p.beta = h->cfg.beta;
   return p;
+}
+
+// (re)uploads the parameter block the grid kernels read; called at create and whenever cfg changes
+static int sync_device_params(ce_engine* h) {
+  if (!h->d_gparams) return CE_OK;
+  const GridParams p = grid_params(h);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(h->d_gparams, &p, sizeof(p), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "parameter block upload", e);
+  return CE_OK;
 }
 
 static SdParams sd_params(ce_engine* h) {
@@ -402,7 +420,7 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
     if (replay_constructor) {
       GridParams p = grid_params(h);
       p.mask = dmask;
-      launch_grid_construct((int)h->cfg.kind, p, nullptr);
+      launch_grid_construct((int)h->cfg.kind, p, h->d_gparams, nullptr);
     }
   } else {
     if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
@@ -427,7 +445,7 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.mask = dmask;
-    launch_grid_reset((int)h->cfg.kind, p, stream);
+    launch_grid_reset((int)h->cfg.kind, p, h->d_gparams, stream);
   } else {
     SdParams p = sd_params(h);
     p.mask = dmask;
@@ -442,7 +460,7 @@ extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, 
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
-    launch_grid_step((int)h->cfg.kind, p, stream);
+    launch_grid_step((int)h->cfg.kind, p, h->d_gparams, stream);
   } else {
     SdParams p = sd_params(h);
     p.actions = (const float*)actions;

@@ -103,9 +103,11 @@ struct SdParams {
 int upload_grid_tables(int kind, const GridTables& t, const uint16_t* pix, int npix, const uint32_t* rgb16);
 void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,
                     const uint8_t* mask_dev, uint32_t E, int python_seeding, void* stream);
-void launch_grid_construct(int kind, const GridParams& p, void* stream);
-void launch_grid_reset(int kind, const GridParams& p, void* stream);
-void launch_grid_step(int kind, const GridParams& p, void* stream);
+// `p` carries the per-call pointers (actions / mask) and the batch size; `dp` is the device-resident copy of
+// the handle's parameter block that the kernels read field by field (keeps them out of long-lived SGPRs)
+void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_sd_construct(const SdParams& p, void* stream);
 void launch_sd_reset(const SdParams& p, void* stream);
 void launch_sd_step(const SdParams& p, void* stream);

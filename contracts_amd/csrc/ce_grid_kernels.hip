@@ -1237,11 +1237,12 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
 }
 
 // --- seed + "construct": replay the RNG use of MapEnv.__init__ (map_env.py:122-131) ---
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+  const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
-  if (p.mask && p.mask[E.e] == 0) return;
+  if (call_mask && call_mask[E.e] == 0) return;
   typedef Geo<KIND> G;
   load_static(E);
   load_rng(E, p);
@@ -1274,11 +1275,12 @@ template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParam
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+  const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
-  if (p.mask && p.mask[E.e] == 0) return;
+  if (call_mask && call_mask[E.e] == 0) return;
   load_static(E);
   load_rng(E, p);
   load_perms(E, p);
@@ -1301,7 +1303,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? 8 : 7) void k_grid_step(GridParams p) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? 8 : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+  const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds)) return;
@@ -1310,7 +1313,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   const u32 lane = E.lane, n = E.n;
   const size_t ia = (size_t)E.e * n + lane;
 
-  u32 ACT = E.is_agent ? (u32)p.actions[ia] : 4u;
+  u32 ACT = E.is_agent ? (u32)call_actions[ia] : 4u;
   const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
   if (ballot(E.is_agent && ACT > max_action) != 0) {  // KeyError in the reference (Agent.py:174,213)
     if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
@@ -1660,14 +1663,16 @@ static unsigned extra_lds() {
   do {                                                                                                \
     dim3 grid((p.E + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);               \
     if (kind == CE_KIND_CLEANUP)                                                                      \
-      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, p);    \
+      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
+                         p.actions, p.mask);                                                          \
     else                                                                                              \
-      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, p);    \
+      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
+                         p.actions, p.mask);                                                          \
   } while (0)
 
-void launch_grid_construct(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
-void launch_grid_reset(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
-void launch_grid_step(int kind, const GridParams& p, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
+void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
+void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
 
 void launch_synth_actions_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions,
                              void* stream) {
