@@ -395,17 +395,18 @@ DEVINL void shuffle_apply(u32& L0, u32& L1, u32 len, const u32* J, u32 lane) {
     const u32 jm = j & 63, im = i - 64;
     const u32 vi = rdl(l1, im), a0 = rdl(l0, jm), b0 = rdl(l1, jm);
     const bool jlow = j < 64;
-    const u32 vj = jlow ? a0 : b0;
-    l0 = (lane == jm && jlow) ? vi : l0;
-    l1 = (lane == jm && !jlow) ? vi : l1;
-    l1 = lane == im ? vj : l1;  // last: wins when jm == im with j < 64
+    // x[j] <- vi in whichever register holds it (the other one is rewritten with its own value),
+    // then x[i] <- old x[j]; the last write wins when both are the same slot
+    l0 = writelane<0>(jlow ? vi : a0, jm, l0);
+    l1 = writelane<0>(jlow ? b0 : vi, jm, l1);
+    l1 = writelane<0>(jlow ? a0 : b0, im, l1);
   }
 #pragma unroll 4
   for (; i >= 1; --i) {
     const u32 j = rdl(J0, i);
     const u32 vi = rdl(l0, i), vj = rdl(l0, j);
-    l0 = lane == i ? vj : l0;
-    l0 = lane == j ? vi : l0;
+    l0 = writelane<0>(vj, i, l0);
+    l0 = writelane<0>(vi, j, l0);
   }
   L0 = l0;
   L1 = l1;
@@ -867,9 +868,13 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     bool waste_found = false;
     CE_SUBSTAMP(12);
     if (waste_on) {
+#ifdef CE_SEQ_SHUFFLE
+      shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+#else
       // the apple doubles in U are dead by now: U doubles as the draw list J[0..118]
       shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
       shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+#endif
       CE_SUBSTAMP(13);
       // The walk over the shuffled list hands double rbase + t to the t-th non-waste cell and stops at the
       // first u < 0.5: t* = first set byte of S from rbase on, independent of the permutation.
@@ -1219,6 +1224,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 // ----------------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------------
+#ifndef CE_CLEANUP_WAVES
+#define CE_CLEANUP_WAVES 7
+#endif
 constexpr int kWavesPerBlock = 1;
 
 template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds) {
@@ -1303,7 +1311,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? 8 : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
