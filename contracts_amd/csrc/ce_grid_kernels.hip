@@ -41,9 +41,11 @@ __constant__ u32 c_rgb[16];                                       // colour LUT,
 DEVINL u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 DEVINL u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 DEVINL u32 rdl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
-// v_writelane has no clang builtin; a compare+select against the lane id is one VALU op more and
-// lets the compiler schedule it (no hand-padded SGPR hazards).
-DEVINL u32 wrl(u32 val, u32 l, u32 old) { return lane_id() == l ? val : old; }
+// clang exposes no builtin for v_writelane_b32, but the LLVM intrinsic can be declared directly; the
+// compiler then manages M0 (gfx9 needs the lane select in M0 when the value is an SGPR too) and the
+// VALU-writes-SGPR -> lane-select hazard.  `val` and `l` must be wave-uniform.
+extern "C" __device__ int ce_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+DEVINL u32 wrl(u32 val, u32 l, u32 old) { return (u32)ce_llvm_writelane((int)val, (int)l, (int)old); }
 DEVINL u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 DEVINL u32 bperm(u32 v, u32 src_lane) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 DEVINL u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
@@ -245,13 +247,7 @@ DEVINL double rng_double(Rng& r, u32 lane) {
   return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
-// clang exposes no builtin for v_writelane_b32, but the LLVM intrinsic can be declared directly; the
-// compiler then manages M0 (gfx9 needs the lane select in M0 when the value is an SGPR too) and the
-// VALU-writes-SGPR -> lane-select hazard.  `val` and `sel` must be wave-uniform.
-extern "C" __device__ int ce_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
-template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) {
-  return (u32)ce_llvm_writelane((int)val, (int)sel, (int)old);
-}
+template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) { return wrl(val, sel, old); }
 
 // np.random.shuffle (untyped path): for i = len-1 .. 1: j = random_interval(i); swap(x[i], x[j]), over a
 // list held across lanes (element k < 64 in lane k of L0, element 64 + k in lane k of L1).
