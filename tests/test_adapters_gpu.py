@@ -141,3 +141,29 @@ def test_adapter_pickle_roundtrip_and_options():
     env.close()
     clone.close()
     fenv.close()
+
+
+def test_reference_config_file_drives_the_engine():
+    """a job list in the reference's experiment_configs format builds HIP-backed envs (config plumbing)"""
+    from contracts_amd.utils.config import build_env, expand_config_list
+    cfg = [{"num_workers": 1, "horizon": 1000, "env_args": {"image_obs": True}, "solver": True},
+           {"num_agents": [2]},
+           {"environment": "cleanup_new", "contract": "CleanupContract"},
+           {"environment": "harvest_new", "contract": "HarvestFeaturemodLocalContract", "separate": True},
+           {"environment": "selfdrive", "contract": "SelfdriveContractDistprop", "env_args": {}}]
+    jobs = expand_config_list(cfg)
+    assert len(jobs) == 3
+    for job in jobs:
+        np.random.seed(job["seed"])
+        random.seed(job["seed"])
+        top, base, contract = build_env(job)
+        o = top.reset()
+        assert set(o.keys()) == {"a0", "a1"}
+        if job["environment"] == "selfdrive":
+            o, r, d, _ = top.step({k: np.array([0.05]) for k in o})
+            assert o["a0"].shape == (2 * 2 + 5 + 2,) and r["a0"] == -100.0
+        else:
+            o, r, d, info = top.step({k: 4 for k in o})
+            assert o["a0"]["image"].shape == (15, 15, 3)
+            assert ("contract" in o["a0"]) == (not job.get("separate"))
+        base.close()

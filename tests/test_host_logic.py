@@ -47,3 +47,23 @@ def test_spaces_standins():
     d = spaces.Dict({"image": spaces.Box(0, 1, (15, 15, 3), np.uint8)})
     assert "image" in d.keys() and d["image"].shape == (15, 15, 3)
     assert spaces.Discrete(8).n == 8
+
+
+def test_config_expansion_matches_runner_semantics():
+    """the reference's experiment_configs format (runner.py:89-135): [global, sweep, job...]"""
+    from contracts_amd.utils.config import expand_config_list
+    cfg = [
+        {"num_workers": 8, "horizon": 1000, "env_args": {"image_obs": True}, "solver": True},
+        {"num_agents": [2, 4, 8], "lr": [1, 2]},
+        {"environment": "cleanup_new", "contract": "CleanupContract"},
+        {"environment": "harvest_new", "contract": "HarvestFeaturemodLocalContract", "horizon": 500},
+    ]
+    jobs = expand_config_list(cfg, seeds=2)
+    assert len(jobs) == 3 * 2 * 2 * 2
+    # sweep-major, then job order, then seeds; job-level values win over globals
+    assert [j["num_agents"] for j in jobs[:8]] == [2] * 8 and jobs[0]["lr"] == 1 and jobs[4]["lr"] == 2
+    assert jobs[0]["environment"] == "cleanup_new" and jobs[2]["environment"] == "harvest_new"
+    assert jobs[2]["horizon"] == 500 and jobs[0]["horizon"] == 1000 and jobs[0]["num_workers"] == 8
+    assert jobs[0]["seed"] == 73907 and jobs[1]["seed"] == 2 * 73907
+    assert jobs[0]["experiment_name"] == "cleanup_new-2agents"
+    assert cfg[2].get("num_workers") is None  # the input list is not mutated
