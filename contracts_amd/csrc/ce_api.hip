@@ -49,7 +49,7 @@ template <int KIND> static void build_tables(GridTables& t) {
     for (int c = 0; c < G::W; ++c) {
       const char ch = map[r][c];
       const uint32_t pad = (uint32_t)((r + kView) * G::PW + c + kView);
-      const uint32_t packed = pad | ((uint32_t)r << 11) | ((uint32_t)c << 16);
+      const uint32_t packed = pad | ((uint32_t)c << 16) | ((uint32_t)r << 24);
       uint8_t code = CE_CELL_EMPTY;
       if (ch == '@') code = CE_CELL_WALL;
       if (ch == 'P') t.spawn[ns++] = packed;

@@ -36,7 +36,7 @@ template <> struct Geo<CE_KIND_HARVEST> {
 };
 
 // Static per-family tables (host-built from the ASCII maps, uploaded to __constant__).
-// Cell entries are packed:  padded_index | row << 11 | col << 16.
+// Cell entries are packed:  padded_index (11 bits) | col << 16 | row << 24  (one byte per coordinate).
 struct GridTables {
   uint32_t apple[160];         // apple spawn cells, row-major (cleanup 'B', harvest 'A')
   uint32_t waste[128];         // cleanup waste cells 'H' u 'R', row-major

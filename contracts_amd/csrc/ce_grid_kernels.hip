@@ -432,8 +432,9 @@ constexpr uint8_t kAgentBit = 0x80;
 constexpr u32 kCodeMask = 0x7fu;
 constexpr u32 kCellPadMask = 0x7ffu;
 DEVINL u32 cell_pad(u32 packed) { return packed & kCellPadMask; }
-DEVINL u32 cell_row(u32 packed) { return (packed >> 11) & 31u; }
-DEVINL u32 cell_col(u32 packed) { return (packed >> 16) & 63u; }
+DEVINL u32 cell_row(u32 packed) { return packed >> 24; }
+DEVINL u32 cell_col(u32 packed) { return (packed >> 16) & 0xffu; }
+DEVINL u32 cell_rc(u32 packed) { return packed >> 16; }  // col | row << 8: one byte per coordinate
 
 // env context: everything a wave keeps in registers for its env
 template <int KIND> struct Env {
@@ -863,7 +864,11 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     u32 waste_cell = 0;
     bool waste_found = false;
     CE_SUBSTAMP(12);
+#ifdef CE_ABLATE_SHUFFLE
+    if (false) {
+#else
     if (waste_on) {
+#endif
 #ifdef CE_SEQ_SHUFFLE
       shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
 #else
@@ -1147,38 +1152,47 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       }
     }
     u32 ca_r = 0, ca_c = 0, cw_r = 0, cw_c = 0, close_now = 0;
+    // Closest apple / waste = min over keys  manhattan << 16 | row << 8 | col  (ties: smallest (row, col) ==
+    // first in the row-major list, as np.argmin).  Coordinates sit one per byte, so the Manhattan distance
+    // is a single v_sad_u8 against the agent's packed (row, col); flagged-out cells get key ~0.
+    u32 arc[3], akey_off[3], wrc[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) arc[r] = cell_rc(E.AP[r]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) wrc[r] = cell_rc(E.WS[r]);
+    (void)akey_off;
     for (u32 a = 0; a < n; ++a) {
       const u32 pa = rdl(E.P, a);
-      const i32 ar = (i32)row_of<KIND>(pa), ac = (i32)col_of<KIND>(pa);
+      const u32 prc = col_of<KIND>(pa) | row_of<KIND>(pa) << 8;
       u32 key = 0xffffffffu;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (64 * r < G::NAPPLE) {
-          const i32 d = abs((i32)cell_row(E.AP[r]) - ar) + abs((i32)cell_col(E.AP[r]) - ac);
-          const u32 k2 = aflag[r] ? ((u32)d << 11 | cell_row(E.AP[r]) << 6 | cell_col(E.AP[r])) : 0xffffffffu;
-          key = k2 < key ? k2 : key;  // ties: smallest (row, col) == first in the row-major list (np.argmin)
+          const u32 d = __builtin_amdgcn_sad_u8(arc[r], prc, 0u);
+          const u32 k2 = aflag[r] ? (d << 16 | arc[r]) : 0xffffffffu;
+          key = k2 < key ? k2 : key;
         }
       }
       const u32 best = wave_min_u32(key);
       u32 br = 0, bc = 0;
-      if (best != 0xffffffffu) {
-        br = (best >> 6) & 31u;
-        bc = best & 63u;
+      if (best != 0xffffffffu) {  // [0, 0] sentinel when there is none
+        br = (best >> 8) & 0xffu;
+        bc = best & 0xffu;
       }
       if (lane == a) { ca_r = br; ca_c = bc; }
       if (KIND == CE_KIND_CLEANUP) {
         u32 keyw = 0xffffffffu;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const i32 d = abs((i32)cell_row(E.WS[r]) - ar) + abs((i32)cell_col(E.WS[r]) - ac);
-          const u32 k2 = wflag[r] ? ((u32)d << 11 | cell_row(E.WS[r]) << 6 | cell_col(E.WS[r])) : 0xffffffffu;
+          const u32 d = __builtin_amdgcn_sad_u8(wrc[r], prc, 0u);
+          const u32 k2 = wflag[r] ? (d << 16 | wrc[r]) : 0xffffffffu;
           keyw = k2 < keyw ? k2 : keyw;
         }
         const u32 bw = wave_min_u32(keyw);
         u32 wr = 0, wc = 0;
         if (bw != 0xffffffffu) {
-          wr = (bw >> 6) & 31u;
-          wc = bw & 63u;
+          wr = (bw >> 8) & 0xffu;
+          wc = bw & 0xffu;
         }
         if (lane == a) { cw_r = wr; cw_c = wc; }
       } else {
@@ -1333,7 +1347,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   // ---------------- MapEnv.step ----------------
   t += 1;
   CE_STAMP(1);
+#ifndef CE_ABLATE_MOVES
   update_moves(E, ACT);
+#endif
   CE_STAMP(2);
   if (!E.is_agent) E.P = 0xffffu;
 
@@ -1415,7 +1431,11 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   long long g_m = lane < 4 ? mi[lane < 4 ? lane : 0] : 0;  // lane k < 4 holds global metric k
   double f_transfers = mf[CE_MF_TRANSFERS];
   CE_STAMP(5);
+#ifndef CE_ABLATE_FEATURES
   const u32 feat8 = compute_features(E, p, cleaned);
+#else
+  const u32 feat8 = 0;
+#endif
   CE_STAMP(6);
   {
     u32 sum_eaten = 0, sum_clean = 0, sum_close = 0;
@@ -1533,7 +1553,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     if (fault) p.error_flags[E.e] |= fault;
   }
   CE_STAMP(8);
+#ifndef CE_ABLATE_OBS
   write_obs(E, p, !did_reset);
+#endif
   CE_STAMP(9);
 }
 
