@@ -460,9 +460,17 @@ DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-i
   return o == 0 ? -PW : o == 1 ? 1 : o == 2 ? PW : -1;
 }
 
-template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return (row + kView) * Geo<KIND>::PW + col + kView; }
-template <int KIND> DEVINL u32 row_of(u32 pad) { return pad / Geo<KIND>::PW - kView; }
-template <int KIND> DEVINL u32 col_of(u32 pad) { return pad % Geo<KIND>::PW - kView; }
+template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return __umul24(row + kView, (u32)Geo<KIND>::PW) + col + kView; }
+// Exact small-range divisions by multiply-shift with 24-bit multiplies (v_mul_u32_u24 is full rate, the
+// 32-bit v_mul_lo/hi the compiler emits for `/ constant` are quarter rate): valid for idx < 640 / pad < 1600.
+template <int KIND> DEVINL u32 div_w(u32 idx) {  // idx / W
+  return KIND == CE_KIND_CLEANUP ? (__umul24(idx, 3641u) >> 16) : (__umul24(idx, 1725u) >> 16);
+}
+template <int KIND> DEVINL u32 div_pw(u32 pad) {  // pad / PW
+  return KIND == CE_KIND_CLEANUP ? (pad >> 5) : (__umul24(pad, 1261u) >> 16);
+}
+template <int KIND> DEVINL u32 row_of(u32 pad) { return div_pw<KIND>(pad) - kView; }
+template <int KIND> DEVINL u32 col_of(u32 pad) { return pad - __umul24(div_pw<KIND>(pad), (u32)Geo<KIND>::PW) - kView; }
 
 // is some agent standing on padded cell `cell` (per-lane query); returns highest agent id + 1 or 0
 template <int KIND> DEVINL void mark_agents(Env<KIND>& E) {
@@ -535,7 +543,7 @@ template <int KIND> DEVINL void load_grid(Env<KIND>& E, const GridParams& p) {
     for (int bb = 0; bb < 4; ++bb) {
       u32 idx = 4 * k + bb;
       if (idx < (u32)G::CELLS) {
-        u32 row = idx / G::W, col = idx - row * G::W;
+        u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
         E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((w >> (8 * bb)) & 0xff);
       }
     }
@@ -552,7 +560,7 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
     for (int bb = 0; bb < 4; ++bb) {
       u32 idx = 4 * k + bb;
       if (idx < (u32)G::CELLS) {
-        u32 row = idx / G::W, col = idx - row * G::W;
+        u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
         w |= (u32)(E.L->pmap[pad_of<KIND>(row, col)] & kCodeMask) << (8 * bb);
       }
     }
@@ -644,7 +652,7 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
       for (int bb = 0; bb < 4; ++bb) {
         const u32 idx = 4 * (lane + 64 * r) + bb;
         if (idx < (u32)G::CELLS) {
-          const u32 row = idx / G::W, col = idx - row * G::W;
+          const u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
           E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((gw[r] >> (8 * bb)) & 0xff);
         }
       }
@@ -982,17 +990,17 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   for (u32 u = lane; u < units; u += 64) {
     // env-wide pixel q -> (agent, i, j): q = 225 a + 15 i + j (exact multiply-shift divisions for q < 2032)
     const u32 q0 = 4 * u;
-    u32 a = (q0 * 4661u) >> 20;
-    const u32 pq = q0 - 225u * a;
-    u32 i = (pq * 2185u) >> 15;
-    u32 j = pq - 15u * i;
+    u32 a = __umul24(q0, 4661u) >> 20;
+    const u32 pq = q0 - __umul24(225u, a);
+    u32 i = __umul24(pq, 2185u) >> 15;
+    u32 j = pq - __umul24(15u, i);
     u32 col[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       u32 c = 0;
       if (q0 + k < npix) {
         const u32 vw = E.L->view[a];
-        const i32 off = (i32)(vw & 0xffffu) + (i32)i * ((i32)(vw << 8) >> 24) + (i32)j * ((i32)vw >> 24);
+        const i32 off = (i32)(vw & 0xffffu) + __mul24((i32)i, (i32)(vw << 8) >> 24) + __mul24((i32)j, (i32)vw >> 24);
         c = E.L->rgb[pm[off]];
       }
       col[k] = c;
@@ -1006,17 +1014,18 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
         }
       }
     }
-    const u32 d0 = (col[0] & 0xffffffu) | (col[1] << 24);
-    const u32 d1 = ((col[1] >> 8) & 0xffffu) | (col[2] << 16);
-    const u32 d2 = ((col[2] >> 16) & 0xffu) | (col[3] << 8);
-    u32* dst = (u32*)(dst_env + (size_t)u * 12);
-    if (u * 12 + 12 <= p.obs_env_stride) {
+    const u32 d0 = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);  // R0 G0 B0 R1
+    const u32 d1 = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);  // G1 B1 R2 G2
+    const u32 d2 = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);  // B2 R3 G3 B3
+    const u32 boff = __umul24(u, 12u);
+    u32* dst = (u32*)(dst_env + boff);
+    if (boff + 12 <= p.obs_env_stride) {
       dst[0] = d0;
       dst[1] = d1;
       dst[2] = d2;
     } else {
-      if (u * 12 + 4 <= p.obs_env_stride) dst[0] = d0;
-      if (u * 12 + 8 <= p.obs_env_stride) dst[1] = d1;
+      if (boff + 4 <= p.obs_env_stride) dst[0] = d0;
+      if (boff + 8 <= p.obs_env_stride) dst[1] = d1;
     }
   }
 }
