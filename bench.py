@@ -46,32 +46,56 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(kind, n, contract, target_s):
     """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this
-    box's host cores with OpenMP over envs: a bounded sample of the same workload."""
+    box's host cores with OpenMP over envs: a bounded sample of the same workload, at all threads (the
+    reported value) and at one thread."""
+    import ctypes
     from oracle.pyoracle import Oracle
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    E = 256 * threads
-    orc = Oracle(kind, E, n, contract=contract, horizon=1000, auto_reset=True)
-    orc.seed(seed0=SEED0)
-    orc.reset()
+    try:
+        threads = len(os.sched_getaffinity(0))  # cores this process may actually run on
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    gomp = ctypes.CDLL("libgomp.so.1")
     rs = np.random.RandomState(1)
     na = 8 if kind == "cleanup" else 7
-    acts = rs.randint(na, size=(32, E, n)).astype(np.uint8)
-    for t in range(8):
-        orc.step(acts[t % 32])
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        for _ in range(8):
-            orc.step(acts[steps % 32])
-            steps += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_s:
-            break
-    return {"value": E * n * steps / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d steps, %s n=%d + contract, auto-reset, OpenMP over envs, %.1f s"
-                      % (E, steps, kind, n, dt)}
+
+    def run(nthreads, E, seconds):
+        gomp.omp_set_num_threads(nthreads)
+        orc = Oracle(kind, E, n, contract=contract, horizon=1000, auto_reset=True)
+        orc.seed(seed0=SEED0)
+        orc.reset()
+        acts = rs.randint(na, size=(32, E, n)).astype(np.uint8)
+        for t in range(8):
+            orc.step(acts[t % 32])
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(8):
+                orc.step(acts[steps % 32])
+                steps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+        orc.close()
+        return E * n * steps / dt, steps, dt
+
+    v_all, steps, dt = run(threads, 256 * threads, target_s)
+    v_one, steps1, dt1 = run(1, 256, min(4.0, target_s))
+    return {"value": v_all, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "single_thread_value": v_one, "cpu_model": _cpu_model(),
+            "python_reference_per_core": 4259,  # BASELINE.md: the reference itself, measured by the survey
+            "sample": "%d envs x %d steps, %s n=%d + contract, auto-reset, OpenMP over envs, %.1f s (+ %d envs x %d steps on "
+                      "1 thread, %.1f s)" % (256 * threads, steps, kind, n, dt, 256, steps1, dt1)}
 
 
 def main():

@@ -184,6 +184,37 @@ class BatchedEnv:
         check(self._L.ce_upload(self._h, field.encode(), env_begin, cnt, arr.ctypes.data, arr.nbytes), self._h,
               "ce_upload(%s)" % field)
 
+    # ---- env-state checkpoint (the reference never checkpoints env state) -----------------
+    _STATE_GRID = ("grid", "agents", "spawn_perm", "waste_perm", "rng", "timestep", "theta", "int_metrics",
+                   "f64_metrics", "final_int_metrics", "final_f64_metrics", "done", "error_flags")
+    _STATE_SD = ("sd_state", "rng", "theta", "f64_metrics", "final_f64_metrics", "int_metrics", "final_int_metrics",
+                 "done", "done_agents", "error_flags")
+
+    def state_dict(self):
+        """host copy of every persistent field: stepping from a restored state is bit-identical"""
+        fields = self._STATE_SD if self.kind == "selfdrive" else [
+            f for f in self._STATE_GRID if not (f == "waste_perm" and self.kind != "cleanup")]
+        out = {f: self.download(f, raw=True) for f in fields}
+        out["_meta"] = np.array([_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon],
+                                np.int64)
+        return out
+
+    def load_state_dict(self, state):
+        meta = [int(x) for x in state["_meta"]]
+        mine = [_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon]
+        if meta[:3] != mine[:3]:
+            raise ValueError("checkpoint is for kind/E/n %s, engine has %s" % (meta[:3], mine[:3]))
+        for f, arr in state.items():
+            if f != "_meta":
+                self.upload(f, arr)
+
+    def save(self, path):
+        np.savez_compressed(path, **self.state_dict())
+
+    def load(self, path):
+        with np.load(path) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+
     def __getattr__(self, name):  # oracle-compatible attribute access = fresh host copy
         if name in _FIELD_DTYPES and "b" in self.__dict__:
             return self.download(name)

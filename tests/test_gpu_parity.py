@@ -129,3 +129,35 @@ def test_bad_action_sets_fault():
     f = env.download("error_flags")
     assert f[2] & 1 and not f[[0, 1, 3]].any()
     env.close()
+
+
+@pytest.mark.parametrize("kind,n,contract", [("cleanup", 4, "cleanup"), ("selfdrive", 3, "selfdrive_distprop")])
+def test_state_checkpoint_roundtrip(tmp_path, kind, n, contract):
+    """save -> keep stepping -> load into a fresh engine -> the same continuation, bit for bit"""
+    E = 96
+    a = _engine(kind, E, n, contract=contract, horizon=40, auto_reset=True)
+    a.seed(seed0=7)
+    a.reset()
+    rs = np.random.RandomState(5)
+
+    def acts():
+        return rs.uniform(-0.15, 0.15, (E, n)).astype(np.float32) if kind == "selfdrive" else rs.randint(8, size=(E, n))
+
+    for _ in range(30):
+        a.step(acts())
+    path = str(tmp_path / "ckpt.npz")
+    a.save(path)
+    st = rs.get_state()
+    ref = []
+    for _ in range(25):
+        a.step(acts())
+        ref.append((a.download("reward").copy(), a.download("obs_f64" if kind == "selfdrive" else "obs").copy()))
+    b = _engine(kind, E, n, contract=contract, horizon=40, auto_reset=True)
+    b.load(path)
+    rs.set_state(st)
+    for t in range(25):
+        b.step(acts())
+        assert np.array_equal(b.download("reward"), ref[t][0], equal_nan=True), t
+        assert np.array_equal(b.download("obs_f64" if kind == "selfdrive" else "obs"), ref[t][1], equal_nan=True), t
+    a.close()
+    b.close()
