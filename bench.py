@@ -56,16 +56,28 @@ def _cpu_model():
     return "unknown"
 
 
+def _usable_cores():
+    """cores this process may actually use: scheduler affinity capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(kind, n, contract, target_s):
     """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this
     box's host cores with OpenMP over envs: a bounded sample of the same workload, at all threads (the
     reported value) and at one thread."""
     import ctypes
     from oracle.pyoracle import Oracle
-    try:
-        threads = len(os.sched_getaffinity(0))  # cores this process may actually run on
-    except AttributeError:
-        threads = os.cpu_count() or 1
+    threads = _usable_cores()
     gomp = ctypes.CDLL("libgomp.so.1")
     rs = np.random.RandomState(1)
     na = 8 if kind == "cleanup" else 7
