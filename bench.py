@@ -5,8 +5,10 @@ Workload (BASELINE.json north star / configs[3]): CleanupEnv `cleanup_new`, 8 ag
 16384 env replicas per GPU (131072 over 8 GPUs; weak scaling, plain shard of the env axis, no
 collectives), horizon 1000 with in-engine auto-reset, uniform i.i.d. synthetic actions generated on
 device by the counter hash keyed (seed, global env index, t, agent) and resident in HBM before the
-timed region.  A "step" = one ce_step launch over the whole env batch of this rank (MapEnv.step +
-obs crop + contract transfer for every env).
+timed region.  A "step" = one pass of the hot path over the whole env batch of this rank (MapEnv.step +
+obs crop + contract transfer for every env), issued as `--streams` (default 2) ce_step_range launches over
+contiguous env slices on separate HIP streams: slices are independent, so one slice's kernel tail overlaps
+the other's head (the same double buffering an RL sampler uses to overlap policy inference with stepping).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -41,6 +43,9 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--agents", type=int, default=N_AGENTS)
     ap.add_argument("--kind", default="cleanup", choices=["cleanup", "harvest"])
+    ap.add_argument("--streams", type=int, default=2,
+                    help="split each rank's env batch into this many contiguous slices stepped on separate HIP streams "
+                         "(slices are independent; one slice's kernel tail overlaps the next slice's head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -149,16 +154,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    S = max(1, a.streams)
+    bounds = [E * i // S for i in range(S + 1)]
+    slices = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(S)]
+    if S == 1:
+        streams = [None]
+        handles = [None]
+    else:
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        handles = [st.cuda_stream for st in streams]
+
+    def launch(t):
+        for (b0, cnt), hs in zip(slices, handles):
+            env.step_range_device(base + t * plane, b0, cnt, stream=hs)
+
     for t in range(W):
-        env.step_device(base + t * plane)
+        launch(t)
     barrier()
-    env.timing_begin()  # HIP events on the launch stream (the null stream the engine launches on)
+    # per-launch kernel time: HIP events on the stream(s) the kernels are launched on
+    if S == 1:
+        env.timing_begin()
+    else:
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+        for e0, st in zip(ev0, streams):
+            e0.record(st)
     t0 = time.perf_counter()
     for t in range(W, W + K):
-        env.step_device(base + t * plane)
+        launch(t)
+    if S > 1:
+        for e1, st in zip(ev1, streams):
+            e1.record(st)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    kernel_ms, launches = env.timing_end()
+    if S == 1:
+        kernel_ms, launches = env.timing_end()
+    else:
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)])) / K
+        launches = K * S
     barrier()
     elapsed = t1 - t0
     if world > 1:
@@ -173,31 +206,32 @@ def main():
     if rank == 0:
         total_agent_steps = world * E * n * K
         value = total_agent_steps / elapsed
-        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * E if (kind == "cleanup" and n == 8) else None
+        # one launch covers E/S envs; S launches (one per stream) run concurrently
+        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * E // S if (kind == "cleanup" and n == 8) else None
         roof = None
         if algo_bytes_launch:
-            achieved = algo_bytes_launch / (kernel_ms * 1e-3) / 1e9
+            achieved = S * algo_bytes_launch / (kernel_ms * 1e-3) / 1e9  # S concurrent launches share the chip
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("envs") == E and tj.get("agents") == n and tj.get("kind") == kind:
+                    if tj.get("envs_per_launch") == E // S and tj.get("agents") == n and tj.get("kind") == kind:
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "k_grid_step<%s>" % kind, "kernel_ms": kernel_ms, "launches": launches,
-                    "algorithmic_bytes_per_launch": algo_bytes_launch}
+                    "algorithmic_bytes_per_launch": algo_bytes_launch, "concurrent_streams": S}
         out = {
             "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "cleanup_new 8 agents + CleanupContract, %d envs/GPU, horizon 1000, auto-reset" % E
                        if kind == "cleanup" else "harvest_new %d agents + HarvestFeaturemodLocalContract, %d envs/GPU" % (n, E),
-                       "envs_per_gpu": E, "agents": n, "global_envs": world * E, "rng": "mt19937-numpy-compat",
-                       "parallelism": "env-shard x%d, no collectives" % world, "sanity": stats},
+                       "envs_per_gpu": E, "envs_per_launch": E // S, "agents": n, "global_envs": world * E, "rng": "mt19937-numpy-compat",
+                       "parallelism": "env-shard x%d, no collectives" % world, "streams_per_gpu": S, "sanity": stats},
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:

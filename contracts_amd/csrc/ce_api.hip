@@ -454,21 +454,32 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   return check_launch(h, "reset kernel");
 }
 
-extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
+extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin,
+                             uint32_t env_count, void* stream) {
   if (!h || !actions) return CE_EINVAL;
+  if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
   (void)hipSetDevice(h->cfg.device);
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
+    p.env_first = env_begin;
+    p.env_count = env_count;
     launch_grid_step((int)h->cfg.kind, p, h->d_gparams, stream);
   } else {
     SdParams p = sd_params(h);
     p.actions = (const float*)actions;
     p.active = active;
+    p.env_first = env_begin;
+    p.env_count = env_count;
     launch_sd_step(p, stream);
   }
   if (h->timing_armed) h->timed_launches++;
   return check_launch(h, "step kernel");
+}
+
+extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
+  if (!h) return CE_EINVAL;
+  return ce_step_range(h, actions, active, 0, h->cfg.num_envs, stream);
 }
 
 extern "C" int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) {

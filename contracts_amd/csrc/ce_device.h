@@ -74,6 +74,7 @@ struct GridParams {
   const uint8_t* mask;     // [E] or null (seed/reset)
   uint32_t E, n, horizon, contract, flags, obs_env_stride, num_features;
   uint32_t replay_constructor;
+  uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
   double contract_low, contract_high, null_prob, alpha, beta;
 };
 
@@ -96,6 +97,7 @@ struct SdParams {
   const uint8_t* active;
   const uint8_t* mask;
   uint32_t E, n, contract, flags, replay_constructor;
+  uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
   double contract_low, contract_high, null_prob, low_bound, high_bound, start_vel, start_vel_ambulance;
 };
 

@@ -89,6 +89,13 @@ DEVINL u32 wave_min_u32(u32 v) {
     __builtin_amdgcn_sched_barrier(0);                                                 \
     if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
   } while (0)
+#define CE_REALSTAMP(k)                                                                \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                    \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
+  } while (0)
 #define CE_SUBSTAMP(k)                                                                 \
   do {                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -102,6 +109,9 @@ DEVINL u32 wave_min_u32(u32 v) {
   } while (0)
 #define CE_SUBSTAMP(k) \
   do {                 \
+  } while (0)
+#define CE_REALSTAMP(k) \
+  do {                  \
   } while (0)
 #endif
 
@@ -1248,10 +1258,10 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #endif
 constexpr int kWavesPerBlock = 1;
 
-template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds) {
+template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds, u32 env_first, u32 env_end) {
   const u32 wave = threadIdx.x >> 6;
   E.lane = lane_id();
-  E.e = rfl(blockIdx.x * kWavesPerBlock + wave);
+  E.e = rfl(env_first + blockIdx.x * kWavesPerBlock + wave);
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
@@ -1260,15 +1270,16 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
 #else
   E.dbg = nullptr;
 #endif
-  return E.e < p.E;
+  return E.e < env_end;
 }
 
 // --- seed + "construct": replay the RNG use of MapEnv.__init__ (map_env.py:122-131) ---
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+                 u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
-  if (!env_begin(E, p, lds)) return;
+  if (!env_begin(E, p, lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
   typedef Geo<KIND> G;
   load_static(E);
@@ -1302,11 +1313,12 @@ template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParam
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+                 u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
-  if (!env_begin(E, p, lds)) return;
+  if (!env_begin(E, p, lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
   load_static(E);
   load_rng(E, p);
@@ -1330,11 +1342,12 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+                 u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
-  if (!env_begin(E, p, lds)) return;
+  if (!env_begin(E, p, lds, env_first, env_end)) return;
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
@@ -1347,6 +1360,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     return;
   }
   CE_STAMP(0);
+  CE_REALSTAMP(14);
   load_env_state(E, p);
   u32 t = (u32)p.timestep[E.e];
   double theta = p.theta[E.e];
@@ -1566,6 +1580,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   write_obs(E, p, !did_reset);
 #endif
   CE_STAMP(9);
+  CE_REALSTAMP(15);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1696,13 +1711,14 @@ static unsigned extra_lds() {
 }
 #define CE_LAUNCH_GRID(kern)                                                                          \
   do {                                                                                                \
-    dim3 grid((p.E + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);               \
+    const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;             \
+    dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);             \
     if (kind == CE_KIND_CLEANUP)                                                                      \
       hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
-                         p.actions, p.mask);                                                          \
+                         p.actions, p.mask, first, first + count);                                    \
     else                                                                                              \
       hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
-                         p.actions, p.mask);                                                          \
+                         p.actions, p.mask, first, first + count);                                    \
   } while (0)
 
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }

@@ -201,8 +201,8 @@ template <int N> __global__ void k_sd_reset(SdParams p) {
 }
 
 template <int N> __global__ void k_sd_step(SdParams p) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.E) return;
+  const u32 e = p.env_first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.env_first + (p.env_count ? p.env_count : p.E - p.env_first)) return;
   Cars<N> c;
   sd_load(p, e, c);
   double theta = p.theta[e];
@@ -459,7 +459,8 @@ __global__ void k_synth_f32(float* out, u64 key, u64 env_base, u32 E, u32 n, u32
 
 #define CE_SD_DISPATCH(kern)                                                                      \
   do {                                                                                            \
-    dim3 grid((p.E + 63) / 64), block(64);                                                        \
+    const u32 cnt_ = p.env_count ? p.env_count : p.E - p.env_first;                               \
+    dim3 grid((cnt_ + 63) / 64), block(64);                                                       \
     switch (p.n) {                                                                                \
       case 1: hipLaunchKernelGGL(kern<1>, grid, block, 0, (hipStream_t)stream, p); break;         \
       case 2: hipLaunchKernelGGL(kern<2>, grid, block, 0, (hipStream_t)stream, p); break;         \

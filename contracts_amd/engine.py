@@ -133,6 +133,11 @@ class BatchedEnv:
         """actions_ptr: raw DEVICE pointer (int) to [E, n] actions already resident in HBM."""
         check(self._L.ce_step(self._h, actions_ptr, active_ptr, stream), self._h, "ce_step")
 
+    def step_range_device(self, actions_ptr, env_begin, env_count, active_ptr=None, stream=None):
+        """step only envs [env_begin, env_begin+env_count); pointers address the full [E, n] planes"""
+        check(self._L.ce_step_range(self._h, actions_ptr, active_ptr, int(env_begin), int(env_count), stream), self._h,
+              "ce_step_range")
+
     def synth_actions(self, key, t0, T, out_ptr, stream=None):
         check(self._L.ce_synth_actions(self._h, int(key), int(t0), int(T), out_ptr, stream), self._h, "ce_synth_actions")
 

@@ -222,6 +222,13 @@ int ce_reset(ce_handle h, const uint8_t* mask, void* stream);
  * not done act, which is what RLlib sends).  Asynchronous on `stream` (hipStream_t). */
 int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream);
 
+/* ce_step restricted to the env slice [env_begin, env_begin + env_count).  `actions` / `active` still
+ * point at the FULL [E][n] planes (the slice indexes into them).  Slices are independent: stepping
+ * disjoint slices on different HIP streams lets one slice's tail overlap another's head (and, in an RL
+ * loop, one slice's policy inference overlap the other slice's env step — double-buffered sampling). */
+int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count,
+                  void* stream);
+
 /* Same as ce_step with HOST action / active pointers: they are copied to an engine-owned
  * staging buffer on `stream` first (the per-env adapters use this). */
 int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream);
