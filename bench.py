@@ -164,12 +164,11 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(S)]
         handles = [st.cuda_stream for st in streams]
 
-    def launch(t):
-        for (b0, cnt), hs in zip(slices, handles):
-            env.step_range_device(base + t * plane, b0, cnt, stream=hs)
+    def run_steps(t_begin, count):
+        # one launch per (step, slice); the loop itself runs in C (ce_rollout) to keep the host off the path
+        env.rollout_device(base + t_begin * plane, count, None if S == 1 else handles)
 
-    for t in range(W):
-        launch(t)
+    run_steps(0, W)
     barrier()
     # per-launch kernel time: HIP events on the stream(s) the kernels are launched on
     if S == 1:
@@ -180,8 +179,7 @@ def main():
         for e0, st in zip(ev0, streams):
             e0.record(st)
     t0 = time.perf_counter()
-    for t in range(W, W + K):
-        launch(t)
+    run_steps(W, K)
     if S > 1:
         for e1, st in zip(ev1, streams):
             e1.record(st)

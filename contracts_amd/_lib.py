@@ -58,6 +58,7 @@ EXPORTS = {
     "ce_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "ce_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_synth_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ce_synth_action_host": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),

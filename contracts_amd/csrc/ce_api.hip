@@ -477,6 +477,21 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
   return check_launch(h, "step kernel");
 }
 
+extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
+  if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
+  const uint32_t E = h->cfg.num_envs;
+  const size_t plane = (size_t)E * h->cfg.num_agents * (is_grid(h->cfg) ? 1 : 4);
+  for (uint32_t t = 0; t < num_steps; ++t) {
+    const char* a_t = (const char*)actions + (size_t)t * plane;
+    for (uint32_t s = 0; s < num_slices; ++s) {
+      const uint32_t b0 = (uint32_t)((uint64_t)E * s / num_slices), b1 = (uint32_t)((uint64_t)E * (s + 1) / num_slices);
+      const int rc = ce_step_range(h, a_t, nullptr, b0, b1 - b0, streams ? streams[s] : nullptr);
+      if (rc != CE_OK) return rc;
+    }
+  }
+  return CE_OK;
+}
+
 extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
   if (!h) return CE_EINVAL;
   return ce_step_range(h, actions, active, 0, h->cfg.num_envs, stream);

@@ -138,6 +138,15 @@ class BatchedEnv:
         check(self._L.ce_step_range(self._h, actions_ptr, active_ptr, int(env_begin), int(env_count), stream), self._h,
               "ce_step_range")
 
+    def rollout_device(self, actions_ptr, num_steps, stream_handles=None):
+        """num_steps consecutive steps from pre-supplied device action planes [T, E, n]; the launch loop runs
+        in C.  stream_handles: list of raw HIP stream handles, one env slice per stream (None = null stream)."""
+        if stream_handles:
+            arr = (C.c_void_p * len(stream_handles))(*stream_handles)
+            check(self._L.ce_rollout(self._h, actions_ptr, int(num_steps), len(stream_handles), arr), self._h, "ce_rollout")
+        else:
+            check(self._L.ce_rollout(self._h, actions_ptr, int(num_steps), 1, None), self._h, "ce_rollout")
+
     def synth_actions(self, key, t0, T, out_ptr, stream=None):
         check(self._L.ce_synth_actions(self._h, int(key), int(t0), int(T), out_ptr, stream), self._h, "ce_synth_actions")
 

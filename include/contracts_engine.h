@@ -229,6 +229,12 @@ int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* strea
 int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count,
                   void* stream);
 
+/* Launch loop in C for pre-supplied actions (benchmarks, random-policy rollouts): `num_steps` consecutive
+ * steps over all envs, each issued as `num_slices` ce_step_range launches on streams[0..num_slices-1] (NULL =
+ * all on the null stream).  actions: DEVICE pointer to [num_steps][E][n] planes.  Every step is still its own
+ * launch reading its own action plane; only the host-side loop moves out of the interpreter. */
+int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams);
+
 /* Same as ce_step with HOST action / active pointers: they are copied to an engine-owned
  * staging buffer on `stream` first (the per-env adapters use this). */
 int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream);
