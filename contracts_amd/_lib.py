@@ -35,9 +35,9 @@ _P = C.c_void_p
 class CeBuffers(C.Structure):
     _fields_ = [
         ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("grid_h", C.c_uint32), ("grid_w", C.c_uint32),
-        ("obs_bytes_per_agent", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
+        ("obs_agent_stride", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
         ("num_f64_metrics", C.c_uint32), ("obs_env_stride", C.c_uint32), ("rng_words", C.c_uint32),
-        ("grid_env_stride", C.c_uint32), ("reserved0", C.c_uint32),
+        ("grid_env_stride", C.c_uint32), ("obs_row_stride", C.c_uint32),
         ("grid", _P), ("agents", _P), ("spawn_perm", _P), ("waste_perm", _P), ("rng", _P), ("timestep", _P),
         ("theta", _P), ("sd_state", _P),
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),

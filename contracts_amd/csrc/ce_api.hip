@@ -210,8 +210,9 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
     h->grid_stride = cl ? Geo<0>::GRID_STRIDE : Geo<1>::GRID_STRIDE;
     b.grid_env_stride = h->grid_stride;
-    b.obs_bytes_per_agent = kPixPerAgent * 3;
-    b.obs_env_stride = (uint32_t)((n * kPixPerAgent * 3 + 3) / 4 * 4);
+    b.obs_row_stride = kObsRowStride;
+    b.obs_agent_stride = kObsAgentStride;
+    b.obs_env_stride = (uint32_t)(n * kObsAgentStride);
     b.num_features = (uint32_t)(cl ? 12 + n : 10 + 2 * n);
     b.rng_words = CE_RNG_WORDS_GRID;
     A(grid, E * h->grid_stride);

@@ -12,6 +12,9 @@ constexpr int kView = 7;    // CLEANUP_VIEW_SIZE / HARVEST_VIEW_SIZE (cleanup_ne
 constexpr int kWin = 15;    // 2*view+1
 constexpr int kPixPerAgent = kWin * kWin;  // 225
 constexpr int kMaxGridAgents = 9;
+// obs pitch: a view row is 16 pixels x 3 B (the 16th is padding), so the 12-byte / 4-pixel store units of the
+// crop kernel tile rows exactly: 4 units per row, 60 per agent, no unit straddles a row or an agent
+constexpr int kObsRowStride = 48, kObsAgentStride = kWin * kObsRowStride, kObsUnitsPerAgent = kObsAgentStride / 12;
 constexpr int kMtN = 624, kMtM = 397;
 constexpr int kRngStride = CE_RNG_WORDS_GRID;  // words per env row
 

@@ -994,49 +994,27 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     E.L->view[lane] = ((u32)o0 & 0xffffu) | (((u32)A & 0xffu) << 16) | (((u32)B & 0xffu) << 24);
   }
   wave_sync();
-  const u32 npix = E.n * kPixPerAgent;
-  const u32 units = (npix + 3) / 4;
+  // One 12-byte unit = 4 horizontally adjacent pixels of one view row (rows are pitched to 16 pixels): 60 units
+  // per agent, unit u -> agent u / 60, row (u % 60) / 4, first column 4 * (u % 4); the 4 cells are B apart.
+  const u32 units = E.n * (u32)kObsUnitsPerAgent;
   uint8_t* dst_env = p.obs + (size_t)E.e * p.obs_env_stride;
   for (u32 u = lane; u < units; u += 64) {
-    // env-wide pixel q -> (agent, i, j): q = 225 a + 15 i + j (exact multiply-shift divisions for q < 2032)
-    const u32 q0 = 4 * u;
-    u32 a = __umul24(q0, 4661u) >> 20;
-    const u32 pq = q0 - __umul24(225u, a);
-    u32 i = __umul24(pq, 2185u) >> 15;
-    u32 j = pq - __umul24(15u, i);
-    u32 col[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      u32 c = 0;
-      if (q0 + k < npix) {
-        const u32 vw = E.L->view[a];
-        const i32 off = (i32)(vw & 0xffffu) + __mul24((i32)i, (i32)(vw << 8) >> 24) + __mul24((i32)j, (i32)vw >> 24);
-        c = E.L->rgb[pm[off]];
-      }
-      col[k] = c;
-      j += 1;
-      if (j == 15) {
-        j = 0;
-        i += 1;
-        if (i == 15) {
-          i = 0;
-          a += 1;
-        }
-      }
-    }
-    const u32 d0 = __builtin_amdgcn_perm(col[1], col[0], 0x04020100u);  // R0 G0 B0 R1
-    const u32 d1 = __builtin_amdgcn_perm(col[2], col[1], 0x05040201u);  // G1 B1 R2 G2
-    const u32 d2 = __builtin_amdgcn_perm(col[3], col[2], 0x06050402u);  // B2 R3 G3 B3
-    const u32 boff = __umul24(u, 12u);
-    u32* dst = (u32*)(dst_env + boff);
-    if (boff + 12 <= p.obs_env_stride) {
-      dst[0] = d0;
-      dst[1] = d1;
-      dst[2] = d2;
-    } else {
-      if (boff + 4 <= p.obs_env_stride) dst[0] = d0;
-      if (boff + 8 <= p.obs_env_stride) dst[1] = d1;
-    }
+    const u32 a = __umul24(u, 1093u) >> 16;  // u / 60, exact for u < 600
+    const u32 rem = u - __umul24(a, (u32)kObsUnitsPerAgent);
+    const u32 i = rem >> 2, j0 = (rem & 3u) << 2;
+    const u32 vw = E.L->view[a];
+    const i32 B = (i32)vw >> 24;
+    const i32 off0 = (i32)(vw & 0xffffu) + __mul24((i32)i, (i32)(vw << 8) >> 24) + __mul24((i32)j0, B);
+    const u32 c0 = E.L->rgb[pm[off0]];
+    const u32 c1 = E.L->rgb[pm[off0 + B]];
+    const u32 c2 = E.L->rgb[pm[off0 + 2 * B]];
+    u32 c3 = E.L->rgb[pm[off0 + 3 * B]];
+    c3 = j0 == 12 ? 0u : c3;  // column 15 is the row padding
+    uint3 d;
+    d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
+    d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
+    d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
+    *(uint3*)(dst_env + __umul24(u, 12u)) = d;
   }
 }
 

@@ -183,8 +183,10 @@ class BatchedEnv:
             return out
         if field == "grid":
             return out[:, : self.b.grid_h * self.b.grid_w].reshape(cnt, self.b.grid_h, self.b.grid_w)
-        if field == "obs":
-            return out[:, : self.n * 675].reshape(cnt, self.n, 15, 15, 3)
+        if field == "obs":  # pitched rows (obs_row_stride bytes) -> dense [cnt, n, 15, 15, 3]
+            b = self.b
+            return np.ascontiguousarray(out.reshape(cnt, self.n, b.obs_agent_stride)[:, :, : 15 * b.obs_row_stride]
+                                        .reshape(cnt, self.n, 15, b.obs_row_stride)[:, :, :, :45]).reshape(cnt, self.n, 15, 15, 3)
         return out
 
     def upload(self, field, array, env_begin=0):
@@ -246,7 +248,7 @@ class BatchedEnv:
         b, E, n = self.b, self.E, self.n
         out = {}
         if self.kind != "selfdrive":
-            out["obs"] = _DevArray(b.obs, (E, n, 15, 15, 3), np.uint8, (b.obs_env_stride, 675, 45, 3, 1), self)
+            out["obs"] = _DevArray(b.obs, (E, n, 15, 15, 3), np.uint8, (b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, 3, 1), self)
             out["grid"] = _DevArray(b.grid, (E, b.grid_h, b.grid_w), np.uint8, (b.grid_env_stride, b.grid_w, 1), self)
             out["features"] = _DevArray(b.features, (E, n, b.num_features), np.int16, None, self)
             out["base_reward"] = _DevArray(b.base_reward, (E, n), np.int32, None, self)

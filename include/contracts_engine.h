@@ -90,17 +90,17 @@ typedef struct ce_config {
 typedef struct ce_buffers {
   uint32_t num_envs, num_agents;
   uint32_t grid_h, grid_w;       /* 25x18 cleanup, 16x38 harvest, 0 selfdrive              */
-  uint32_t obs_bytes_per_agent;  /* 675 for grid families                                  */
+  uint32_t obs_agent_stride;     /* bytes between consecutive agents of an env in `obs` (720)  */
   uint32_t num_features;         /* 12+n cleanup (cleanup_new.py:243-251), 10+2n harvest
                                     (harvest_new.py:215-222), 2n+7 selfdrive obs length    */
   uint32_t num_int_metrics;      /* see CE_MI_* / CE_MIA_*                                  */
   uint32_t num_f64_metrics;      /* see CE_MF_*                                            */
-  uint32_t obs_env_stride;       /* bytes between consecutive envs in `obs`:
-                                    round_up(n*675, 4) (== n*675 when n is a multiple of 4) */
+  uint32_t obs_env_stride;       /* bytes between consecutive envs in `obs` (n * obs_agent_stride) */
   uint32_t rng_words;            /* CE_RNG_WORDS_GRID / CE_RNG_WORDS_SELFDRIVE             */
   uint32_t grid_env_stride;      /* bytes between consecutive envs in `grid` (H*W rounded up
                                     to 16: 464 cleanup, 608 harvest)                       */
-  uint32_t reserved0;
+  uint32_t obs_row_stride;       /* bytes between consecutive rows of a 15x15x3 view (48: rows are
+                                    pitched to 16 pixels so a 4-pixel store unit never straddles a row) */
 
   /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
   uint8_t* grid;        /* [E] x grid_env_stride, each env holding [H][W] cell codes CE_CELL_* */
@@ -117,7 +117,8 @@ typedef struct ce_buffers {
   double* sd_state;     /* selfdrive: [E][CE_SD_STATE_DOUBLES(n)]                           */
 
   /* ---- per-step outputs ---- */
-  uint8_t* obs;          /* [E] x obs_env_stride bytes, each env holding [n][15][15][3] uint8 */
+  uint8_t* obs;          /* pitched image stack: pixel (e, a, i, j, ch) at e*obs_env_stride + a*obs_agent_stride
+                            + i*obs_row_stride + 3*j + ch; a zero-copy [E][n][15][15][3] strided view */
   double* obs_f64;       /* selfdrive: [E][n][2n+7]                                         */
   int32_t* base_reward;  /* [E][n]  MapEnv reward before the contract (ints, Agent.py:87)   */
   double* reward;        /* [E][n]  reward after the contract transfer

@@ -1396,7 +1396,8 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     build_static(o);
     o->b.grid_h = o->H;
     o->b.grid_w = o->W;
-    o->b.obs_bytes_per_agent = WIN * WIN * 3;
+    o->b.obs_agent_stride = WIN * WIN * 3;
+    o->b.obs_row_stride = WIN * 3;
     o->b.obs_env_stride = (uint32_t)((n * WIN * WIN * 3 + 3) / 4 * 4);
     o->b.rng_words = CE_RNG_WORDS_GRID;
     o->b.grid_env_stride = (uint32_t)o->cells;

@@ -35,9 +35,9 @@ _P = C.c_void_p
 class CeBuffers(C.Structure):
     _fields_ = [
         ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("grid_h", C.c_uint32), ("grid_w", C.c_uint32),
-        ("obs_bytes_per_agent", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
+        ("obs_agent_stride", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
         ("num_f64_metrics", C.c_uint32), ("obs_env_stride", C.c_uint32), ("rng_words", C.c_uint32),
-        ("grid_env_stride", C.c_uint32), ("reserved0", C.c_uint32),
+        ("grid_env_stride", C.c_uint32), ("obs_row_stride", C.c_uint32),
         ("grid", _P), ("agents", _P), ("spawn_perm", _P), ("waste_perm", _P), ("rng", _P), ("timestep", _P),
         ("theta", _P), ("sd_state", _P),
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
@@ -118,10 +118,11 @@ def _view(ptr, dtype, shape):
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
-def obs_view(raw, n):
+def obs_view(raw, n, agent_stride=675, row_stride=45):
     """[E][obs_env_stride] raw bytes -> zero-copy [E][n][15][15][3] view"""
     E, stride = raw.shape
-    return np.lib.stride_tricks.as_strided(raw, shape=(E, n, 15, 15, 3), strides=(stride, 675, 45, 3, 1), writeable=False)
+    return np.lib.stride_tricks.as_strided(raw, shape=(E, n, 15, 15, 3), strides=(stride, agent_stride, row_stride, 3, 1),
+                                           writeable=False)
 
 
 def buffer_views(b, kind):
@@ -135,7 +136,7 @@ def buffer_views(b, kind):
         v["spawn_perm"] = _view(b.spawn_perm, np.uint8, (E, 20))
         v["waste_perm"] = _view(b.waste_perm, np.uint8, (E, 119))
         v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
-        v["obs"] = obs_view(_view(b.obs, np.uint8, (E, b.obs_env_stride)), n)
+        v["obs"] = obs_view(_view(b.obs, np.uint8, (E, b.obs_env_stride)), n, b.obs_agent_stride, b.obs_row_stride)
         v["features"] = _view(b.features, np.int16, (E, n, b.num_features))
     else:
         v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
