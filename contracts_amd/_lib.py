@@ -37,7 +37,8 @@ class CeBuffers(C.Structure):
         ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("grid_h", C.c_uint32), ("grid_w", C.c_uint32),
         ("obs_agent_stride", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
         ("num_f64_metrics", C.c_uint32), ("obs_env_stride", C.c_uint32), ("rng_words", C.c_uint32),
-        ("grid_env_stride", C.c_uint32), ("obs_row_stride", C.c_uint32),
+        ("grid_env_stride", C.c_uint32), ("grid_row_stride", C.c_uint32), ("grid_origin", C.c_uint32),
+        ("obs_row_stride", C.c_uint32),
         ("grid", _P), ("agents", _P), ("spawn_perm", _P), ("waste_perm", _P), ("rng", _P), ("timestep", _P),
         ("theta", _P), ("sd_state", _P),
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),

@@ -210,6 +210,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
     h->grid_stride = cl ? Geo<0>::GRID_STRIDE : Geo<1>::GRID_STRIDE;
     b.grid_env_stride = h->grid_stride;
+    b.grid_row_stride = cl ? Geo<0>::PW : Geo<1>::PW;
+    b.grid_origin = kView * b.grid_row_stride + kView;
     b.obs_row_stride = kObsRowStride;
     b.obs_agent_stride = kObsAgentStride;
     b.obs_env_stride = (uint32_t)(n * kObsAgentStride);

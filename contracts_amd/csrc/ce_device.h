@@ -29,13 +29,15 @@ template <> struct Geo<CE_KIND_CLEANUP> {
   // LDS keeps the words of the apple doubles only; of a waste double only "u < 0.5" matters, which is
   // bit 31 of its first word (kept as one byte per double)
   static constexpr int UWORDS = 2 * 103, SBYTES = 224;
-  static constexpr int GRID_STRIDE = 464;  // bytes per env row in HBM (CELLS rounded up to 16)
+  // HBM keeps the map in the SAME bordered layout as LDS: loading / storing an env's map is a straight
+  // dword copy (no per-cell index arithmetic, no separate border zeroing)
+  static constexpr int GRID_STRIDE = (PCELLS + 15) / 16 * 16;
 };
 template <> struct Geo<CE_KIND_HARVEST> {
   static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
   static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
   static constexpr int UWORDS = 2 * 155, SBYTES = 16;
-  static constexpr int GRID_STRIDE = 608;
+  static constexpr int GRID_STRIDE = (PCELLS + 15) / 16 * 16;
 };
 
 // Static per-family tables (host-built from the ASCII maps, uploaded to __constant__).

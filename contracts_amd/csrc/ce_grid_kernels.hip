@@ -545,37 +545,17 @@ template <int KIND> DEVINL void zero_pmap(Env<KIND>& E) {
 
 template <int KIND> DEVINL void load_grid(Env<KIND>& E, const GridParams& p) {
   typedef Geo<KIND> G;
-  zero_pmap(E);
   const u32* src = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
-  for (u32 k = E.lane; k < (u32)(G::CELLS + 3) / 4; k += 64) {
-    u32 w = src[k];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      u32 idx = 4 * k + bb;
-      if (idx < (u32)G::CELLS) {
-        u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
-        E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((w >> (8 * bb)) & 0xff);
-      }
-    }
-  }
+  u32* dst = (u32*)E.L->pmap;
+  for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k];
   wave_sync();
 }
 template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
   typedef Geo<KIND> G;
   wave_sync();
   u32* dst = (u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
-  for (u32 k = E.lane; k < (u32)(G::CELLS + 3) / 4; k += 64) {
-    u32 w = 0;
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      u32 idx = 4 * k + bb;
-      if (idx < (u32)G::CELLS) {
-        u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
-        w |= (u32)(E.L->pmap[pad_of<KIND>(row, col)] & kCodeMask) << (8 * bb);
-      }
-    }
-    dst[k] = w;
-  }
+  const u32* src = (const u32*)E.L->pmap;
+  for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k] & 0x7f7f7f7fu;  // strip the agent bits
 }
 
 template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
@@ -616,16 +596,16 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane;
-  constexpr u32 NDW = (G::CELLS + 3) / 4;
   const uint4* rsrc = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
   const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64];
   uint4 r2 = make_uint4(0, 0, 0, 0);
   if (lane + 128 < kMtN / 4) r2 = rsrc[lane + 128];
   const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
   const u32* gsrc = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
-  u32 gw[3];
+  constexpr int GROUNDS = (G::PCELLS / 4 + 63) / 64;
+  u32 gw[GROUNDS];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) gw[r] = lane + 64 * r < NDW ? gsrc[lane + 64 * r] : 0u;
+  for (int r = 0; r < GROUNDS; ++r) gw[r] = lane + 64 * r < (u32)G::PCELLS / 4 ? gsrc[lane + 64 * r] : 0u;
   u32 aw = 0;
   if (E.is_agent) aw = ((const u32*)p.agents)[(size_t)E.e * E.n + lane];
   E.SP = lane < 20 ? p.spawn_perm[(size_t)E.e * 20 + lane] : 0;
@@ -648,26 +628,14 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   const u32 rgbv = c_rgb[lane & 15];
   // ---- LDS image ----
   u32* pm32 = (u32*)E.L->pmap;
-  for (u32 k = lane; k < (u32)G::PCELLS / 4; k += 64) pm32[k] = 0;
+#pragma unroll
+  for (int r = 0; r < GROUNDS; ++r)
+    if (lane + 64 * r < (u32)G::PCELLS / 4) pm32[lane + 64 * r] = gw[r];
   if (lane < 16) E.L->rgb[lane] = rgbv;
   uint4* mt4 = (uint4*)E.L->mt;
   mt4[lane] = r0;
   mt4[lane + 64] = r1;
   if (lane + 128 < kMtN / 4) mt4[lane + 128] = r2;
-  wave_sync();
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    if (64 * r < (int)NDW) {
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const u32 idx = 4 * (lane + 64 * r) + bb;
-        if (idx < (u32)G::CELLS) {
-          const u32 row = div_w<KIND>(idx), col = idx - __umul24(row, (u32)G::W);
-          E.L->pmap[pad_of<KIND>(row, col)] = (uint8_t)((gw[r] >> (8 * bb)) & 0xff);
-        }
-      }
-    }
-  }
   E.rng.mt = E.L->mt;
   E.rng.pos = rfl(rpos);
   E.rng.cbase = 0;

@@ -181,20 +181,26 @@ class BatchedEnv:
               "ce_download(%s)" % field)
         if raw:
             return out
-        if field == "grid":
-            return out[:, : self.b.grid_h * self.b.grid_w].reshape(cnt, self.b.grid_h, self.b.grid_w)
+        if field == "grid":  # bordered image -> dense [cnt, H, W]
+            return np.ascontiguousarray(self._grid_interior(out))
         if field == "obs":  # pitched rows (obs_row_stride bytes) -> dense [cnt, n, 15, 15, 3]
             b = self.b
             return np.ascontiguousarray(out.reshape(cnt, self.n, b.obs_agent_stride)[:, :, : 15 * b.obs_row_stride]
                                         .reshape(cnt, self.n, 15, b.obs_row_stride)[:, :, :, :45]).reshape(cnt, self.n, 15, 15, 3)
         return out
 
+    def _grid_interior(self, raw):
+        """strided [cnt, H, W] view of the interior of raw bordered grid slices [cnt, grid_env_stride]"""
+        b = self.b
+        return np.lib.stride_tricks.as_strided(raw[:, b.grid_origin:], shape=(raw.shape[0], b.grid_h, b.grid_w),
+                                               strides=(raw.strides[0], b.grid_row_stride, 1))
+
     def upload(self, field, array, env_begin=0):
         arr = np.asarray(array)
         cnt = arr.shape[0]
         if field == "grid" and arr.ndim == 3:
             raw = np.zeros((cnt, self.b.grid_env_stride), np.uint8)
-            raw[:, : self.b.grid_h * self.b.grid_w] = arr.reshape(cnt, -1)
+            self._grid_interior(raw)[...] = arr
             arr = raw
         arr = np.ascontiguousarray(arr, _FIELD_DTYPES[field]).reshape((cnt,) + self._env_shape(field))
         check(self._L.ce_upload(self._h, field.encode(), env_begin, cnt, arr.ctypes.data, arr.nbytes), self._h,
@@ -249,7 +255,8 @@ class BatchedEnv:
         out = {}
         if self.kind != "selfdrive":
             out["obs"] = _DevArray(b.obs, (E, n, 15, 15, 3), np.uint8, (b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, 3, 1), self)
-            out["grid"] = _DevArray(b.grid, (E, b.grid_h, b.grid_w), np.uint8, (b.grid_env_stride, b.grid_w, 1), self)
+            out["grid"] = _DevArray(b.grid + b.grid_origin, (E, b.grid_h, b.grid_w), np.uint8,
+                                    (b.grid_env_stride, b.grid_row_stride, 1), self)
             out["features"] = _DevArray(b.features, (E, n, b.num_features), np.int16, None, self)
             out["base_reward"] = _DevArray(b.base_reward, (E, n), np.int32, None, self)
         else:

@@ -97,13 +97,16 @@ typedef struct ce_buffers {
   uint32_t num_f64_metrics;      /* see CE_MF_*                                            */
   uint32_t obs_env_stride;       /* bytes between consecutive envs in `obs` (n * obs_agent_stride) */
   uint32_t rng_words;            /* CE_RNG_WORDS_GRID / CE_RNG_WORDS_SELFDRIVE             */
-  uint32_t grid_env_stride;      /* bytes between consecutive envs in `grid` (H*W rounded up
-                                    to 16: 464 cleanup, 608 harvest)                       */
+  uint32_t grid_env_stride;      /* bytes between consecutive envs in `grid`                  */
+  uint32_t grid_row_stride;      /* bytes between consecutive map rows inside an env's `grid` slice: the map
+                                    is stored with the 7-cell view border on every side (32 cleanup, 52 harvest) */
+  uint32_t grid_origin;          /* byte offset of cell (0, 0) inside the slice (7 * grid_row_stride + 7)   */
   uint32_t obs_row_stride;       /* bytes between consecutive rows of a 15x15x3 view (48: rows are
                                     pitched to 16 pixels so a 4-pixel store unit never straddles a row) */
 
   /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
-  uint8_t* grid;        /* [E] x grid_env_stride, each env holding [H][W] cell codes CE_CELL_* */
+  uint8_t* grid;        /* bordered image: cell (e, r, c) at e*grid_env_stride + grid_origin + r*grid_row_stride
+                           + c, cell codes CE_CELL_*; border bytes are 0; a zero-copy [E][H][W] strided view  */
   uint8_t* agents;      /* [E][n][4]  row, col, orientation (UP0 RIGHT1 DOWN2 LEFT3,
                                       Agent.py:18-23), 0                                   */
   uint8_t* spawn_perm;  /* [E][20]    persistent shuffled spawn list (map_env.py:821) as

@@ -1401,6 +1401,8 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     o->b.obs_env_stride = (uint32_t)((n * WIN * WIN * 3 + 3) / 4 * 4);
     o->b.rng_words = CE_RNG_WORDS_GRID;
     o->b.grid_env_stride = (uint32_t)o->cells;
+    o->b.grid_row_stride = (uint32_t)o->W;
+    o->b.grid_origin = 0;
     o->b.num_features = o->kind == CE_KIND_CLEANUP ? 12 + n : 10 + 2 * n;
     ALLOC(grid, uint8_t, E * o->cells);
     ALLOC(agents, uint8_t, E * n * 4);

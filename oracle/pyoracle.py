@@ -37,7 +37,8 @@ class CeBuffers(C.Structure):
         ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("grid_h", C.c_uint32), ("grid_w", C.c_uint32),
         ("obs_agent_stride", C.c_uint32), ("num_features", C.c_uint32), ("num_int_metrics", C.c_uint32),
         ("num_f64_metrics", C.c_uint32), ("obs_env_stride", C.c_uint32), ("rng_words", C.c_uint32),
-        ("grid_env_stride", C.c_uint32), ("obs_row_stride", C.c_uint32),
+        ("grid_env_stride", C.c_uint32), ("grid_row_stride", C.c_uint32), ("grid_origin", C.c_uint32),
+        ("obs_row_stride", C.c_uint32),
         ("grid", _P), ("agents", _P), ("spawn_perm", _P), ("waste_perm", _P), ("rng", _P), ("timestep", _P),
         ("theta", _P), ("sd_state", _P),
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
@@ -131,7 +132,7 @@ def buffer_views(b, kind):
     v = {}
     if kind != "selfdrive":
         cells = b.grid_h * b.grid_w
-        v["grid"] = _view(b.grid, np.uint8, (E, b.grid_env_stride))[:, :cells].reshape(E, b.grid_h, b.grid_w)
+        v["grid"] = _view(b.grid, np.uint8, (E, b.grid_env_stride))[:, :cells].reshape(E, b.grid_h, b.grid_w)  # dense in the oracle
         v["agents"] = _view(b.agents, np.uint8, (E, n, 4))
         v["spawn_perm"] = _view(b.spawn_perm, np.uint8, (E, 20))
         v["waste_perm"] = _view(b.waste_perm, np.uint8, (E, 119))
