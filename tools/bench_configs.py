@@ -1,4 +1,4 @@
-"""Throughput of every BASELINE.json config on one GPU (not the headline bench; results go to
+"""Throughput of every BASELINE.json config on one GPU (2 env slices on 2 streams, like bench.py) (not the headline bench; results go to
 profiles/<round>_configs.json for DESIGN.md).  Same timing method as bench.py."""
 import json
 import sys
@@ -25,19 +25,25 @@ for name, kind, n, E, contract, algo in CONFIGS:
     acts = torch.empty((W + K, E, n), dtype=dt, device="cuda")
     env.synth_actions(73908, 0, W + K, acts.data_ptr())
     stride = E * n * acts.element_size()
-    for t in range(W):
-        env.step_device(acts.data_ptr() + t * stride)
+    S = 2
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    handles = [st.cuda_stream for st in streams]
+    env.rollout_device(acts.data_ptr(), W, handles)
     torch.cuda.synchronize()
-    env.timing_begin()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    for e0, st in zip(ev0, streams):
+        e0.record(st)
     t0 = time.perf_counter()
-    for t in range(W, W + K):
-        env.step_device(acts.data_ptr() + t * stride)
+    env.rollout_device(acts.data_ptr() + W * stride, K, handles)
+    for e1, st in zip(ev1, streams):
+        e1.record(st)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ms, cnt = env.timing_end()
+    ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / S / K  # mean duration of one launch (E/S envs); S run concurrently
     env.check_faults() if kind != "selfdrive" else None
-    row = {"config": name, "agent_steps_per_s": E * n * K / el, "kernel_ms": ms, "algorithmic_GBs": algo * E / (ms * 1e-3) / 1e9,
-           "roofline_frac": algo * E / (ms * 1e-3) / 1e9 / 8000.0}
+    row = {"config": name, "agent_steps_per_s": E * n * K / el, "streams": S, "envs_per_launch": E // S, "kernel_ms": ms,
+           "algorithmic_GBs": algo * E / (ms * 1e-3) / 1e9, "roofline_frac": algo * E / (ms * 1e-3) / 1e9 / 8000.0}
     print(json.dumps(row))
     out.append(row)
     env.close()
