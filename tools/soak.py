@@ -1,0 +1,59 @@
+"""Randomised soak: engine vs CPU oracle over random configurations (family, n, flags, horizon, policy mix),
+every persistent and output field compared after every step.  Usage: python tools/soak.py [seconds] [seed]"""
+import sys
+import time
+import numpy as np
+sys.path.insert(0, ".")
+from contracts_amd.engine import BatchedEnv
+from oracle.pyoracle import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+FIELDS = ["grid", "agents", "spawn_perm", "rng", "timestep", "theta", "obs", "base_reward", "reward", "done", "info", "features",
+          "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics"]
+t_end = time.time() + budget
+runs = steps_total = 0
+while time.time() < t_end:
+    kind = rs.choice(["cleanup", "harvest"])
+    n = int(rs.randint(1, 10))
+    firing = bool(rs.randint(2))
+    contract = None if rs.rand() < 0.3 else ("cleanup" if kind == "cleanup" else "harvest_local")
+    inequity = n > 1 and rs.rand() < 0.15
+    collective = (not inequity) and rs.rand() < 0.15
+    horizon = int(rs.choice([7, 23, 60, 1000]))
+    E = int(rs.choice([65, 128, 300]))
+    kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, collective=collective, inequity=inequity,
+              alpha=float(rs.rand() * 5), beta=float(rs.rand()))
+    env, orc = BatchedEnv(kind, E, n, **kw), Oracle(kind, E, n, **kw)
+    seeds = rs.randint(0, 2 ** 31 - 1, size=E).astype(np.uint64)
+    for o in (env, orc):
+        o.seed(seeds)
+        o.reset()
+    na = env.num_actions
+    p = rs.dirichlet(np.ones(na) * rs.choice([0.3, 1.0, 5.0]))
+    fields = FIELDS + (["waste_perm"] if kind == "cleanup" else [])
+    T = int(rs.choice([40, 120]))
+    ok = True
+    for t in range(T):
+        a = rs.choice(na, size=(E, n), p=p).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        for f in fields:
+            x, y = env.download(f), getattr(orc, f)
+            if f == "rng":
+                x, y = x[:, :625], y[:, :625]
+            same = np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+            if not same:
+                bad = np.nonzero((x != y).reshape(E, -1).any(axis=1))[0]
+                print("MISMATCH", kind, n, kw, "field", f, "step", t, "envs", bad[:6])
+                ok = False
+                break
+        if not ok:
+            break
+    runs += 1
+    steps_total += T * E
+    env.close()
+    orc.close()
+    if not ok:
+        sys.exit(1)
+print("soak ok: %d random configs, %d env-steps compared field by field" % (runs, steps_total))
