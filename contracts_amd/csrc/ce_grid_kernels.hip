@@ -1089,110 +1089,136 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
 // total_close_apples).  Apples / wastes only ever sit on the static apple / waste cells, so the
 // closest-cell searches scan those lists (2-3 lane rounds) instead of the whole map.
 // ----------------------------------------------------------------------------------------
+// min over the aligned group of 2^sh lanes (sh = 2, 3, 4) this lane belongs to; every lane of the group gets it
+DEVINL u32 group_min_u32(u32 v, u32 sh) {
+#define CE_DPP_MIN(ctrl)                                                                    \
+  {                                                                                         \
+    const u32 t = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, 0xf, 0xf, false);  \
+    v = t < v ? t : v;                                                                      \
+  }
+  CE_DPP_MIN(0xB1)               // quad_perm [1,0,3,2]
+  CE_DPP_MIN(0x4E)               // quad_perm [2,3,0,1]
+  if (sh >= 3) CE_DPP_MIN(0x141)  // row_half_mirror
+  if (sh >= 4) CE_DPP_MIN(0x140)  // row_mirror
+#undef CE_DPP_MIN
+  return v;
+}
+
+// two feature values as one dword when the row is dword aligned (num_features even), else two shorts
+DEVINL void store_feat2(int16_t* f, u32 idx, u32 lo, u32 hi, bool aligned) {
+  if (aligned) {
+    *reinterpret_cast<u32*>(f + idx) = (lo & 0xffffu) | hi << 16;
+  } else {
+    f[idx] = (int16_t)lo;
+    f[idx + 1] = (int16_t)hi;
+  }
+}
+
 template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, u32 cleaned) {
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
   const size_t ia = (size_t)E.e * n + lane;
   uint8_t* pm = E.L->pmap;
-    const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
-    const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
-    const u32 myrow = row_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
-    const u32 mycol = col_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
-    const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
-    bool aflag[3];
-    u32 napples = 0;
+  const u32 nf = p.num_features;
+  const bool al = (nf & 1u) == 0;  // feature rows dword aligned
+  const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
+  const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
+  const u32 myrow = row_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+  const u32 mycol = col_of<KIND>(E.is_agent ? E.P : pad_of<KIND>(0, 0));
+  const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
+
+  // Closest apple / waste = min over keys  manhattan << 16 | row << 8 | col  (ties: smallest (row, col) ==
+  // first in the row-major list, as np.argmin).  Coordinates sit one per byte, so the Manhattan distance is a
+  // single v_sad_u8 against the agent's packed (row, col).  The present apples / wastes are first written as a
+  // key list (absent cell = ~0, which also yields key ~0) into the now idle random-word scratch; then the wave
+  // splits into n groups of 2^sh lanes, group a scanning the whole list for agent a, 4 cells per LDS read.
+  constexpr u32 NCHUNK = KIND == CE_KIND_CLEANUP ? 32u : 64u;  // 4-cell chunks per list
+  constexpr u32 NENT = NCHUNK * 4u;
+  static_assert(NENT >= (u32)G::NAPPLE && (KIND != CE_KIND_CLEANUP || NENT >= (u32)G::NWASTE), "key list too short");
+  static_assert(KIND == CE_KIND_CLEANUP ? 2 * NENT * 4 <= sizeof(E.L->U) + sizeof(E.L->S) : NENT * 4 <= sizeof(E.L->U), "scratch");
+  u32* keyA = E.L->U;
+  u32* keyW = E.L->U + NENT;
+  u32 napples = 0, nwaste = 0;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      aflag[r] = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r])] == CE_CELL_APPLE;
-      napples += popc64(ballot(aflag[r]));
+  for (u32 r = 0; r < NENT / 64u; ++r) {
+    bool f = false;
+    u32 rc = 0;
+    if (r < 3) {
+      f = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r < 3 ? r : 0])] == CE_CELL_APPLE;
+      rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
-    bool wflag[2] = {false, false};
-    u32 nwaste = 0;
+    napples += popc64(ballot(f));
+    keyA[lane + 64 * r] = f ? rc : 0xffffffffu;
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (u32 r = 0; r < 2; ++r) {
+      const bool f = lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE;
+      nwaste += popc64(ballot(f));
+      keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : 0xffffffffu;
+    }
+  }
+  const u32 sh = n <= 4 ? 4u : n <= 8 ? 3u : 2u;
+  const u32 ga = lane >> sh, gl = lane & ((1u << sh) - 1u);
+  const u32 prc = bperm(mycol | myrow << 8, ga);  // also the wave_sync-free way to get agent ga's position
+  wave_sync();
+  u32 ka = 0xffffffffu, kw = 0xffffffffu;
+  for (u32 c = gl; c < NCHUNK; c += 1u << sh) {
+    const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
+    const u32 k0 = __builtin_amdgcn_sad_u8(a4.x, prc, 0u) << 16 | a4.x, k1 = __builtin_amdgcn_sad_u8(a4.y, prc, 0u) << 16 | a4.y;
+    const u32 k2 = __builtin_amdgcn_sad_u8(a4.z, prc, 0u) << 16 | a4.z, k3 = __builtin_amdgcn_sad_u8(a4.w, prc, 0u) << 16 | a4.w;
+    ka = min(min(ka, min(k0, k1)), min(k2, k3));
     if (KIND == CE_KIND_CLEANUP) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        wflag[r] = lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE;
-        nwaste += popc64(ballot(wflag[r]));
-      }
+      const uint4 w4 = *reinterpret_cast<const uint4*>(keyW + 4 * c);
+      const u32 q0 = __builtin_amdgcn_sad_u8(w4.x, prc, 0u) << 16 | w4.x, q1 = __builtin_amdgcn_sad_u8(w4.y, prc, 0u) << 16 | w4.y;
+      const u32 q2 = __builtin_amdgcn_sad_u8(w4.z, prc, 0u) << 16 | w4.z, q3 = __builtin_amdgcn_sad_u8(w4.w, prc, 0u) << 16 | w4.w;
+      kw = min(min(kw, min(q0, q1)), min(q2, q3));
     }
-    u32 ca_r = 0, ca_c = 0, cw_r = 0, cw_c = 0, close_now = 0;
-    // Closest apple / waste = min over keys  manhattan << 16 | row << 8 | col  (ties: smallest (row, col) ==
-    // first in the row-major list, as np.argmin).  Coordinates sit one per byte, so the Manhattan distance
-    // is a single v_sad_u8 against the agent's packed (row, col); flagged-out cells get key ~0.
-    u32 arc[3], akey_off[3], wrc[2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) arc[r] = cell_rc(E.AP[r]);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) wrc[r] = cell_rc(E.WS[r]);
-    (void)akey_off;
+  }
+  ka = group_min_u32(ka, sh);
+  if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
+  if (ka == 0xffffffffu) ka = 0;  // [0, 0] sentinel when there is none
+  if (kw == 0xffffffffu) kw = 0;
+  if (gl == 0 && ga < n) {  // the group's first lane writes agent ga's closest-apple / closest-waste features
+    int16_t* f = p.features + ((size_t)E.e * n + ga) * nf;
+    store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
+    if (KIND == CE_KIND_CLEANUP) store_feat2(f, 8, (kw >> 8) & 0xffu, kw & 0xffu, al);
+  }
+  u32 close_now = 0;
+  if (KIND == CE_KIND_HARVEST) {
     for (u32 a = 0; a < n; ++a) {
       const u32 pa = rdl(E.P, a);
-      const u32 prc = col_of<KIND>(pa) | row_of<KIND>(pa) << 8;
-      u32 key = 0xffffffffu;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (64 * r < G::NAPPLE) {
-          const u32 d = __builtin_amdgcn_sad_u8(arc[r], prc, 0u);
-          const u32 k2 = aflag[r] ? (d << 16 | arc[r]) : 0xffffffffu;
-          key = k2 < key ? k2 : key;
-        }
-      }
-      const u32 best = wave_min_u32(key);
-      u32 br = 0, bc = 0;
-      if (best != 0xffffffffu) {  // [0, 0] sentinel when there is none
-        br = (best >> 8) & 0xffu;
-        bc = best & 0xffu;
-      }
-      if (lane == a) { ca_r = br; ca_c = bc; }
-      if (KIND == CE_KIND_CLEANUP) {
-        u32 keyw = 0xffffffffu;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const u32 d = __builtin_amdgcn_sad_u8(wrc[r], prc, 0u);
-          const u32 k2 = wflag[r] ? (d << 16 | wrc[r]) : 0xffffffffu;
-          keyw = k2 < keyw ? k2 : keyw;
-        }
-        const u32 bw = wave_min_u32(keyw);
-        u32 wr = 0, wc = 0;
-        if (bw != 0xffffffffu) {
-          wr = (bw >> 8) & 0xffu;
-          wc = bw & 0xffu;
-        }
-        if (lane == a) { cw_r = wr; cw_c = wc; }
-      } else {
-        const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
-        const u32 cnt = popc64(ballot(v));
-        if (lane == a) close_now = cnt;
-      }
+      const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+      const u32 cnt = popc64(ballot(v));
+      if (lane == a) close_now = cnt;
     }
-    if (KIND == CE_KIND_CLEANUP) {
+  }
+  int16_t* f = p.features + ia * nf;
+  if (KIND == CE_KIND_CLEANUP) {
+    if (al) {  // n even: the cleaned vector as n/2 dwords
+      for (u32 b = 0; b < n; b += 2) {
+        const u32 w = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
+        if (E.is_agent) *reinterpret_cast<u32*>(f + 12 + b) = w;
+      }
+    } else {
       for (u32 b = 0; b < n; ++b) {
         const u32 cb = rdl(cleaned, b);
-        if (E.is_agent) p.features[ia * p.num_features + 12 + b] = (int16_t)cb;
+        if (E.is_agent) f[12 + b] = (int16_t)cb;
       }
     }
-    if (E.is_agent) {
-      int16_t* f = p.features + ia * p.num_features;
-      f[0] = (int16_t)myrow;
-      f[1] = (int16_t)mycol;
-      f[2] = (int16_t)E.O;
-      f[3] = (int16_t)row_of<KIND>(cpp);
-      f[4] = (int16_t)col_of<KIND>(cpp);
-      f[5] = (int16_t)cpo;
-      f[6] = (int16_t)ca_r;
-      f[7] = (int16_t)ca_c;
-      if (KIND == CE_KIND_CLEANUP) {
-        f[8] = (int16_t)cw_r;
-        f[9] = (int16_t)cw_c;
-        f[10] = (int16_t)napples;
-        f[11] = (int16_t)nwaste;
-      } else {
-        f[8] = (int16_t)close_now;
-        f[9] = (int16_t)napples;
-        for (u32 b = 0; b < 2 * n; ++b) f[10 + b] = 0;
-      }
+  }
+  if (E.is_agent) {
+    store_feat2(f, 0, myrow, mycol, al);
+    store_feat2(f, 2, E.O, row_of<KIND>(cpp), al);
+    store_feat2(f, 4, col_of<KIND>(cpp), cpo, al);
+    if (KIND == CE_KIND_CLEANUP) {
+      store_feat2(f, 10, napples, nwaste, al);
+    } else {
+      store_feat2(f, 8, close_now, napples, al);
+      for (u32 b = 0; b < n; ++b) *reinterpret_cast<u32*>(f + 10 + 2 * b) = 0u;  // num_features = 10 + 2n: always aligned
     }
+  }
   return close_now;
 }
 
