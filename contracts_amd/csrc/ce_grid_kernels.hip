@@ -418,6 +418,65 @@ DEVINL void shuffle_apply(u32& L0, u32& L1, u32 len, const u32* J, u32 lane) {
   L1 = l1;
 }
 
+// The same list update without the serial chain.  Position i is final right after step i (later steps have
+// smaller i and j <= i), and what step i leaves there is the content of position J[i] at that time:
+//   - C(x), the content of position x just before its own step x, is C(G[x]) with G[x] = the smallest step
+//     i' > x that targets x (the last deposit before time x; a deposit at step i' is the old x[i'] = C(i')),
+//     or the initial x[x] when no step targets it: a forest ascending in x, flattened by pointer doubling;
+//   - final x[i] = C(F[i]) with F[i] = the smallest step i' > i with J[i'] == J[i], or the initial x[J[i]];
+//   - a position that has no step of its own in the phase ends with C(smallest step targeting it).
+// "Smallest step above i targeting p" is a find-first-set on a per-target 64-bit step mask built with LDS
+// atomic ORs.  Two phases (steps len-1..64 with x[i] in L1, then steps 63..1 inside L0) keep the masks 64 bit.
+// `scratch` is the LDS block holding J on entry; it is overwritten (needs 8 * len bytes).
+DEVINL u32 ffs64_or(u64 m, u32 none) { return m ? (u32)__builtin_ctzll(m) : none; }
+DEVINL u32 chase_roots(u32 parent) {  // parent[l] >= l; returns the root of every lane's chain
+  u32 R = parent;
+  for (int k = 0; k < 6; ++k) {
+    const u32 R2 = bperm(R, R);
+    if (ballot(R2 != R) == 0) break;
+    R = R2;
+  }
+  return R;
+}
+DEVINL void shuffle_apply_par(u32& L0, u32& L1, u32 len, u32* scratch, u32 lane) {  // 64 < len <= 128
+  const u32 n1 = len - 64;  // steps 64 .. len-1 live in lanes 0 .. n1-1
+  const u32 J0 = lane >= 1 ? scratch[lane] : 0u;  // lane 0 has no step; J = 0 makes F = "first step targeting 0"
+  const u32 J1 = lane < n1 ? scratch[64 + lane] : 0u;
+  wave_sync();
+  unsigned long long* M = reinterpret_cast<unsigned long long*>(scratch);
+  const u64 above = (~1ull) << lane;  // steps after this lane's own
+  // ---- phase 1
+  M[lane] = 0ull;
+  if (lane + 64 < len) M[64 + lane] = 0ull;
+  wave_sync();
+  if (lane < n1) atomicOr(&M[J1], 1ull << lane);
+  wave_sync();
+  {
+    const u64 mF = lane < n1 ? (M[J1] & above) : 0ull;
+    const u64 mG = lane < n1 ? (M[64 + lane] & above) : 0ull;
+    const u64 mH = M[lane];
+    const u32 R = chase_roots(ffs64_or(mG, lane));
+    const u32 rF = bperm(R, ffs64_or(mF, 0u)), rH = bperm(R, ffs64_or(mH, 0u));
+    const u32 v1 = bperm(L1, mF ? rF : (J1 & 63u)), v0 = bperm(L0, J1 & 63u), vH = bperm(L1, rH);
+    const u32 nL1 = (mF == 0 && J1 < 64) ? v0 : v1;
+    L1 = lane < n1 ? nL1 : L1;
+    L0 = mH ? vH : L0;
+  }
+  wave_sync();
+  // ---- phase 2
+  M[lane] = 0ull;
+  wave_sync();
+  if (lane >= 1) atomicOr(&M[J0], 1ull << lane);
+  wave_sync();
+  {
+    const u64 mF = M[J0] & above, mG = M[lane] & above;
+    const u32 R = chase_roots(ffs64_or(mG, lane));
+    const u32 rF = bperm(R, ffs64_or(mF, 0u));
+    L0 = bperm(L0, mF ? rF : J0);
+  }
+  wave_sync();
+}
+
 DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
   u32 dummy = 0;
   shuffle_core<false>(r, L0, dummy, len, lane);
@@ -831,7 +890,6 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
     const u64 thr = T.apple_thresh[nH];
     const bool waste_on = T.waste_on[nH] != 0;
-    CE_SUBSTAMP(10);
     rng_bulk(E.rng, E.L->U, E.L->S, (u32)G::RANDW, (u32)G::UWORDS, true, lane);
     CE_SUBSTAMP(11);
     u32 rbase = 0;
@@ -855,14 +913,6 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #else
     if (waste_on) {
 #endif
-#ifdef CE_SEQ_SHUFFLE
-      shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
-#else
-      // the apple doubles in U are dead by now: U doubles as the draw list J[0..118]
-      shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
-      shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
-#endif
-      CE_SUBSTAMP(13);
       // The walk over the shuffled list hands double rbase + t to the t-th non-waste cell and stops at the
       // first u < 0.5: t* = first set byte of S from rbase on, independent of the permutation.
       const u32 ncand = (u32)G::NWASTE - nH;
@@ -875,6 +925,22 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
           if (sb) tstar = ctz64(sb) + 64 * r;
         }
       }
+#ifdef CE_SEQ_SHUFFLE
+      shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+#else
+      // the apple doubles in U are dead by now: U doubles as the draw list J[0..118]
+      shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
+      CE_SUBSTAMP(10);
+#ifdef CE_SERIAL_APPLY
+      shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+#else
+      // the step-mask table of the list update spills from U into S (both dead by now: t* is already known)
+      static_assert(offsetof(WaveLds<KIND>, S) == offsetof(WaveLds<KIND>, U) + sizeof(E.L->U), "S must follow U");
+      static_assert(sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
+      shuffle_apply_par(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+#endif
+#endif
+      CE_SUBSTAMP(13);
       if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
         u32 seen = 0;
 #pragma unroll
@@ -1652,6 +1718,36 @@ __global__ void k_selftest(u32* out) {
     L0 = wrl(vj, 5, L0);
     L1 = wrl(vi, 3, L1);
     if (ballot((lane == 5 && L0 != 67) || (lane == 3 && L1 != 5) || (lane != 5 && L0 != lane)) != 0) fail |= 4u;
+  }
+  // (3) pointer-chasing list update against the serial swap loop, over random and adversarial draw lists
+  {
+    __shared__ u32 jl[2][256];
+    for (u32 trial = 0; trial < 64; ++trial) {
+      const u32 len = trial < 48 ? 119u : 65u + ((trial * 37u) & 63u);
+      for (u32 i = lane; i < 128; i += 64) {
+        u32 h = (i * 2654435761u) ^ (trial * 0x9e3779b9u);
+        h ^= h >> 13;
+        h *= 0x85ebca6bu;
+        h ^= h >> 16;
+        u32 j = h % (i + 1);
+        if (trial == 1) j = 0;
+        if (trial == 2) j = i;
+        if (trial == 3) j = i ? i - 1 : 0;
+        if (trial == 4) j = i >= 64 ? 64 : 0;
+        if (trial == 5) j = i >= 64 ? 63 : i / 2;
+        if (trial == 6) j = i & 1 ? i : i / 3;
+        if (trial >= 7 && trial < 16) j = h % ((i >> (trial - 6)) + 1);  // crowded low targets
+        jl[0][i] = j;
+        jl[1][i] = j;
+      }
+      wave_sync();
+      u32 a0 = (lane * 7u + trial) & 127u, a1 = (lane * 5u + 3u * trial + 64u) & 127u;
+      u32 b0 = a0, b1 = a1;
+      shuffle_apply(a0, a1, len, jl[0], lane);
+      shuffle_apply_par(b0, b1, len, jl[1], lane);
+      if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0) fail |= 8u;
+      wave_sync();
+    }
   }
   if (lane == 0) out[0] = fail;
 }

@@ -28,8 +28,10 @@ print("mean cycles per wave per phase (s_memtime ticks):")
 for k, v in zip(names, acc):
     print("  %-18s %9.0f  %5.1f%%" % (k, v, 100 * v / acc.sum()))
 sub = env.download("debug").astype(np.int64)
-sh = sub[:, 13] > sub[:, 12]
-print("  spawn breakdown (last step): nH+thr %.0f | bulk %.0f | apple scan %.0f | shuffle (of %d%% envs) %.0f | rest(shuffling envs) %.0f" % (
-    (sub[:, 10] - sub[:, 3]).mean(), (sub[:, 11] - sub[:, 10]).mean(), (sub[:, 12] - sub[:, 11]).mean(), 100 * sh.mean(),
-    (sub[sh, 13] - sub[sh, 12]).mean() if sh.any() else 0, (sub[sh, 4] - sub[sh, 13]).mean() if sh.any() else 0))
+d13 = sub[:, 13] - sub[:, 12]
+sh = (d13 > 0) & (d13 < 500000) & (sub[:, 10] > sub[:, 12]) & (sub[:, 10] < sub[:, 13]) & (sub[:, 4] > sub[:, 13]) & (sub[:, 4] - sub[:, 13] < 500000)
+print("  spawn breakdown (last step): bulk %.0f | apple scan %.0f | %d%% of envs shuffle: draws %.0f, apply %.0f, waste pick %.0f" % (
+    (sub[:, 11] - sub[:, 3]).mean(), (sub[:, 12] - sub[:, 11]).mean(), 100 * sh.mean(),
+    (sub[sh, 10] - sub[sh, 12]).mean() if sh.any() else 0, (sub[sh, 13] - sub[sh, 10]).mean() if sh.any() else 0,
+    (sub[sh, 4] - sub[sh, 13]).mean() if sh.any() else 0))
 print("  total %.0f ; p50/p90/max of last step %s" % (acc.sum(), np.percentile(tot, [50, 90, 100])))
