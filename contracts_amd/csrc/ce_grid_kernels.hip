@@ -266,7 +266,7 @@ template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) { return wrl(
 // find-first-set), the words before it are the rejected attempts.  Indices are walked in segments that
 // share a mask (2^k .. 2^(k+1)-1) so the masked words are computed once per segment; the hot inner loop
 // is ~16 instructions, all in registers; only the outermost loop may refill the cache (and call the twist).
-template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
+template <bool TWO, bool DRAWS_ONLY = false> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
   if (len < 2) return;
   u32 i = len - 1;
   u32 pos = r.pos, cbase = r.cbase, ccount = r.ccount, cache = r.cache;
@@ -322,9 +322,13 @@ template <bool TWO> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, 
           const u32 j = rdl(v, k);
           avail &= (~1ull << k);
           lastk = k;
-          const u32 vi = rdl(l0, i), vj = rdl(l0, j);
-          l0 = writelane<0>(vj, i, l0);
-          l0 = writelane<2>(vi, j, l0);
+          if (DRAWS_ONLY) {  // collect J[i] in lane i instead of swapping
+            l0 = writelane<0>(j, i, l0);
+          } else {
+            const u32 vi = rdl(l0, i), vj = rdl(l0, j);
+            l0 = writelane<0>(vj, i, l0);
+            l0 = writelane<2>(vi, j, l0);
+          }
           --i;
         } while (i >= lo);
       }
@@ -341,19 +345,23 @@ DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
-// The 118 draws of the waste-list shuffle, vectorised.  For one mask segment [lo, i0] and the cached words
-// k = off.. (v_k = word_k & mask), sequential rejection sampling accepts word k iff v_k <= i0 - a_k, where a_k
-// is the number of words accepted before k.  That self-referential predicate is solved by monotone bounds:
-// L (surely accepted) grows and U (possibly accepted) shrinks until they meet —
+// The draws of the waste-list shuffle.  Indices >= 32 are vectorised: for one mask segment [lo, i0] and the
+// cached words k = off.. (v_k = word_k & mask), sequential rejection sampling accepts word k iff
+// v_k <= i0 - a_k, where a_k is the number of words accepted before k.  That self-referential predicate is
+// solved by monotone bounds: L (surely accepted) and U (possibly accepted) are recomputed from each other's ranks
 //   L' = { v_k <= i0 - |U below k| },  U' = { v_k <= i0 - |L below k| }
-// (the lowest undecided lane always resolves, so it terminates; in practice 2-4 rounds per 64 words).
-// Accepted word with rank a is the draw for index i0 - a; draws are scattered to J[index] in LDS.
+// until they meet (the lowest undecided lane always resolves, so it terminates; 1-3 rounds per 64 words from the
+// start L = { v_k <= max(lo, i0 - (k - off)) }, U = { v_k <= i0 }).  The accepted word with rank a is the draw for
+// index i0 - a; draws are scattered to J[index] in LDS.  The short segments below 32 cost a whole vector round
+// each, so they take the one-draw-per-ballot walk instead (3 VALU per draw), collecting J[i] in lane i.
 // Returns with r advanced past every consumed word.
 DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
+#ifndef CE_VEC_MIN
+#define CE_VEC_MIN 8
+#endif
+  constexpr u32 kVecMin = CE_VEC_MIN;
   u32 i0 = len - 1;
-  const u64 lt = (1ull << lane) - 1ull;
-  (void)lt;
-  while (i0 >= 1) {
+  while (i0 >= kVecMin) {
     const u32 lo = 1u << (31 - __builtin_clz(i0));  // segment [lo, i0] shares mask 2*lo - 1
     const u32 mask = 2 * lo - 1;
     u32 off = r.pos - r.cbase;
@@ -361,33 +369,34 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
       rng_refill(r, lane);
       off = 0;
     }
-    const u64 A = r.cvalid & (~0ull << off);
-    const u32 v = r.cache & mask;
-    const bool inA = bit(A, lane);
-    u64 Lm = 0, Um = A;
-    for (;;) {
+    const u32 d = lane - off;  // rank among the unread cached words
+    const i32 v = d < r.ccount - off ? (i32)(r.cache & mask) : 0x7fffffff;  // read / missing words never accept
+    const i32 t0 = (i32)i0 - (i32)d;
+    u64 Lm = ballot(v <= (t0 > (i32)lo ? t0 : (i32)lo)), Um = ballot(v <= (i32)i0);
+    while (Lm != Um) {
       const i32 aL = (i32)rank_in(Lm, lane), aU = (i32)rank_in(Um, lane);
-      const u64 nL = ballot(inA && (i32)v <= (i32)i0 - aU);
-      const u64 nU = ballot(inA && (i32)v <= (i32)i0 - aL);
-      Lm = nL;
-      Um = nU;
-      if (nL == nU) break;
+      Lm = ballot(v <= (i32)i0 - aU);
+      Um = ballot(v <= (i32)i0 - aL);
     }
     const u32 a = rank_in(Lm, lane);
+    const u32 idx = i0 - a;
     const u32 need = i0 - lo + 1;  // draws left in this segment
     const u32 total = popc64(Lm);
     u32 used;
     if (total >= need) {  // the segment completes inside this batch: stop after its last accepted word
-      const u64 last = ballot(bit(Lm, lane) && a == need - 1);
+      const u64 last = ballot(a == need - 1) & Lm;
       used = need;
       r.pos = r.cbase + ctz64(last) + 1;
     } else {  // every cached word is consumed (accepted or rejected)
       used = total;
       r.pos = r.cbase + r.ccount;
     }
-    if (bit(Lm, lane) && a < used) J[i0 - a] = v;
+    if (v <= (i32)idx && a < used) J[idx] = (u32)v;
     i0 -= used;
   }
+  u32 JL = 0, dummy = 0;
+  shuffle_core<false, true>(r, JL, dummy, i0 + 1, lane);
+  if (lane >= 1 && lane <= i0) J[lane] = JL;
   wave_sync();
 }
 
@@ -1386,8 +1395,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds, env_first, env_end)) return;
-  typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+    const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
   const size_t ia = (size_t)E.e * n + lane;
 
