@@ -132,7 +132,10 @@ DEVINL u32 mt_mix(u32 a, u32 b, u32 c) {  // new = c ^ twist(a,b)
 
 // Regenerates the 624-word state with 64 lanes: three dependent chunks (0..226 read only old
 // words, 227..453 read chunk-1 results, 454..622 read chunk-2 results), then word 623.
-__device__ __noinline__ void mt_twist(u32* mt, u32 lane) {
+// (noinline: it is reached from every place that can run the stream dry.  The state pointer is passed in the
+// LDS address space so the body is ds_read / ds_write with 32-bit addresses instead of flat accesses.)
+typedef __attribute__((address_space(3))) u32 lds_u32;
+__device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) {
   wave_sync();
   // chunk 1: words 0..226 (4 lane rounds) read only old words -> all reads first, then all writes
   {
@@ -185,6 +188,8 @@ __device__ __noinline__ void mt_twist(u32* mt, u32 lane) {
   if (lane == 0) mt[623] = mt_mix(mt[623], mt[0], mt[396]);
   wave_sync();
 }
+
+DEVINL void mt_twist(u32* mt, u32 lane) { mt_twist_lds((lds_u32*)mt, lane); }
 
 struct Rng {
   u32* mt;     // LDS, 624 words
@@ -266,7 +271,8 @@ template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) { return wrl(
 // find-first-set), the words before it are the rejected attempts.  Indices are walked in segments that
 // share a mask (2^k .. 2^(k+1)-1) so the masked words are computed once per segment; the hot inner loop
 // is ~16 instructions, all in registers; only the outermost loop may refill the cache (and call the twist).
-template <bool TWO, bool DRAWS_ONLY = false> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
+// MODE 0: swap the list; 1: collect the draws (J[i] in lane i of L0); 2: only consume the stream words
+template <bool TWO, int MODE = 0> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
   if (len < 2) return;
   u32 i = len - 1;
   u32 pos = r.pos, cbase = r.cbase, ccount = r.ccount, cache = r.cache;
@@ -322,7 +328,8 @@ template <bool TWO, bool DRAWS_ONLY = false> DEVINL void shuffle_core(Rng& r, u3
           const u32 j = rdl(v, k);
           avail &= (~1ull << k);
           lastk = k;
-          if (DRAWS_ONLY) {  // collect J[i] in lane i instead of swapping
+          if (MODE == 2) {
+          } else if (MODE == 1) {  // collect J[i] in lane i instead of swapping
             l0 = writelane<0>(j, i, l0);
           } else {
             const u32 vi = rdl(l0, i), vj = rdl(l0, j);
@@ -395,7 +402,7 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
     i0 -= used;
   }
   u32 JL = 0, dummy = 0;
-  shuffle_core<false, true>(r, JL, dummy, i0 + 1, lane);
+  shuffle_core<false, 1>(r, JL, dummy, i0 + 1, lane);
   if (lane >= 1 && lane <= i0) J[lane] = JL;
   wave_sync();
 }
@@ -742,6 +749,23 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
   const u64 M = ballot(mover);
   if (M == 0) return;
   const u32 m = popc64(M);
+  // Interaction-free steps (the common case): no two movers share a target and no mover's target is another
+  // agent's cell.  Then phase B has nothing to arbitrate and every pass-C entry either finds its cell empty
+  // (targets are distinct from every live position) or is the agent itself (stay / wall), so the outcome is
+  // P <- target whatever the shuffled order: only the stream words of the shuffle are consumed.
+  if (E.n <= 8) {  // one (a, b) agent pair per lane
+    const u32 a = lane >> 3, b = lane & 7u;
+    const u32 ta = bperm(TGT0, a), pb = bperm(E.P, b), tb = bperm(TGT0, b);
+    const u32 mlo = (u32)M;
+    const bool ma = ((mlo >> a) & 1u) != 0, mb = ((mlo >> b) & 1u) != 0;
+    const bool clash = ma && a != b && b < E.n && (ta == pb || (mb && ta == tb));
+    if (ballot(clash) == 0) {
+      u32 d0 = 0, d1 = 0;
+      shuffle_core<false, 2>(E.rng, d0, d1, m, lane);
+      if (mover) E.P = TGT0;
+      return;
+    }
+  }
   // slot list in agent order, then np.random.shuffle of the (agent, slot) pairs
   u32 SA = 0;
   {
@@ -1488,8 +1512,30 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     rew = (double)base_rew - (dis + adv) / (double)(n - 1);
   }
 
-  // ---------------- infos, metrics, feature obs ----------------
-  // metric accumulators: loads are issued here and consumed after the feature pass (latency hidden)
+  CE_STAMP(5);
+  // ---------------- feature obs, infos, metrics ----------------
+#ifndef CE_ABLATE_FEATURES
+  const u32 feat8 = compute_features(E, p, cleaned);
+#else
+  const u32 feat8 = 0;
+#endif
+  // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
+  double transfers_total = 0.0;
+  if (p.contract != CE_CONTRACT_NONE) {
+    double tr;
+    if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;  // contract_list.py:26
+    else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
+    double total = 0.0;
+    const double share = tr / (double)(n - 1);  // t_i / (len(acts) - 1), one division per agent
+    for (u32 i = 0; i < n; ++i) {
+      const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
+      if (lane == i) rew -= ti;
+      else rew += qi;
+      total += ti;
+    }
+    transfers_total = total;
+  }
+  // metric accumulators (loaded after the feature pass and the transfer arithmetic: holding them across either costs an occupancy step)
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
   int64_t* mi = p.int_metrics + (size_t)E.e * nmi;
   double* mf = p.f64_metrics + (size_t)E.e * nmf;
@@ -1499,12 +1545,6 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   double f_sr = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, la)], f_str = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, la)];
   long long g_m = lane < 4 ? mi[lane < 4 ? lane : 0] : 0;  // lane k < 4 holds global metric k
   double f_transfers = mf[CE_MF_TRANSFERS];
-  CE_STAMP(5);
-#ifndef CE_ABLATE_FEATURES
-  const u32 feat8 = compute_features(E, p, cleaned);
-#else
-  const u32 feat8 = 0;
-#endif
   CE_STAMP(6);
   {
     u32 sum_eaten = 0, sum_clean = 0, sum_close = 0;
@@ -1524,20 +1564,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     m_sr += base_rew;
     m_str += (long long)(t - 1) * base_rew;
   }
-  // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   if (p.contract != CE_CONTRACT_NONE) {
-    double tr;
-    if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;  // contract_list.py:26
-    else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
-    double total = 0.0;
-    const double share = tr / (double)(n - 1);  // t_i / (len(acts) - 1), one division per agent
-    for (u32 i = 0; i < n; ++i) {
-      const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
-      if (lane == i) rew -= ti;
-      else rew += qi;
-      total += ti;
-    }
-    f_transfers += total;
+    f_transfers += transfers_total;
     f_sr += rew;
     f_str += (double)(t - 1) * rew;
   }
