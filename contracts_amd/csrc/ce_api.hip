@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#define CE_PLAIN_PARAM_POINTERS 1  // host side: ordinary pointers in the parameter blocks
 #include "ce_device.h"
 
 using namespace ce;

@@ -52,31 +52,40 @@ struct GridTables {
   uint32_t close_off[24];      // harvest: 21 padded-index offsets with j^2+k^2 <= 5 (as int32)
 };
 
+// Device-side view of the parameter blocks: the pointers are typed into the global address space so that every
+// access through them is a global_load / global_store with an SGPR base (no flat addressing, no 64-bit VALU
+// address arithmetic).  Host code (CE_PLAIN_PARAM_POINTERS) sees the same layout with ordinary pointers.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CE_PLAIN_PARAM_POINTERS)
+#define CE_GPTR(T) __attribute__((address_space(1))) T*
+#else
+#define CE_GPTR(T) T*
+#endif
+
 struct GridParams {
   // persistent state
-  uint8_t* grid;
-  uint8_t* agents;
-  uint8_t* spawn_perm;
-  uint8_t* waste_perm;
-  uint32_t* rng;
-  int32_t* timestep;
-  double* theta;
+  CE_GPTR(uint8_t) grid;
+  CE_GPTR(uint8_t) agents;
+  CE_GPTR(uint8_t) spawn_perm;
+  CE_GPTR(uint8_t) waste_perm;
+  CE_GPTR(uint32_t) rng;
+  CE_GPTR(int32_t) timestep;
+  CE_GPTR(double) theta;
   // outputs
-  uint8_t* obs;
-  int32_t* base_reward;
-  double* reward;
-  uint8_t* done;
-  uint8_t* info;
-  int16_t* features;
-  int64_t* int_metrics;
-  double* f64_metrics;
-  int64_t* final_int_metrics;
-  double* final_f64_metrics;
-  uint32_t* error_flags;
-  unsigned long long* debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
+  CE_GPTR(uint8_t) obs;
+  CE_GPTR(int32_t) base_reward;
+  CE_GPTR(double) reward;
+  CE_GPTR(uint8_t) done;
+  CE_GPTR(uint8_t) info;
+  CE_GPTR(int16_t) features;
+  CE_GPTR(int64_t) int_metrics;
+  CE_GPTR(double) f64_metrics;
+  CE_GPTR(int64_t) final_int_metrics;
+  CE_GPTR(double) final_f64_metrics;
+  CE_GPTR(uint32_t) error_flags;
+  CE_GPTR(unsigned long long) debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
   // inputs
-  const uint8_t* actions;  // [E][n]
-  const uint8_t* mask;     // [E] or null (seed/reset)
+  CE_GPTR(const uint8_t) actions;  // [E][n]
+  CE_GPTR(const uint8_t) mask;     // [E] or null (seed/reset)
   uint32_t E, n, horizon, contract, flags, obs_env_stride, num_features;
   uint32_t replay_constructor;
   uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
@@ -84,23 +93,23 @@ struct GridParams {
 };
 
 struct SdParams {
-  double* sd_state;
-  uint32_t* rng;
-  double* theta;
-  double* obs_f64;
-  int32_t* base_reward;
-  double* reward;
-  uint8_t* done;
-  uint8_t* done_agents;
-  uint8_t* info;
-  double* f64_metrics;
-  double* final_f64_metrics;
-  int64_t* int_metrics;
-  int64_t* final_int_metrics;
-  uint32_t* error_flags;
-  const float* actions;
-  const uint8_t* active;
-  const uint8_t* mask;
+  CE_GPTR(double) sd_state;
+  CE_GPTR(uint32_t) rng;
+  CE_GPTR(double) theta;
+  CE_GPTR(double) obs_f64;
+  CE_GPTR(int32_t) base_reward;
+  CE_GPTR(double) reward;
+  CE_GPTR(uint8_t) done;
+  CE_GPTR(uint8_t) done_agents;
+  CE_GPTR(uint8_t) info;
+  CE_GPTR(double) f64_metrics;
+  CE_GPTR(double) final_f64_metrics;
+  CE_GPTR(int64_t) int_metrics;
+  CE_GPTR(int64_t) final_int_metrics;
+  CE_GPTR(uint32_t) error_flags;
+  CE_GPTR(const float) actions;
+  CE_GPTR(const uint8_t) active;
+  CE_GPTR(const uint8_t) mask;
   uint32_t E, n, contract, flags, replay_constructor;
   uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
   double contract_low, contract_high, null_prob, low_bound, high_bound, start_vel, start_vel_ambulance;
