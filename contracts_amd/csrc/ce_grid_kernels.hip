@@ -23,6 +23,10 @@
 
 #include "ce_device.h"
 
+// base[idx] for a wave-uniform global base and a per-lane 32-bit index: the byte offset is formed in 32 bits,
+// which is what lets the access take the SGPR-base + VGPR-offset form (a 64-bit scaled index does not).
+#define GAT(base, idx) (*(decltype(base))((CE_GPTR(char))(base) + (u32)((u32)(idx) * (u32)sizeof(*(base)))))
+
 namespace ce {
 
 typedef uint32_t u32;
@@ -635,7 +639,7 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
 
 template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
   u32 w = 0;
-  if (E.is_agent) w = ((const u32*)p.agents)[(size_t)E.e * E.n + E.lane];
+  if (E.is_agent) w = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, E.lane);
   E.P = pad_of<KIND>(w & 0xff, (w >> 8) & 0xff);
   E.O = (w >> 16) & 3;
   E.RW = 0;
@@ -644,24 +648,24 @@ template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
 template <int KIND> DEVINL void store_agents(Env<KIND>& E, const GridParams& p) {
   if (E.is_agent) {
     u32 w = row_of<KIND>(E.P) | (col_of<KIND>(E.P) << 8) | (E.O << 16);
-    ((u32*)p.agents)[(size_t)E.e * E.n + E.lane] = w;
+    GAT((CE_GPTR(u32))p.agents + (size_t)E.e * E.n, E.lane) = w;
   }
 }
 template <int KIND> DEVINL void load_perms(Env<KIND>& E, const GridParams& p) {
-  E.SP = E.lane < 20 ? p.spawn_perm[(size_t)E.e * 20 + E.lane] : 0;
+  E.SP = E.lane < 20 ? GAT(p.spawn_perm + (size_t)E.e * 20, E.lane) : 0;
   E.WP0 = E.WP1 = 0;
   if (KIND == CE_KIND_CLEANUP) {
-    const uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
-    E.WP0 = wp[E.lane];
-    E.WP1 = E.lane + 64 < 119 ? wp[E.lane + 64] : 0;
+    const auto wp = p.waste_perm + (size_t)E.e * 119;
+    E.WP0 = GAT(wp, E.lane);
+    E.WP1 = E.lane + 64 < 119 ? GAT(wp, E.lane + 64) : 0;
   }
 }
 template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, bool spawn_too) {
-  if (spawn_too && E.lane < 20) p.spawn_perm[(size_t)E.e * 20 + E.lane] = (uint8_t)E.SP;
+  if (spawn_too && E.lane < 20) GAT(p.spawn_perm + (size_t)E.e * 20, E.lane) = (uint8_t)E.SP;
   if (KIND == CE_KIND_CLEANUP) {
-    uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
-    wp[E.lane] = (uint8_t)E.WP0;
-    if (E.lane + 64 < 119) wp[E.lane + 64] = (uint8_t)E.WP1;
+    const auto wp = p.waste_perm + (size_t)E.e * 119;
+    GAT(wp, E.lane) = (uint8_t)E.WP0;
+    if (E.lane + 64 < 119) GAT(wp, E.lane + 64) = (uint8_t)E.WP1;
   }
 }
 
@@ -682,13 +686,13 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
 #pragma unroll
   for (int r = 0; r < GROUNDS; ++r) gw[r] = lane + 64 * r < (u32)G::PCELLS / 4 ? gsrc[lane + 64 * r] : 0u;
   u32 aw = 0;
-  if (E.is_agent) aw = ((const u32*)p.agents)[(size_t)E.e * E.n + lane];
-  E.SP = lane < 20 ? p.spawn_perm[(size_t)E.e * 20 + lane] : 0;
+  if (E.is_agent) aw = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, lane);
+  E.SP = lane < 20 ? GAT(p.spawn_perm + (size_t)E.e * 20, lane) : 0;
   E.WP0 = E.WP1 = 0;
   if (KIND == CE_KIND_CLEANUP) {
-    const uint8_t* wp = p.waste_perm + (size_t)E.e * 119;
-    E.WP0 = wp[lane];
-    E.WP1 = lane + 64 < 119 ? wp[lane + 64] : 0;
+    const auto wp = p.waste_perm + (size_t)E.e * 119;
+    E.WP0 = GAT(wp, lane);
+    E.WP1 = lane + 64 < 119 ? GAT(wp, lane + 64) : 0;
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -1204,9 +1208,9 @@ DEVINL u32 group_min_u32(u32 v, u32 sh) {
 }
 
 // two feature values as one dword when the row is dword aligned (num_features even), else two shorts
-DEVINL void store_feat2(int16_t* f, u32 idx, u32 lo, u32 hi, bool aligned) {
+template <class P> DEVINL void store_feat2(P f, u32 idx, u32 lo, u32 hi, bool aligned) {
   if (aligned) {
-    *reinterpret_cast<u32*>(f + idx) = (lo & 0xffffu) | hi << 16;
+    *(CE_GPTR(u32))(f + idx) = (lo & 0xffffu) | hi << 16;
   } else {
     f[idx] = (int16_t)lo;
     f[idx + 1] = (int16_t)hi;
@@ -1217,9 +1221,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
-  const size_t ia = (size_t)E.e * n + lane;
   uint8_t* pm = E.L->pmap;
   const u32 nf = p.num_features;
+  const auto feat_env = p.features + (size_t)E.e * n * nf;  // wave-uniform base, 32-bit lane offsets below
   const bool al = (nf & 1u) == 0;  // feature rows dword aligned
   const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
   const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
@@ -1280,7 +1284,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (ka == 0xffffffffu) ka = 0;  // [0, 0] sentinel when there is none
   if (kw == 0xffffffffu) kw = 0;
   if (gl == 0 && ga < n) {  // the group's first lane writes agent ga's closest-apple / closest-waste features
-    int16_t* f = p.features + ((size_t)E.e * n + ga) * nf;
+    auto f = feat_env + __umul24(ga, nf);
     store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
     if (KIND == CE_KIND_CLEANUP) store_feat2(f, 8, (kw >> 8) & 0xffu, kw & 0xffu, al);
   }
@@ -1293,12 +1297,12 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       if (lane == a) close_now = cnt;
     }
   }
-  int16_t* f = p.features + ia * nf;
+  auto f = feat_env + __umul24(E.is_agent ? lane : 0u, nf);
   if (KIND == CE_KIND_CLEANUP) {
     if (al) {  // n even: the cleaned vector as n/2 dwords
       for (u32 b = 0; b < n; b += 2) {
         const u32 w = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
-        if (E.is_agent) *reinterpret_cast<u32*>(f + 12 + b) = w;
+        if (E.is_agent) *(CE_GPTR(u32))(f + 12 + b) = w;
       }
     } else {
       for (u32 b = 0; b < n; ++b) {
@@ -1315,7 +1319,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       store_feat2(f, 10, napples, nwaste, al);
     } else {
       store_feat2(f, 8, close_now, napples, al);
-      for (u32 b = 0; b < n; ++b) *reinterpret_cast<u32*>(f + 10 + 2 * b) = 0u;  // num_features = 10 + 2n: always aligned
+      for (u32 b = 0; b < n; ++b) *(CE_GPTR(u32))(f + 10 + 2 * b) = 0u;  // num_features = 10 + 2n: always aligned
     }
   }
   return close_now;
@@ -1376,11 +1380,11 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
 
 template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParams& p) {
   if (E.is_agent) {
-    const size_t ia = (size_t)E.e * E.n + E.lane;
-    p.base_reward[ia] = 0;
-    p.reward[ia] = 0.0;
-    p.info[ia * 2] = 0;
-    p.info[ia * 2 + 1] = 0;
+    const size_t ea = (size_t)E.e * E.n;
+    (p.base_reward + ea)[E.lane] = 0;
+    (p.reward + ea)[E.lane] = 0.0;
+    (p.info + 2 * ea)[2 * E.lane] = 0;
+    (p.info + 2 * ea)[2 * E.lane + 1] = 0;
   }
 }
 
@@ -1421,9 +1425,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   if (!env_begin(E, p, lds, env_first, env_end)) return;
     const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
-  const size_t ia = (size_t)E.e * n + lane;
+  const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
 
-  u32 ACT = E.is_agent ? (u32)call_actions[ia] : 4u;
+  u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + ea, lane) : 4u;
   const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
   if (ballot(E.is_agent && ACT > max_action) != 0) {  // KeyError in the reference (Agent.py:174,213)
     if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
@@ -1537,13 +1541,13 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
   // metric accumulators (loaded after the feature pass and the transfer arithmetic: holding them across either costs an occupancy step)
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
-  int64_t* mi = p.int_metrics + (size_t)E.e * nmi;
-  double* mf = p.f64_metrics + (size_t)E.e * nmf;
+  const auto mi = p.int_metrics + (size_t)E.e * nmi;
+  const auto mf = p.f64_metrics + (size_t)E.e * nmf;
   const u32 la = E.is_agent ? lane : 0;
-  long long m_a = mi[CE_MI_AGENT(n, CE_MIA_A, la)], m_b = mi[CE_MI_AGENT(n, CE_MIA_B, la)];
-  long long m_sr = mi[CE_MI_AGENT(n, CE_MIA_SUM_R, la)], m_str = mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, la)];
-  double f_sr = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, la)], f_str = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, la)];
-  long long g_m = lane < 4 ? mi[lane < 4 ? lane : 0] : 0;  // lane k < 4 holds global metric k
+  long long m_a = GAT(mi, CE_MI_AGENT(n, CE_MIA_A, la)), m_b = GAT(mi, CE_MI_AGENT(n, CE_MIA_B, la));
+  long long m_sr = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, la)), m_str = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, la));
+  double f_sr = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, la)), f_str = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, la));
+  long long g_m = lane < 4 ? GAT(mi, lane < 4 ? lane : 0) : 0;  // lane k < 4 holds global metric k
   double f_transfers = mf[CE_MF_TRANSFERS];
   CE_STAMP(6);
   {
@@ -1571,21 +1575,21 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
   const bool done = t == p.horizon;
   // running metrics back to HBM
-  if (lane < 4) mi[lane] = g_m;
+  if (lane < 4) GAT(mi, lane) = g_m;
   if (lane == 0) mf[CE_MF_TRANSFERS] = f_transfers;
   if (E.is_agent) {
-    mi[CE_MI_AGENT(n, CE_MIA_A, lane)] = m_a;
-    mi[CE_MI_AGENT(n, CE_MIA_B, lane)] = m_b;
-    mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] = m_sr;
-    mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] = m_str;
-    mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] = f_sr;
-    mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] = f_str;
+    GAT(mi, CE_MI_AGENT(n, CE_MIA_A, lane)) = m_a;
+    GAT(mi, CE_MI_AGENT(n, CE_MIA_B, lane)) = m_b;
+    GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) = m_sr;
+    GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) = m_str;
+    GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) = f_sr;
+    GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) = f_str;
   }
   if (E.is_agent) {
-    p.base_reward[ia] = base_rew;
-    p.reward[ia] = rew;
-    p.info[ia * 2] = (uint8_t)eaten;
-    p.info[ia * 2 + 1] = (uint8_t)(KIND == CE_KIND_CLEANUP ? cleaned : eaten_close);
+    GAT(p.base_reward + ea, lane) = base_rew;
+    GAT(p.reward + ea, lane) = rew;
+    const u32 info2 = eaten | (KIND == CE_KIND_CLEANUP ? cleaned : eaten_close) << 8;  // info[a][0..1] as one short
+    *(CE_GPTR(uint16_t))(p.info + 2 * ea + 2 * lane) = (uint16_t)info2;
   }
 
   bool did_reset = false;
