@@ -107,6 +107,33 @@ DEVINL u32 wave_min_u32(u32 v) {
     __builtin_amdgcn_sched_barrier(0);                                                 \
     if (lane == 0 && E.dbg) E.dbg[(k)] = t_;                                           \
   } while (0)
+#elif defined(CE_TRUNCATE)
+// Profiling builds (-DCE_TRUNCATE=k, tools/valu_profile.py): the step kernel ends at phase boundary k, so the
+// instruction counters of consecutive builds difference into per-phase counts.  Never shipped.
+// (everything the remaining phases would consume is folded into one store, so that nothing before the cut is dead)
+#define CE_TRUNC_SINK()                                                                                         \
+  do {                                                                                                          \
+    const u32 sink_ = E.P ^ E.O ^ (u32)E.RW ^ E.SP ^ E.WP0 ^ E.WP1 ^ E.rng.pos ^ E.rng.cache ^                  \
+                      ((const u32*)E.L->pmap)[E.lane] ^ ((const u32*)E.L->pmap)[E.lane + 248] ^ E.L->mt[E.lane]; \
+    E.dbg[E.lane & 15] = sink_;                                                                                 \
+  } while (0)
+#define CE_STAMP(k)               \
+  do {                            \
+    if (CE_TRUNCATE == (k)) {     \
+      CE_TRUNC_SINK();            \
+      return;                     \
+    }                             \
+  } while (0)
+#define CE_SUBSTAMP(k)            \
+  do {                            \
+    if (CE_TRUNCATE == (k)) {     \
+      CE_TRUNC_SINK();            \
+      return;                     \
+    }                             \
+  } while (0)
+#define CE_REALSTAMP(k) \
+  do {                  \
+  } while (0)
 #else
 #define CE_STAMP(k) \
   do {              \
@@ -1340,8 +1367,8 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
-#ifdef CE_PHASE_STAMPS
-  E.dbg = p.debug ? p.debug + (size_t)E.e * 16 : nullptr;
+#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
+  E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
 #else
   E.dbg = nullptr;
 #endif
@@ -1465,9 +1492,13 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
   {  // consume in agent order: the first agent on the cell gets the apple
     bool first = true;
-    for (u32 b = 0; b < n; ++b) {
-      const u32 pb = rdl(E.P, b);
-      if (lane > b && E.P == pb) first = false;
+    const u64 onm = ballot(onA);
+    if (onm & (onm - 1)) {  // two or more agents on apples: only then can a cell be shared
+      for (u64 it = onm; it; it &= it - 1) {
+        const u32 b = ctz64(it);
+        const u32 pb = rdl(E.P, b);
+        if (lane > b && E.P == pb) first = false;
+      }
     }
     if (onA && first) E.RW += 1;
     wave_sync();
@@ -1494,6 +1525,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
   CE_STAMP(3);
   custom_map_update(E);
+#ifdef CE_TRUNCATE
+  if (CE_TRUNCATE >= 10 && CE_TRUNCATE <= 13) return;
+#endif
   CE_STAMP(4);
 
   // ---------------- rewards ----------------
@@ -1531,7 +1565,10 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
     double total = 0.0;
     const double share = tr / (double)(n - 1);  // t_i / (len(acts) - 1), one division per agent
-    for (u32 i = 0; i < n; ++i) {
+    // Agents with a zero transfer are skipped: x - (+-0) and x + (+-0) leave every x but -0.0 unchanged, and
+    // neither a reward (an integer, or an integer minus a positive penalty) nor the running total is ever -0.0.
+    for (u64 it = ballot(tr != 0.0); it; it &= it - 1) {
+      const u32 i = ctz64(it);
       const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
       if (lane == i) rew -= ti;
       else rew += qi;
@@ -1551,14 +1588,12 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   double f_transfers = mf[CE_MF_TRANSFERS];
   CE_STAMP(6);
   {
-    u32 sum_eaten = 0, sum_clean = 0, sum_close = 0;
+    // eaten / eaten_close are 0/1 flags; cleaned and the base rewards are zero for most agents
+    const u32 sum_eaten = popc64(ballot(eaten != 0)), sum_close = popc64(ballot(eaten_close != 0));
+    u32 sum_clean = 0;
     i32 sum_rew = 0;
-    for (u32 b = 0; b < n; ++b) {
-      sum_eaten += rdl(eaten, b);
-      sum_clean += rdl(cleaned, b);
-      sum_close += rdl(eaten_close, b);
-      sum_rew += shfl_i32(base_rew, b);
-    }
+    for (u64 it = ballot(cleaned != 0); it; it &= it - 1) sum_clean += rdl(cleaned, ctz64(it));
+    for (u64 it = ballot(E.is_agent && base_rew != 0); it; it &= it - 1) sum_rew += shfl_i32(base_rew, ctz64(it));
     if (lane == CE_MI_TOTAL_APPLES_EATEN) g_m += sum_eaten;
     if (lane == CE_MI_RAW_ENV_REWARDS) g_m += sum_rew;
     if (lane == CE_MI_DIRT_CLEANED && KIND == CE_KIND_CLEANUP) g_m += sum_clean;

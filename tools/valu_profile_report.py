@@ -1,0 +1,22 @@
+import csv, glob, sys
+root = sys.argv[1]
+order = ["1", "2", "3", "11", "12", "10", "13", "4", "5", "6", "7", "8", "full"]
+names = {"1": "load", "2": "moves", "3": "consume + n-shuffle + beams", "11": "spawn: thresholds + bulk rng (+twist)", "12": "spawn: apple scan",
+         "10": "spawn: t* + shuffle draws", "13": "spawn: shuffle apply", "4": "spawn: waste pick + writes", "5": "rewards",
+         "6": "features + contract + metric loads", "7": "metric update/stores + done", "8": "state stores", "full": "obs"}
+def load(k):
+    f = glob.glob("%s/%s/**/*counter_collection.csv" % (root, k), recursive=True)
+    acc = {}
+    for row in csv.DictReader(open(f[0])):
+        if "k_grid_step" in row["Kernel_Name"]:
+            s, c = acc.get(row["Counter_Name"], (0.0, 0)); acc[row["Counter_Name"]] = (s + float(row["Counter_Value"]), c + 1)
+    w = acc["SQ_WAVES"][0] / acc["SQ_WAVES"][1]
+    return {c: s / k2 / w for c, (s, k2) in acc.items()}
+prev = {}
+cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
+print("%-42s" % "phase (per wave)" + "".join("%12s" % c.replace("SQ_", "").replace("INSTS_", "") for c in cols))
+for k in order:
+    cur = load(k)
+    print("%-42s" % names[k] + "".join("%12.1f" % (cur.get(c, 0) - prev.get(c, 0)) for c in cols))
+    prev = cur
+print("%-42s" % "total" + "".join("%12.1f" % prev.get(c, 0) for c in cols))
