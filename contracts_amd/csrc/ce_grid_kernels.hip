@@ -231,6 +231,16 @@ struct Rng {
   u64 cvalid;  // lanes < ccount
 };
 
+// The stream position / cache window are wave-uniform by construction, but after inlined helpers with several
+// exits merge, the compiler's divergence analysis can lose that and turn every loop over the stream into an
+// exec-masked vector loop.  Re-asserting uniformity at the entry of those loops costs five v_readfirstlane.
+DEVINL void rng_assert_uniform(Rng& r) {
+  r.pos = rfl(r.pos);
+  r.cbase = rfl(r.cbase);
+  r.ccount = rfl(r.ccount);
+  r.cvalid = ((u64)rfl((u32)(r.cvalid >> 32)) << 32) | rfl((u32)r.cvalid);
+}
+
 // make the per-lane cache cover stream words [pos, pos + ccount)
 DEVINL void rng_refill(Rng& r, u32 lane) {
   if (r.pos >= (u32)kMtN) {
@@ -259,6 +269,7 @@ DEVINL u32 rng_next(Rng& r, u32 lane) {
 // go to U (the doubles that are compared against a real threshold); for every double d the byte S[d] records
 // "u_d < 0.5", i.e. bit 31 of its first word is clear (X < 2^52 <=> (a >> 5) < 2^26 <=> a < 2^31).
 DEVINL void rng_bulk(Rng& r, u32* U, uint8_t* S, u32 count, u32 keep, bool want_s, u32 lane) {
+  rng_assert_uniform(r);
   u32 done = 0;
   while (done < count) {
     if (r.pos >= (u32)kMtN) {
@@ -305,7 +316,8 @@ template <int PAD> DEVINL u32 writelane(u32 val, u32 sel, u32 old) { return wrl(
 // MODE 0: swap the list; 1: collect the draws (J[i] in lane i of L0); 2: only consume the stream words
 template <bool TWO, int MODE = 0> DEVINL void shuffle_core(Rng& r, u32& L0, u32& L1, u32 len, u32 lane) {
   if (len < 2) return;
-  u32 i = len - 1;
+  rng_assert_uniform(r);
+  u32 i = rfl(len) - 1;
   u32 pos = r.pos, cbase = r.cbase, ccount = r.ccount, cache = r.cache;
   u64 cvalid = r.cvalid;
   u32 l0 = L0, l1 = L1;
@@ -398,6 +410,7 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
 #define CE_VEC_MIN 8
 #endif
   constexpr u32 kVecMin = CE_VEC_MIN;
+  rng_assert_uniform(r);
   u32 i0 = len - 1;
   while (i0 >= kVecMin) {
     const u32 lo = 1u << (31 - __builtin_clz(i0));  // segment [lo, i0] shares mask 2*lo - 1
