@@ -91,6 +91,7 @@ template <int KIND> static void build_tables(GridTables& t) {
       }
       t.apple_thresh[nH] = (uint64_t)std::ceil(std::ldexp(p_apple, 53));
       t.waste_on[nH] = p_waste != 0;
+      if (p_waste != 0) t.apple_thresh[nH] |= kWasteOnBit;  // one scalar load yields both (see ce_device.h)
     }
   } else {
     const double spawn_prob[4] = {0, 0.005, 0.02, 0.05};  // SPAWN_PROB harvest_new.py:34

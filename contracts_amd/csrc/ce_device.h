@@ -42,12 +42,17 @@ template <> struct Geo<CE_KIND_HARVEST> {
 
 // Static per-family tables (host-built from the ASCII maps, uploaded to __constant__).
 // Cell entries are packed:  padded_index (11 bits) | col << 16 | row << 24  (one byte per coordinate).
+// Bit 63 of a cleanup apple_thresh entry: the waste spawn probability is non-zero at that waste count.  The flag
+// rides in the threshold word because a second, byte-indexed scalar table made the compiler fold both accesses
+// onto a common base + nH, and s_load drops the low two bits of a misaligned base.
+constexpr uint64_t kWasteOnBit = 1ull << 63;
+
 struct GridTables {
   uint32_t apple[160];         // apple spawn cells, row-major (cleanup 'B', harvest 'A')
   uint32_t waste[128];         // cleanup waste cells 'H' u 'R', row-major
   uint32_t spawn[20];          // 'P' cells; cleanup: entries 10..19 repeat 0..9 (cleanup_new.py:114-115)
-  uint64_t apple_thresh[120];  // cleanup: by #H on the map -> ceil(p_apple * 2^53); harvest: [0..3] by neighbour count
-  uint8_t waste_on[120];       // cleanup: by #H -> waste spawn probability is non-zero
+  uint64_t apple_thresh[120];  // cleanup: by #H on the map -> ceil(p_apple * 2^53) | kWasteOnBit; harvest: [0..3] by neighbour count
+  uint8_t waste_on[120];       // cleanup: by #H -> waste spawn probability is non-zero (host-side copy of the flag bit)
   uint8_t base_pmap[1568];     // padded reset-time map (walls + H/R/S, or harvest apples)
   uint32_t close_off[24];      // harvest: 21 padded-index offsets with j^2+k^2 <= 5 (as int32)
 };

@@ -951,69 +951,168 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean)
 // ----------------------------------------------------------------------------------------
 // spawn models
 // ----------------------------------------------------------------------------------------
+// The rand(k) call of the spawn models consumes RANDW stream words every step, but only a few are ever looked at:
+// the first word of the double of each eligible apple cell (the 27 high bits decide x < threshold except on an
+// exact tie, which falls back to the second word), and — for the waste walk — only whether a double is < 0.5,
+// i.e. the sign of its tempered first word, which is the parity of four raw state bits (temper is GF(2)-linear:
+// bit31(temper(w)) = w31 ^ w27 ^ w24 ^ w16).  So the window [pos, pos + RANDW) is never materialised: each lane
+// fetches its own words straight from the MT state, before the in-place twist for the part of the window that
+// lies in the current generation and after it for the rest.
+struct StreamWindow {
+  u32* mt;
+  u32 pos, alen;  // window start in the current generation; words of the window that lie in it
+};
+template <int RANDW> DEVINL StreamWindow window_open(Rng& r, u32 lane) {
+  rng_assert_uniform(r);
+  if (r.pos >= (u32)kMtN) {
+    mt_twist(r.mt, lane);
+    r.pos = 0;
+  }
+  StreamWindow w;
+  w.mt = r.mt;
+  w.pos = r.pos;
+  const u32 left = (u32)kMtN - r.pos;
+  w.alen = left < (u32)RANDW ? left : (u32)RANDW;
+  return w;
+}
+DEVINL u32 window_read_old(const StreamWindow& w, bool need, u32 s) { return (need && s < w.alen) ? w.mt[w.pos + s] : 0u; }
+DEVINL u32 window_read_new(const StreamWindow& w, bool need, u32 s, u32 old) { return (need && s >= w.alen) ? w.mt[s - w.alen] : old; }
+template <int RANDW> DEVINL void window_close(Rng& r, const StreamWindow& w) {
+  r.pos = w.alen < (u32)RANDW ? (u32)RANDW - w.alen : w.pos + (u32)RANDW;
+  r.ccount = 0;
+}
+// x < thr for the 53-bit X = (a >> 5) << 26 | (b >> 6) of a double, from the tempered first word alone unless tied
+DEVINL bool below_hi(u32 a_tempered, u64 thr, bool& tie) {
+  const u32 a27 = a_tempered >> 5, hi = (u32)(thr >> 26);
+  tie = a27 == hi;
+  return a27 < hi;
+}
+DEVINL bool below_lo(u32 b_raw, u64 thr) { return (mt_temper(b_raw) >> 6) < ((u32)thr & 0x3ffffffu); }
+
 template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane;
   const u64 lt = (1ull << lane) - 1ull;
   uint8_t* pm = E.L->pmap;
+  constexpr int AR = (G::NAPPLE + 63) / 64;  // lane rounds over the apple cells
+  // eligible apple cells (apple cell, no apple, no agent: bit 7) and the index of the double each one is handed
+  bool elig[AR];
+  u32 sa[AR];
+  u64 thrA[AR];
+  u32 rbase = 0;
+  u32 nH = 0;
+  bool waste_on = false;
   if (KIND == CE_KIND_CLEANUP) {
     // compute_probabilities: #H on the map -> host-precomputed 53-bit threshold
-    u32 nH = 0;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
       nH += popc64(ballot(v && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE));
     }
-    const u64 thr = T.apple_thresh[nH];
-    const bool waste_on = T.waste_on[nH] != 0;
-    rng_bulk(E.rng, E.L->U, E.L->S, (u32)G::RANDW, (u32)G::UWORDS, true, lane);
-    CE_SUBSTAMP(11);
-    u32 rbase = 0;
-    bool spawnA[2];
+    waste_on = (T.apple_thresh[nH] & kWasteOnBit) != 0;
+  }
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const bool v = lane + 64 * r < (u32)G::NAPPLE;
+    const u32 cell = cell_pad(E.AP[r]);
+    elig[r] = v && pm[cell] == CE_CELL_EMPTY;
+    if (KIND == CE_KIND_CLEANUP) {
+      thrA[r] = T.apple_thresh[nH] & ~kWasteOnBit;
+    } else {
+      // apples in the 3x3 block around the cell (j^2 + k^2 <= APPLE_RADIUS = 2), pre-update map
+      u32 num = 0;
+      if (elig[r]) {
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+          for (int k = -1; k <= 1; ++k) num += pm[(i32)cell + j * G::PW + k] == CE_CELL_APPLE ? 1u : 0u;
+      }
+      thrA[r] = T.apple_thresh[num < 3 ? num : 3];
+    }
+    const u64 eb = ballot(elig[r]);
+    sa[r] = 2 * (rbase + popc64(eb & lt));
+    rbase += popc64(eb);
+  }
+  CE_SUBSTAMP(11);
+  // waste walk candidates: the t-th non-waste cell of the (shuffled) list gets double rbase + t
+  const u32 ncand = (u32)G::NWASTE - nH;
+  bool needw[2] = {false, false};
+  u32 sw[2] = {0, 0};
+  if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const bool v = lane + 64 * r < (u32)G::NAPPLE;
-      const u32 cell = cell_pad(E.AP[r]);
-      const bool elig = v && pm[cell] == CE_CELL_EMPTY;  // apple cell, no apple, no agent (bit 7)
-      const u64 eb = ballot(elig);
-      const u32 ri = rbase + popc64(eb & lt);
-      const u64 x = u53(E.L->U, elig ? ri : 0);
-      spawnA[r] = elig && x < thr;
-      rbase += popc64(eb);
+      const u32 t = lane + 64 * r;
+      needw[r] = waste_on && t < ncand;
+      sw[r] = 2 * (rbase + t);
     }
-    u32 waste_cell = 0;
-    bool waste_found = false;
-    CE_SUBSTAMP(12);
+  }
+  StreamWindow W = window_open<G::RANDW>(E.rng, lane);
+  u32 wa[AR], wb[AR], ww[2] = {0, 0};
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    wa[r] = window_read_old(W, elig[r], sa[r]);
+    wb[r] = window_read_old(W, elig[r], sa[r] + 1);
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ww[r] = window_read_old(W, needw[r], sw[r]);
+  }
+  if (W.alen < (u32)G::RANDW) {  // the window runs into the next generation
+    mt_twist(W.mt, lane);
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      wa[r] = window_read_new(W, elig[r], sa[r], wa[r]);
+      wb[r] = window_read_new(W, elig[r], sa[r] + 1, wb[r]);
+    }
+    if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) ww[r] = window_read_new(W, needw[r], sw[r], ww[r]);
+    }
+  }
+  window_close<G::RANDW>(E.rng, W);
+  bool spawnA[AR], tie[AR];
+  bool any_tie = false;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    spawnA[r] = below_hi(mt_temper(wa[r]), thrA[r], tie[r]) && elig[r];
+    tie[r] = tie[r] && elig[r];
+    any_tie = any_tie || tie[r];
+  }
+  if (ballot(any_tie) != 0) {  // exact tie of the 27 high bits (once in 2^27 doubles): the second word decides
+#pragma unroll
+    for (int r = 0; r < AR; ++r)
+      if (tie[r]) spawnA[r] = below_lo(wb[r], thrA[r]);
+  }
+  CE_SUBSTAMP(12);
+  u32 waste_cell = 0;
+  bool waste_found = false;
+  if (KIND == CE_KIND_CLEANUP) {
 #ifdef CE_ABLATE_SHUFFLE
     if (false) {
 #else
     if (waste_on) {
 #endif
-      // The walk over the shuffled list hands double rbase + t to the t-th non-waste cell and stops at the
-      // first u < 0.5: t* = first set byte of S from rbase on, independent of the permutation.
-      const u32 ncand = (u32)G::NWASTE - nH;
+      // The walk over the shuffled list stops at the first candidate whose double is < 0.5: t* is the first
+      // candidate index with a clear tempered sign bit, independent of the permutation.
       u32 tstar = 0xffffffffu;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (tstar == 0xffffffffu && (u32)(64 * r) < ncand) {
-          const u32 t = lane + 64 * r;
-          const u64 sb = ballot(t < ncand && E.L->S[rbase + (t < ncand ? t : 0)] != 0);
-          if (sb) tstar = ctz64(sb) + 64 * r;
-        }
+        const u64 sb = ballot(needw[r] && (__builtin_popcount(ww[r] & 0x89010000u) & 1) == 0);
+        if (tstar == 0xffffffffu && sb) tstar = ctz64(sb) + 64 * r;
       }
 #ifdef CE_SEQ_SHUFFLE
       shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
 #else
-      // the apple doubles in U are dead by now: U doubles as the draw list J[0..118]
+      // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
+      // spills into S)
       shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
       CE_SUBSTAMP(10);
 #ifdef CE_SERIAL_APPLY
       shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
 #else
-      // the step-mask table of the list update spills from U into S (both dead by now: t* is already known)
       static_assert(offsetof(WaveLds<KIND>, S) == offsetof(WaveLds<KIND>, U) + sizeof(E.L->U), "S must follow U");
-      static_assert(sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
+      static_assert(KIND != CE_KIND_CLEANUP || sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
       shuffle_apply_par(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
 #endif
 #endif
@@ -1038,42 +1137,13 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
         }
       }
     }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
-    if (waste_found && lane == 0) pm[waste_cell] = (uint8_t)(CE_CELL_WASTE | (pm[waste_cell] & kAgentBit));
-    wave_sync();
-  } else {
-    rng_bulk(E.rng, E.L->U, E.L->S, (u32)G::RANDW, (u32)G::UWORDS, false, lane);
-    u32 rbase = 0;
-    bool spawnA[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const bool v = lane + 64 * r < (u32)G::NAPPLE;
-      const u32 cell = cell_pad(E.AP[r]);
-      const bool elig = v && pm[cell] == CE_CELL_EMPTY;  // apple cell, no apple, no agent (bit 7)
-      // apples in the 3x3 block around the cell (j^2 + k^2 <= APPLE_RADIUS = 2), pre-update map
-      u32 num = 0;
-      if (elig) {
-#pragma unroll
-        for (int j = -1; j <= 1; ++j)
-#pragma unroll
-          for (int k = -1; k <= 1; ++k) num += pm[(i32)cell + j * G::PW + k] == CE_CELL_APPLE ? 1u : 0u;
-      }
-      const u64 thr = T.apple_thresh[num < 3 ? num : 3];
-      const u64 eb = ballot(elig);
-      const u32 ri = rbase + popc64(eb & lt);
-      const u64 x = u53(E.L->U, elig ? ri : 0);
-      spawnA[r] = elig && x < thr;
-      rbase += popc64(eb);
-    }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
-    wave_sync();
   }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < AR; ++r)
+    if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
+  if (waste_found && lane == 0) pm[waste_cell] = (uint8_t)(CE_CELL_WASTE | (pm[waste_cell] & kAgentBit));
+  wave_sync();
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1307,7 +1377,8 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   const u32 prc = bperm(mycol | myrow << 8, ga);  // also the wave_sync-free way to get agent ga's position
   wave_sync();
   u32 ka = 0xffffffffu, kw = 0xffffffffu;
-  for (u32 c = gl; c < NCHUNK; c += 1u << sh) {
+  for (u32 kc = 0; kc < (NCHUNK >> sh); ++kc) {  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
+    const u32 c = gl + (kc << sh);
     const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
     const u32 k0 = __builtin_amdgcn_sad_u8(a4.x, prc, 0u) << 16 | a4.x, k1 = __builtin_amdgcn_sad_u8(a4.y, prc, 0u) << 16 | a4.y;
     const u32 k2 = __builtin_amdgcn_sad_u8(a4.z, prc, 0u) << 16 | a4.z, k3 = __builtin_amdgcn_sad_u8(a4.w, prc, 0u) << 16 | a4.w;
@@ -1520,8 +1591,18 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
   {  // update_custom_moves: always shuffles the n ids, then fires in that order
     u32 IDS = lane;
-    shuffle_lanes1(E.rng, IDS, n, lane);
-    if (ballot(E.is_agent && ACT >= 7) != 0) {
+    const u64 firing = ballot(E.is_agent && ACT >= 7);
+#ifdef CE_OLD_NSHUFFLE
+    if (true) {
+#else
+    if (firing & (firing - 1)) {  // the shuffled order only matters between two or more beams
+#endif
+      shuffle_lanes1(E.rng, IDS, n, lane);
+    } else {
+      u32 d0 = 0, d1 = 0;
+      shuffle_core<false, 2>(E.rng, d0, d1, n, lane);  // same stream words, no swaps
+    }
+    if (firing != 0) {
       for (u32 k = 0; k < n; ++k) {
         const u32 a = rdl(IDS, k);
         const u32 act = rdl(ACT, a);
