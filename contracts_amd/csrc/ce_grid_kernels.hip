@@ -1302,6 +1302,7 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
 // total_close_apples).  Apples / wastes only ever sit on the static apple / waste cells, so the
 // closest-cell searches scan those lists (2-3 lane rounds) instead of the whole map.
 // ----------------------------------------------------------------------------------------
+DEVINL u32 min3u(u32 a, u32 b, u32 c) { return min(a, min(b, c)); }  // v_min3_u32
 // min over the aligned group of 2^sh lanes (sh = 2, 3, 4) this lane belongs to; every lane of the group gets it
 DEVINL u32 group_min_u32(u32 v, u32 sh) {
 #define CE_DPP_MIN(ctrl)                                                                    \
@@ -1344,9 +1345,10 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   // Closest apple / waste = min over keys  manhattan << 16 | row << 8 | col  (ties: smallest (row, col) ==
   // first in the row-major list, as np.argmin).  Coordinates sit one per byte, so the Manhattan distance is a
   // single v_sad_u8 against the agent's packed (row, col).  The present apples / wastes are first written as a
-  // key list (absent cell = ~0, which also yields key ~0) into the now idle random-word scratch; then the wave
+  // key list (absent cell = kNoKey, whose key stays above every real one) into the now idle random-word scratch; then the wave
   // splits into n groups of 2^sh lanes, group a scanning the whole list for agent a, 4 cells per LDS read.
   constexpr u32 NCHUNK = KIND == CE_KIND_CLEANUP ? 32u : 64u;  // 4-cell chunks per list
+  constexpr u32 kNoKey = 0x7f000000u;  // list entry of an absent cell: its key (sad << 16) + entry stays above every real key, no wrap
   constexpr u32 NENT = NCHUNK * 4u;
   static_assert(NENT >= (u32)G::NAPPLE && (KIND != CE_KIND_CLEANUP || NENT >= (u32)G::NWASTE), "key list too short");
   static_assert(KIND == CE_KIND_CLEANUP ? 2 * NENT * 4 <= sizeof(E.L->U) + sizeof(E.L->S) : NENT * 4 <= sizeof(E.L->U), "scratch");
@@ -1362,14 +1364,14 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
     napples += popc64(ballot(f));
-    keyA[lane + 64 * r] = f ? rc : 0xffffffffu;
+    keyA[lane + 64 * r] = f ? rc : kNoKey;
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (u32 r = 0; r < 2; ++r) {
       const bool f = lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE;
       nwaste += popc64(ballot(f));
-      keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : 0xffffffffu;
+      keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
     }
   }
   const u32 sh = n <= 4 ? 4u : n <= 8 ? 3u : 2u;
@@ -1377,23 +1379,25 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   const u32 prc = bperm(mycol | myrow << 8, ga);  // also the wave_sync-free way to get agent ga's position
   wave_sync();
   u32 ka = 0xffffffffu, kw = 0xffffffffu;
+#pragma unroll 1  // unrolling keeps 8 b128 loads in flight and costs an occupancy step
   for (u32 kc = 0; kc < (NCHUNK >> sh); ++kc) {  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
     const u32 c = gl + (kc << sh);
+    // key = manhattan << 16 | row << 8 | col in one v_sad_hi_u8 per cell (absent entries land at >= kNoKey)
     const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
-    const u32 k0 = __builtin_amdgcn_sad_u8(a4.x, prc, 0u) << 16 | a4.x, k1 = __builtin_amdgcn_sad_u8(a4.y, prc, 0u) << 16 | a4.y;
-    const u32 k2 = __builtin_amdgcn_sad_u8(a4.z, prc, 0u) << 16 | a4.z, k3 = __builtin_amdgcn_sad_u8(a4.w, prc, 0u) << 16 | a4.w;
-    ka = min(min(ka, min(k0, k1)), min(k2, k3));
+    const u32 k0 = __builtin_amdgcn_sad_hi_u8(a4.x, prc, a4.x), k1 = __builtin_amdgcn_sad_hi_u8(a4.y, prc, a4.y);
+    const u32 k2 = __builtin_amdgcn_sad_hi_u8(a4.z, prc, a4.z), k3 = __builtin_amdgcn_sad_hi_u8(a4.w, prc, a4.w);
+    ka = min3u(min3u(ka, k0, k1), k2, k3);
     if (KIND == CE_KIND_CLEANUP) {
       const uint4 w4 = *reinterpret_cast<const uint4*>(keyW + 4 * c);
-      const u32 q0 = __builtin_amdgcn_sad_u8(w4.x, prc, 0u) << 16 | w4.x, q1 = __builtin_amdgcn_sad_u8(w4.y, prc, 0u) << 16 | w4.y;
-      const u32 q2 = __builtin_amdgcn_sad_u8(w4.z, prc, 0u) << 16 | w4.z, q3 = __builtin_amdgcn_sad_u8(w4.w, prc, 0u) << 16 | w4.w;
-      kw = min(min(kw, min(q0, q1)), min(q2, q3));
+      const u32 q0 = __builtin_amdgcn_sad_hi_u8(w4.x, prc, w4.x), q1 = __builtin_amdgcn_sad_hi_u8(w4.y, prc, w4.y);
+      const u32 q2 = __builtin_amdgcn_sad_hi_u8(w4.z, prc, w4.z), q3 = __builtin_amdgcn_sad_hi_u8(w4.w, prc, w4.w);
+      kw = min3u(min3u(kw, q0, q1), q2, q3);
     }
   }
   ka = group_min_u32(ka, sh);
   if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
-  if (ka == 0xffffffffu) ka = 0;  // [0, 0] sentinel when there is none
-  if (kw == 0xffffffffu) kw = 0;
+  if (ka >= kNoKey) ka = 0;  // [0, 0] sentinel when there is none
+  if (kw >= kNoKey) kw = 0;
   if (gl == 0 && ga < n) {  // the group's first lane writes agent ga's closest-apple / closest-waste features
     auto f = feat_env + __umul24(ga, nf);
     store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
