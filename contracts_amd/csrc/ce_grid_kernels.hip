@@ -1165,37 +1165,40 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     if (E.is_agent) pm[E.P] = (uint8_t)(pm[E.P] & kCodeMask);  // reset(): agents are not on the colour map
     wave_sync();
   }
-  if (E.is_agent) {
-    const i32 base = (i32)E.P - kView * G::PW - kView;
+  // crop address of view pixel (i, j): off = o0 + i*A + j*B, kept per agent in its own lane
+  u32 VW = 0;
+  {
+    const i32 base = (i32)(E.is_agent ? E.P : pad_of<KIND>(0, 0)) - kView * G::PW - kView;
     i32 o0, A, B;
     if (E.O == 0) { o0 = base; A = G::PW; B = 1; }                                   // UP
     else if (E.O == 3) { o0 = base + 14; A = -1; B = G::PW; }                        // LEFT  rot90(k=1)
     else if (E.O == 2) { o0 = base + 14 * G::PW + 14; A = -G::PW; B = -1; }          // DOWN  rot90(k=2)
     else { o0 = base + 14 * G::PW; A = 1; B = -G::PW; }                              // RIGHT rot90(k=1,(1,0))
-    E.L->view[lane] = ((u32)o0 & 0xffffu) | (((u32)A & 0xffu) << 16) | (((u32)B & 0xffu) << 24);
+    VW = ((u32)o0 & 0xffffu) | (((u32)A & 0xffu) << 16) | (((u32)B & 0xffu) << 24);
   }
   wave_sync();
-  // One 12-byte unit = 4 horizontally adjacent pixels of one view row (rows are pitched to 16 pixels): 60 units
-  // per agent, unit u -> agent u / 60, row (u % 60) / 4, first column 4 * (u % 4); the 4 cells are B apart.
-  const u32 units = E.n * (u32)kObsUnitsPerAgent;
-  uint8_t* dst_env = p.obs + (size_t)E.e * p.obs_env_stride;
-  for (u32 u = lane; u < units; u += 64) {
-    const u32 a = __umul24(u, 1093u) >> 16;  // u / 60, exact for u < 600
-    const u32 rem = u - __umul24(a, (u32)kObsUnitsPerAgent);
-    const u32 i = rem >> 2, j0 = (rem & 3u) << 2;
-    const u32 vw = E.L->view[a];
-    const i32 B = (i32)vw >> 24;
-    const i32 off0 = (i32)(vw & 0xffffu) + __mul24((i32)i, (i32)(vw << 8) >> 24) + __mul24((i32)j0, B);
-    const u32 c0 = E.L->rgb[pm[off0]];
-    const u32 c1 = E.L->rgb[pm[off0 + B]];
-    const u32 c2 = E.L->rgb[pm[off0 + 2 * B]];
-    u32 c3 = E.L->rgb[pm[off0 + 3 * B]];
-    c3 = j0 == 12 ? 0u : c3;  // column 15 is the row padding
+  // One lane round per agent: lane l < 60 produces the 4 horizontally adjacent pixels (row l / 4, columns
+  // 4 * (l % 4) ..) of that agent's view as 12 bytes (rows are pitched to 16 pixels).  The view parameters of the
+  // round are wave-uniform scalars, the lane's (row, column) never changes, and the store is base + lane * 12.
+  const u32 row = (lane < 60 ? lane : 59u) >> 2, j0 = (lane & 3u) << 2;
+  const bool padded = j0 == 12;  // column 15 is the row padding
+  const u32 voff = __umul24(lane, 12u);
+  const u32* rgb = E.L->rgb;
+  auto dst = (CE_GPTR(char))(p.obs + (size_t)E.e * p.obs_env_stride);
+  for (u32 a = 0; a < E.n; ++a, dst += kObsAgentStride) {
+    const u32 vw = rdl(VW, a);
+    const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24, B2 = 2 * B, B3 = 3 * B;
+    const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)(vw & 0xffffu);
+    const u32 c0 = rgb[pm[off0]];
+    const u32 c1 = rgb[pm[off0 + B]];
+    const u32 c2 = rgb[pm[off0 + B2]];
+    u32 c3 = rgb[pm[off0 + B3]];
+    c3 = padded ? 0u : c3;
     uint3 d;
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
     d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
     d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
-    *(uint3*)(dst_env + __umul24(u, 12u)) = d;
+    if (lane < 60) *(CE_GPTR(uint3))(dst + voff) = d;
   }
 }
 
@@ -1480,7 +1483,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   u32 fault = 0;
   if (!setup_agents(E, (u32)G::NSPAWN_CTOR)) fault |= CE_FAULT_NO_SPAWN;
   zero_pmap(E);  // world_map is blank until the first reset
+#ifndef CE_ABLATE_GRIDSTORE
   store_grid(E, p);
+#endif
   store_agents(E, p);
   store_perms(E, p, true);
   store_rng(E, p);
@@ -1516,7 +1521,9 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   double theta = 0.0;
   u32 t = 0, fault = 0;
   reset_env(E, p, theta, t, fault);
+#ifndef CE_ABLATE_GRIDSTORE
   store_grid(E, p);
+#endif
   store_agents(E, p);
   store_perms(E, p, true);
   store_rng(E, p);
@@ -1776,10 +1783,14 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 
   CE_STAMP(7);
   // ---------------- state out, then the observation ----------------
+#ifndef CE_ABLATE_GRIDSTORE
   store_grid(E, p);
+#endif
   store_agents(E, p);
   store_perms(E, p, did_reset);
+#ifndef CE_ABLATE_RNGSTORE
   store_rng(E, p);
+#endif
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
     p.done[E.e] = done ? 1 : 0;
