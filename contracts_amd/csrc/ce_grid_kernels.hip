@@ -1614,10 +1614,12 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
       shuffle_core<false, 2>(E.rng, d0, d1, n, lane);  // same stream words, no swaps
     }
     if (firing != 0) {
-      for (u32 k = 0; k < n; ++k) {
+      // positions of the shuffled list that hold a firing agent, visited in list order
+      const u32 act_at = bperm(ACT, IDS);  // lane k: action of the agent at list position k
+      for (u64 it = ballot(lane < n && act_at >= 7); it; it &= it - 1) {
+        const u32 k = ctz64(it);
         const u32 a = rdl(IDS, k);
-        const u32 act = rdl(ACT, a);
-        if (act < 7) continue;
+        const u32 act = rdl(act_at, k);
         if (KIND == CE_KIND_CLEANUP && act == 7) {
           const u32 c = fire_beam(E, a, true);
           if (lane == a) cleaned = c;
