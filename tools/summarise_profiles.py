@@ -57,7 +57,7 @@ with open(stats_path) as f:
         if KERNEL in row["Name"]:
             kt = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "percentage": float(row["Percentage"]),
                   "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
-line = open(os.path.join(src, "kt.log")).read().strip().splitlines()[-1]
+line = open(os.path.join(src, "kt.json")).read().strip().splitlines()[-1]
 try:
     bench = json.loads(line)
     kt["bench_kernel_ms_hip_events"] = bench["roofline"]["kernel_ms"]
