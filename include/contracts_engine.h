@@ -39,7 +39,11 @@ extern "C" {
 enum ce_kind {
   CE_KIND_CLEANUP = 0,   /* environments/cleanup_new.py:59  CleanupEnv(MapEnv)            */
   CE_KIND_HARVEST = 1,   /* environments/harvest_new.py:48  HarvestEnv(MapEnv)            */
-  CE_KIND_SELFDRIVE = 2  /* environments/self_driving_car_accelerate.py:18                */
+  CE_KIND_SELFDRIVE = 2, /* environments/self_driving_car_accelerate.py:18                */
+  /* feature-vector envs of BASELINE config 0; same maps as the two grid kinds, no MapEnv logic,
+   * respawn doubles and the spawn shuffle from CPython's `random`, orientations from np.random */
+  CE_KIND_HARVEST_FEATURES = 3, /* environments/harvest_features.py:60  HarvestFeatures   */
+  CE_KIND_CLEANUP_FEATURES = 4  /* environments/cleanup_features.py:48  CleanupFeatures   */
 };
 
 /* contract fused into the step epilogue (contract/contract_list.py) */
@@ -106,7 +110,11 @@ typedef struct ce_buffers {
 
   /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
   uint8_t* grid;        /* bordered image: cell (e, r, c) at e*grid_env_stride + grid_origin + r*grid_row_stride
-                           + c, cell codes CE_CELL_*; border bytes are 0; a zero-copy [E][H][W] strided view  */
+                           + c, cell codes CE_CELL_*; border bytes are 0; a zero-copy [E][H][W] strided view.
+                           Feature kinds: CE_FEAT_STATE_BYTES per env instead (grid_env_stride) —
+                           u16 apple_stamp[CE_FEAT_APPLE_SLOTS], u16 waste_stamp[CE_FEAT_WASTE_SLOTS], u32 next_apple_stamp,
+                           u32 next_waste_stamp: the stamp of a cell is its rank in the reference's current_apple_points /
+                           current_waste_points list (argmin ties break by list order), 0xffff = absent            */
   uint8_t* agents;      /* [E][n][4]  row, col, orientation (UP0 RIGHT1 DOWN2 LEFT3,
                                       Agent.py:18-23), 0                                   */
   uint8_t* spawn_perm;  /* [E][20]    persistent shuffled spawn list (map_env.py:821) as
@@ -177,6 +185,10 @@ typedef struct ce_buffers {
  * n_crossed, crossed[n] (agent indices in crossing order), transfers metric */
 #define CE_SD_STATE_DOUBLES(n) (5 * (n) + 3)
 
+#define CE_FEAT_APPLE_SLOTS 160u
+#define CE_FEAT_WASTE_SLOTS 120u
+#define CE_FEAT_STATE_BYTES (2u * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) + 8u)
+#define CE_FEAT_ABSENT 0xffffu
 #define CE_RNG_WORDS_GRID 628u       /* key[624], pos, 3 pad words (16-byte aligned rows)   */
 #define CE_RNG_WORDS_SELFDRIVE 1256u /* numpy MT block then Python `random` MT block        */
 

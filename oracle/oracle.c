@@ -224,6 +224,9 @@ typedef struct {
   uint8_t waste_perm[119];
   int timesteps;
   double theta;
+  /* feature-vector envs: list-order stamps of current_apple_points / current_waste_points */
+  uint16_t apple_stamp[CE_FEAT_APPLE_SLOTS], waste_stamp[CE_FEAT_WASTE_SLOTS];
+  uint32_t next_apple_stamp, next_waste_stamp;
   /* apples present when the step was entered == reference current_apple_points */
   uint8_t entry_apples[16 * 38];
   /* selfdrive */
@@ -249,9 +252,10 @@ typedef struct orc {
 static int in_bounds(const orc_t* o, int r, int c) { return 0 <= r && r < o->H && 0 <= c && c < o->W; }
 
 static void build_static(orc_t* o) {
-  const char** map = o->kind == CE_KIND_CLEANUP ? CLEANUP_MAP : HARVEST_MAP;
-  o->H = o->kind == CE_KIND_CLEANUP ? 25 : 16;
-  o->W = o->kind == CE_KIND_CLEANUP ? 18 : 38;
+  const int cleanup_map = o->kind == CE_KIND_CLEANUP || o->kind == CE_KIND_CLEANUP_FEATURES; /* same maps as the feature envs */
+  const char** map = cleanup_map ? CLEANUP_MAP : HARVEST_MAP;
+  o->H = cleanup_map ? 25 : 16;
+  o->W = cleanup_map ? 18 : 38;
   o->cells = o->H * o->W;
   o->n_apple = o->n_waste = o->n_spawn_static = 0;
   for (int r = 0; r < o->H; r++)
@@ -261,7 +265,7 @@ static void build_static(orc_t* o) {
       o->is_wall[idx] = ch == '@';
       o->base_cell[idx] = ch == '@' ? CE_CELL_WALL : CE_CELL_EMPTY;
       if (ch == 'P') o->spawn_pts[o->n_spawn_static++] = (pt_t){r, c};
-      if (o->kind == CE_KIND_CLEANUP) {
+      if (cleanup_map) {
         if (ch == 'B') o->apple_pts[o->n_apple++] = (pt_t){r, c};
         if (ch == 'H' || ch == 'R') o->waste_pts[o->n_waste++] = (pt_t){r, c};
         if (ch == 'H') o->base_cell[idx] = CE_CELL_WASTE;
@@ -274,7 +278,7 @@ static void build_static(orc_t* o) {
         }
       }
     }
-  if (o->kind == CE_KIND_CLEANUP) {
+  if (cleanup_map) {
     /* cleanup_new.py:114-115 appends the P cells a second time */
     for (int i = 0; i < 10; i++) o->spawn_pts[10 + i] = o->spawn_pts[i];
   }
@@ -1101,6 +1105,394 @@ static void grid_step(orc_t* o, int ei, const uint8_t* act) {
   export_state(o, ei);
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* feature-vector envs: HarvestFeatures (harvest_features.py:60-336) and        */
+/* CleanupFeatures (cleanup_features.py:48-309), + the SeparateContract wrapper */
+/* The reference keeps current_apple_points / current_waste_points as Python    */
+/* lists; np.argmin over them breaks distance ties by LIST order, so each       */
+/* present cell carries the stamp of its list position (stamps only grow).      */
+/* ------------------------------------------------------------------------- */
+static int is_feat_kind(int kind) { return kind == CE_KIND_HARVEST_FEATURES || kind == CE_KIND_CLEANUP_FEATURES; }
+
+/* CPython random (Lib/random.py): getrandbits(k <= 32) takes the TOP k bits of one word */
+static uint32_t py_randbelow(mt_t* m, uint32_t nn) { /* _randbelow_with_getrandbits */
+  int k = 0;
+  for (uint32_t v = nn; v; v >>= 1) k++; /* n.bit_length() */
+  uint32_t r = mt_next(m) >> (32 - k);
+  while (r >= nn) r = mt_next(m) >> (32 - k);
+  return r;
+}
+static void py_shuffle_u8(mt_t* m, uint8_t* x, int len) { /* random.shuffle: i = len-1 .. 1, j = randbelow(i + 1) */
+  for (int i = len - 1; i >= 1; i--) {
+    uint32_t j = py_randbelow(m, (uint32_t)i + 1);
+    uint8_t t = x[i];
+    x[i] = x[j];
+    x[j] = t;
+  }
+}
+
+static int feat_apple_index(const orc_t* o, int r, int c) {
+  for (int i = 0; i < o->n_apple; i++)
+    if (o->apple_pts[i].row == r && o->apple_pts[i].col == c) return i;
+  return -1;
+}
+static int feat_waste_index(const orc_t* o, int r, int c) {
+  for (int i = 0; i < o->n_waste; i++)
+    if (o->waste_pts[i].row == r && o->waste_pts[i].col == c) return i;
+  return -1;
+}
+static int feat_apple_at(const orc_t* o, const env_t* e, int r, int c) {
+  int i = feat_apple_index(o, r, c);
+  return i >= 0 && e->apple_stamp[i] != CE_FEAT_ABSENT;
+}
+/* count_apples_in_radius harvest_features.py:127-137 (j^2 + k^2 <= radius, current apples) */
+static int feat_count_apples(const orc_t* o, const env_t* e, int radius, pt_t loc) {
+  int num = 0;
+  for (int j = -radius; j <= radius; j++)
+    for (int k = -radius; k <= radius; k++)
+      if (j * j + k * k <= radius && feat_apple_at(o, e, loc.row + j, loc.col + k)) num++;
+  return num;
+}
+static int feat_agent_on(const orc_t* o, const env_t* e, pt_t p) { /* `p in self.agent_pos.values()` */
+  for (int a = 0; a < o->n; a++)
+    if (pt_eq(e->pos[a], p)) return 1;
+  return 0;
+}
+
+/* initialize_arrays: harvest starts with every apple, cleanup with no apple and the H cells as waste */
+static void feat_init_arrays(orc_t* o, env_t* e) {
+  for (int i = 0; i < (int)CE_FEAT_APPLE_SLOTS; i++) e->apple_stamp[i] = CE_FEAT_ABSENT;
+  for (int i = 0; i < (int)CE_FEAT_WASTE_SLOTS; i++) e->waste_stamp[i] = CE_FEAT_ABSENT;
+  e->next_apple_stamp = e->next_waste_stamp = 0;
+  if (o->kind == CE_KIND_HARVEST_FEATURES) {
+    for (int i = 0; i < o->n_apple; i++) e->apple_stamp[i] = (uint16_t)e->next_apple_stamp++;
+  } else {
+    for (int i = 0; i < o->n_waste; i++) /* waste_start_points: the 'H' cells in row-major order */
+      if (o->base_cell[o->waste_pts[i].row * o->W + o->waste_pts[i].col] == CE_CELL_WASTE)
+        e->waste_stamp[i] = (uint16_t)e->next_waste_stamp++;
+  }
+}
+/* initialize_players: random.shuffle(range(len(spawn_points))), then np.random.randint(0, 4) per agent */
+static void feat_init_players(orc_t* o, env_t* e) {
+  uint8_t idx[20];
+  int L = o->n_spawn_static;
+  for (int i = 0; i < L; i++) idx[i] = (uint8_t)i;
+  py_shuffle_u8(&e->py_rng, idx, L);
+  for (int a = 0; a < o->n; a++) e->pos[a] = o->spawn_pts[idx[a]];
+  for (int a = 0; a < o->n; a++) e->orient[a] = (int)(mt_next(&e->np_rng) & 3u); /* legacy randint(0,4): masked 32-bit word */
+}
+static void feat_cleanup_probs(const orc_t* o, const env_t* e, double* p_apple, double* p_waste) {
+  int cur = 0;
+  for (int i = 0; i < o->n_waste; i++) cur += e->waste_stamp[i] != CE_FEAT_ABSENT;
+  double density = 0;
+  if (o->n_waste > 0) density = 1 - (double)(o->n_waste - cur) / o->n_waste;
+  if (density >= 0.4) {
+    *p_apple = 0;
+    *p_waste = 0;
+  } else {
+    *p_waste = 0.5;
+    if (density <= 0.0)
+      *p_apple = 0.05;
+    else
+      *p_apple = (1 - (density - 0.0) / (0.4 - 0.0)) * 0.05;
+  }
+}
+static void feat_spawn(orc_t* o, env_t* e) {
+  static const double SPAWN_PROB[4] = {0, 0.005, 0.02, 0.05};
+  if (o->kind == CE_KIND_HARVEST_FEATURES) { /* spawn_apples :139-151: neighbours include apples added earlier in this loop */
+    for (int i = 0; i < o->n_apple; i++) {
+      if (e->apple_stamp[i] != CE_FEAT_ABSENT || feat_agent_on(o, e, o->apple_pts[i])) continue;
+      int num = feat_count_apples(o, e, 2, o->apple_pts[i]);
+      double r = mt_double(&e->py_rng);
+      if (r < SPAWN_PROB[num < 3 ? num : 3]) e->apple_stamp[i] = (uint16_t)e->next_apple_stamp++;
+    }
+  } else { /* spawn_apples_and_waste cleanup_features.py:115-130 */
+    double pa, pw;
+    feat_cleanup_probs(o, e, &pa, &pw);
+    for (int i = 0; i < o->n_apple; i++) {
+      if (e->apple_stamp[i] != CE_FEAT_ABSENT || feat_agent_on(o, e, o->apple_pts[i])) continue;
+      double r = mt_double(&e->py_rng);
+      if (r < pa) e->apple_stamp[i] = (uint16_t)e->next_apple_stamp++;
+    }
+    for (int i = 0; i < o->n_waste; i++) {
+      if (e->waste_stamp[i] != CE_FEAT_ABSENT) continue;
+      double r = mt_double(&e->py_rng);
+      if (r < pw) {
+        e->waste_stamp[i] = (uint16_t)e->next_waste_stamp++;
+        break;
+      }
+    }
+  }
+}
+/* closest present cell: min over (manhattan, stamp) == np.argmin over the list; [0, 0] when the list is empty */
+static void feat_closest(const pt_t* pts, const uint16_t* stamp, int cnt, pt_t from, int* out_r, int* out_c, int* present) {
+  long best = -1;
+  int br = 0, bc = 0, np_ = 0;
+  for (int i = 0; i < cnt; i++) {
+    if (stamp[i] == CE_FEAT_ABSENT) continue;
+    np_++;
+    long key = ((long)(abs(pts[i].row - from.row) + abs(pts[i].col - from.col)) << 16) | stamp[i];
+    if (best < 0 || key < best) {
+      best = key;
+      br = pts[i].row;
+      bc = pts[i].col;
+    }
+  }
+  *out_r = br;
+  *out_c = bc;
+  *present = np_;
+}
+static void feat_write_features(orc_t* o, env_t* e, int ei, const int* cleaned) {
+  int n = o->n, F = (int)o->b.num_features;
+  int cp = n > 1 ? 1 : 0; /* compute_closest_pos: a0 -> a1, everyone else -> a0 (the inf - inf = nan argmin quirk) */
+  for (int a = 0; a < n; a++) {
+    int16_t* f = o->b.features + ((size_t)ei * n + a) * F;
+    int other = a == 0 ? cp : 0;
+    int ar, ac, na, wr = 0, wc = 0, nw = 0;
+    feat_closest(o->apple_pts, e->apple_stamp, o->n_apple, e->pos[a], &ar, &ac, &na);
+    f[0] = (int16_t)e->pos[a].row;
+    f[1] = (int16_t)e->pos[a].col;
+    f[2] = (int16_t)e->orient[a];
+    f[3] = (int16_t)e->pos[other].row;
+    f[4] = (int16_t)e->pos[other].col;
+    f[5] = (int16_t)e->orient[other];
+    f[6] = (int16_t)ar;
+    f[7] = (int16_t)ac;
+    if (o->kind == CE_KIND_HARVEST_FEATURES) {
+      f[8] = (int16_t)feat_count_apples(o, e, 5, e->pos[a]);
+      f[9] = (int16_t)na;
+      for (int b = 0; b < 2 * n; b++) f[10 + b] = 0;
+    } else {
+      feat_closest(o->waste_pts, e->waste_stamp, o->n_waste, e->pos[a], &wr, &wc, &nw);
+      f[8] = (int16_t)wr;
+      f[9] = (int16_t)wc;
+      f[10] = (int16_t)na;
+      f[11] = (int16_t)nw;
+      for (int b = 0; b < n; b++) f[12 + b] = (int16_t)cleaned[b];
+    }
+  }
+}
+static void feat_export(orc_t* o, int ei) {
+  env_t* e = &o->envs[ei];
+  int n = o->n;
+  uint8_t* st = o->b.grid + (size_t)ei * CE_FEAT_STATE_BYTES;
+  memcpy(st, e->apple_stamp, 2 * CE_FEAT_APPLE_SLOTS);
+  memcpy(st + 2 * CE_FEAT_APPLE_SLOTS, e->waste_stamp, 2 * CE_FEAT_WASTE_SLOTS);
+  memcpy(st + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS), &e->next_apple_stamp, 4);
+  memcpy(st + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) + 4, &e->next_waste_stamp, 4);
+  for (int a = 0; a < n; a++) {
+    uint8_t* p = o->b.agents + ((size_t)ei * n + a) * 4;
+    p[0] = (uint8_t)e->pos[a].row;
+    p[1] = (uint8_t)e->pos[a].col;
+    p[2] = (uint8_t)e->orient[a];
+    p[3] = 0;
+  }
+  o->b.timestep[ei] = e->timesteps;
+  o->b.theta[ei] = e->theta;
+  uint32_t* rw = o->b.rng + (size_t)ei * CE_RNG_WORDS_SELFDRIVE;
+  memcpy(rw, e->np_rng.key, 624 * 4);
+  rw[624] = e->np_rng.pos;
+  memcpy(rw + CE_RNG_WORDS_GRID, e->py_rng.key, 624 * 4);
+  rw[CE_RNG_WORDS_GRID + 624] = e->py_rng.pos;
+}
+static void feat_import(orc_t* o, int ei) {
+  env_t* e = &o->envs[ei];
+  int n = o->n;
+  const uint8_t* st = o->b.grid + (size_t)ei * CE_FEAT_STATE_BYTES;
+  memcpy(e->apple_stamp, st, 2 * CE_FEAT_APPLE_SLOTS);
+  memcpy(e->waste_stamp, st + 2 * CE_FEAT_APPLE_SLOTS, 2 * CE_FEAT_WASTE_SLOTS);
+  memcpy(&e->next_apple_stamp, st + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS), 4);
+  memcpy(&e->next_waste_stamp, st + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) + 4, 4);
+  for (int a = 0; a < n; a++) {
+    const uint8_t* p = o->b.agents + ((size_t)ei * n + a) * 4;
+    e->pos[a].row = p[0];
+    e->pos[a].col = p[1];
+    e->orient[a] = p[2];
+  }
+  e->timesteps = o->b.timestep[ei];
+  e->theta = o->b.theta[ei];
+  const uint32_t* rw = o->b.rng + (size_t)ei * CE_RNG_WORDS_SELFDRIVE;
+  memcpy(e->np_rng.key, rw, 624 * 4);
+  e->np_rng.pos = rw[624];
+  memcpy(e->py_rng.key, rw + CE_RNG_WORDS_GRID, 624 * 4);
+  e->py_rng.pos = rw[CE_RNG_WORDS_GRID + 624];
+}
+static void feat_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
+  env_t* e = &o->envs[ei];
+  if (mode & CE_SEED_RESEED) {
+    mt_init_genrand(&e->np_rng, (uint32_t)seed);
+    uint32_t k32 = (uint32_t)seed;
+    mt_init_by_array(&e->py_rng, &k32, 1);
+  }
+  if (!(mode & CE_SEED_CONSTRUCT)) return;
+  feat_init_arrays(o, e); /* __init__: initialize_arrays, (compute_probabilities), initialize_players */
+  feat_init_players(o, e);
+  e->timesteps = 0;
+  e->theta = 0;
+  latch_zero_metrics(o, ei);
+}
+static void feat_reset(orc_t* o, int ei) {
+  env_t* e = &o->envs[ei];
+  int n = o->n;
+  feat_init_arrays(o, e);
+  feat_init_players(o, e);
+  feat_spawn(o, e);
+  latch_zero_metrics(o, ei);
+  e->timesteps = 0;
+  sample_theta(o, e);
+  int zero[MAXN] = {0};
+  feat_write_features(o, e, ei, zero);
+  for (int a = 0; a < n; a++) {
+    o->b.base_reward[(size_t)ei * n + a] = 0;
+    o->b.reward[(size_t)ei * n + a] = 0;
+    o->b.info[((size_t)ei * n + a) * 2] = 0;
+    o->b.info[((size_t)ei * n + a) * 2 + 1] = 0;
+  }
+  o->b.done[ei] = 0;
+  feat_export(o, ei);
+}
+static void feat_step(orc_t* o, int ei, const uint8_t* act) {
+  static const int MOVE[4][2] = {{0, -1}, {0, 1}, {-1, 0}, {1, 0}};  /* MOVE_ACTIONS */
+  static const int FIRE[4][2] = {{-1, 0}, {0, 1}, {1, 0}, {0, -1}};  /* FIRE_DIRECTIONS */
+  env_t* e = &o->envs[ei];
+  int n = o->n, W = o->W;
+  int harvest = o->kind == CE_KIND_HARVEST_FEATURES;
+  int max_action = harvest ? 7 : 8;
+  for (int a = 0; a < n; a++)
+    if (act[a] > max_action) {
+      o->b.error_flags[ei] |= CE_FAULT_BAD_ACTION;
+      return;
+    }
+  int64_t* mi = o->b.int_metrics + (size_t)ei * CE_MI_COUNT(n);
+  double* mf = o->b.f64_metrics + (size_t)ei * CE_MF_COUNT(n);
+  /* move_squares, an insertion-ordered dict: stayers first, then movers in key order */
+  int order[MAXN], has[MAXN] = {0}, cnt = 0;
+  pt_t sq[MAXN];
+  for (int a = 0; a < n; a++)
+    if (harvest ? act[a] > 3 : act[a] == 4) {
+      sq[a] = e->pos[a];
+      has[a] = 1;
+      order[cnt++] = a;
+    }
+  for (int a = 0; a < n; a++)
+    if (act[a] < 4) {
+      pt_t t = {e->pos[a].row + MOVE[act[a]][0], e->pos[a].col + MOVE[act[a]][1]};
+      int blocked = !in_bounds(o, t.row, t.col) || o->is_wall[t.row * W + t.col];
+      for (int k = 0; k < cnt && !blocked; k++) blocked = pt_eq(sq[order[k]], t);
+      sq[a] = blocked ? e->pos[a] : t;
+      has[a] = 1;
+      order[cnt++] = a;
+    }
+  for (int a = 0; a < n; a++)
+    if (has[a]) e->pos[a] = sq[a];
+  /* consume apples in move_squares order */
+  int rew[MAXN] = {0}, eaten[MAXN] = {0}, eaten_close[MAXN] = {0}, cleaned[MAXN] = {0};
+  for (int k = 0; k < cnt; k++) {
+    int a = order[k];
+    int ai = feat_apple_index(o, sq[a].row, sq[a].col);
+    if (ai < 0 || e->apple_stamp[ai] == CE_FEAT_ABSENT) continue;
+    rew[a] += 1;
+    if (harvest) {
+      eaten[a] += 1;
+      if (feat_count_apples(o, e, 5, e->pos[a]) < 4) {
+        eaten_close[a] += 1;
+        mi[CE_MI_LOW_DENSITY_APPLES] += 1;
+        mi[CE_MI_AGENT(n, CE_MIA_B, a)] += 1;
+      }
+      mi[CE_MI_TOTAL_APPLES_EATEN] += 1;
+      mi[CE_MI_AGENT(n, CE_MIA_A, a)] += 1;
+    }
+    e->apple_stamp[ai] = CE_FEAT_ABSENT;
+  }
+  for (int a = 0; a < n; a++) { /* rotations */
+    if (act[a] == 5) e->orient[a] = (e->orient[a] + 1) % 4;
+    if (act[a] == 6) e->orient[a] = (e->orient[a] + 3) % 4;
+  }
+  if (!harvest) /* clean beams (act 7): three rays of 6 cells from the agent's own row, through waste, until a wall */
+    for (int a = 0; a < n; a++) {
+      if (act[a] != 7) continue;
+      const int* d = FIRE[e->orient[a]];
+      const int* s = FIRE[(e->orient[a] + 1) % 4];
+      for (int ray = 0; ray < 3; ray++) {
+        int r0 = e->pos[a].row + (ray == 1 ? s[0] : ray == 2 ? -s[0] : 0);
+        int c0 = e->pos[a].col + (ray == 1 ? s[1] : ray == 2 ? -s[1] : 0);
+        for (int j = 0; j < 6; j++) {
+          int r = r0 + j * d[0], c = c0 + j * d[1];
+          if (in_bounds(o, r, c) && o->is_wall[r * W + c]) break;
+          int wi = in_bounds(o, r, c) ? feat_waste_index(o, r, c) : -1;
+          if (wi >= 0 && e->waste_stamp[wi] != CE_FEAT_ABSENT) {
+            e->waste_stamp[wi] = CE_FEAT_ABSENT;
+            cleaned[a] += 1;
+            mi[CE_MI_DIRT_CLEANED] += 1;
+            mi[CE_MI_AGENT(n, CE_MIA_A, a)] += 1;
+          }
+        }
+      }
+    }
+  feat_spawn(o, e);
+  feat_write_features(o, e, ei, cleaned);
+  int16_t* feat = o->b.features + (size_t)ei * n * o->b.num_features;
+  e->timesteps += 1;
+  int done = e->timesteps == (int)o->cfg.horizon;
+  for (int a = 0; a < n; a++) { /* total_reward_dict / raw_env_rewards (floats holding small integers) */
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_R, a)] += rew[a];
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, a)] += (int64_t)(e->timesteps - 1) * rew[a];
+    mi[CE_MI_RAW_ENV_REWARDS] += rew[a];
+  }
+  double rews[MAXN];
+  for (int a = 0; a < n; a++) rews[a] = (double)rew[a];
+  if (o->cfg.contract != CE_CONTRACT_NONE) { /* SeparateContractEnv.step two_stage_train.py:62-121 */
+    double tr[MAXN];
+    for (int a = 0; a < n; a++) {
+      if (o->cfg.contract == CE_CONTRACT_CLEANUP)
+        tr[a] = -e->theta * cleaned[a];
+      else
+        tr[a] = (feat[(size_t)a * o->b.num_features + 8] < 4 && eaten_close[a] > 0) ? e->theta : 0.0;
+    }
+    double total = 0;
+    for (int i = 0; i < n; i++) {
+      rews[i] -= tr[i];
+      total += tr[i];
+      for (int j = 0; j < n; j++)
+        if (i != j) rews[j] += tr[i] / (n - 1);
+    }
+    mf[CE_MF_TRANSFERS] += total;
+    for (int a = 0; a < n; a++) {
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_R, a)] += rews[a];
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, a)] += (double)(e->timesteps - 1) * rews[a];
+    }
+  }
+  for (int a = 0; a < n; a++) {
+    o->b.base_reward[(size_t)ei * n + a] = rew[a];
+    o->b.reward[(size_t)ei * n + a] = rews[a];
+    o->b.info[((size_t)ei * n + a) * 2] = (uint8_t)eaten[a];
+    o->b.info[((size_t)ei * n + a) * 2 + 1] = (uint8_t)(harvest ? eaten_close[a] : cleaned[a]);
+  }
+  o->b.done[ei] = (uint8_t)done;
+  if (done) {
+    finalize_episode_metrics(o, ei);
+    if (o->cfg.flags & CE_FLAG_AUTO_RESET) {
+      int32_t br[MAXN];
+      double rr[MAXN];
+      uint8_t inf[MAXN * 2];
+      int16_t ft[MAXN * 40];
+      memcpy(br, o->b.base_reward + (size_t)ei * n, sizeof(int32_t) * n);
+      memcpy(rr, o->b.reward + (size_t)ei * n, sizeof(double) * n);
+      memcpy(inf, o->b.info + (size_t)ei * n * 2, 2 * n);
+      memcpy(ft, feat, sizeof(int16_t) * n * o->b.num_features);
+      feat_reset(o, ei);
+      o->b.done[ei] = 1;
+      memcpy(o->b.base_reward + (size_t)ei * n, br, sizeof(int32_t) * n);
+      memcpy(o->b.reward + (size_t)ei * n, rr, sizeof(double) * n);
+      memcpy(o->b.info + (size_t)ei * n * 2, inf, 2 * n);
+      memcpy(feat, ft, sizeof(int16_t) * n * o->b.num_features);
+      return;
+    }
+  }
+  feat_export(o, ei);
+}
+
 /* ------------------------------------------------------------------------- */
 /* selfdrive (self_driving_car_accelerate.py) + SelfdriveContractDistprop      */
 /* ------------------------------------------------------------------------- */
@@ -1376,7 +1768,7 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
 
 int orc_create(const ce_config* cfg, orc_t** out) {
   if (!cfg || !out || cfg->abi_version != CE_ABI_VERSION) return CE_EINVAL;
-  if (cfg->kind > CE_KIND_SELFDRIVE || cfg->num_envs == 0) return CE_EINVAL;
+  if (cfg->kind > CE_KIND_CLEANUP_FEATURES || cfg->num_envs == 0) return CE_EINVAL;
   int maxn = cfg->kind == CE_KIND_SELFDRIVE ? 10 : 9;
   if (cfg->num_agents < 1 || (int)cfg->num_agents > maxn) return CE_EINVAL;
   orc_t* o = (orc_t*)calloc(1, sizeof(orc_t));
@@ -1392,7 +1784,18 @@ int orc_create(const ce_config* cfg, orc_t** out) {
   o->b.num_agents = cfg->num_agents;
   o->b.num_int_metrics = CE_MI_COUNT(n);
   o->b.num_f64_metrics = CE_MF_COUNT(n);
-  if (o->kind != CE_KIND_SELFDRIVE) {
+  if (is_feat_kind(o->kind)) {
+    build_static(o);
+    o->b.grid_h = o->H;
+    o->b.grid_w = o->W;
+    o->b.grid_env_stride = CE_FEAT_STATE_BYTES;
+    o->b.rng_words = CE_RNG_WORDS_SELFDRIVE;
+    o->b.num_features = o->kind == CE_KIND_CLEANUP_FEATURES ? 12 + n : 10 + 2 * n;
+    ALLOC(grid, uint8_t, E * CE_FEAT_STATE_BYTES);
+    ALLOC(agents, uint8_t, E * n * 4);
+    ALLOC(rng, uint32_t, E * CE_RNG_WORDS_SELFDRIVE);
+    ALLOC(features, int16_t, E * n * o->b.num_features);
+  } else if (o->kind != CE_KIND_SELFDRIVE) {
     build_static(o);
     o->b.grid_h = o->H;
     o->b.grid_w = o->W;
@@ -1452,6 +1855,11 @@ int orc_seed(orc_t* o, const uint64_t* seeds, uint64_t seed0, const uint8_t* mas
   for (long ei = 0; ei < (long)o->cfg.num_envs; ei++) {
     if (mask && !mask[ei]) continue;
     uint64_t s = seeds ? seeds[ei] : seed0 + o->cfg.env_index_base + (uint64_t)ei;
+    if (is_feat_kind(o->kind)) {
+      feat_seed_construct(o, (int)ei, s, mode);
+      feat_export(o, (int)ei);
+      continue;
+    }
     if (o->kind == CE_KIND_SELFDRIVE)
       sd_seed_construct(o, (int)ei, s, mode);
     else
@@ -1466,7 +1874,9 @@ int orc_reset(orc_t* o, const uint8_t* mask) {
 #pragma omp parallel for schedule(static)
   for (long ei = 0; ei < (long)o->cfg.num_envs; ei++) {
     if (mask && !mask[ei]) continue;
-    if (o->kind == CE_KIND_SELFDRIVE)
+    if (is_feat_kind(o->kind))
+      feat_reset(o, (int)ei);
+    else if (o->kind == CE_KIND_SELFDRIVE)
       sd_reset(o, (int)ei);
     else
       grid_reset(o, (int)ei);
@@ -1479,7 +1889,9 @@ int orc_step(orc_t* o, const void* actions, const uint8_t* active) {
   int n = o->n;
 #pragma omp parallel for schedule(static)
   for (long ei = 0; ei < (long)o->cfg.num_envs; ei++) {
-    if (o->kind == CE_KIND_SELFDRIVE)
+    if (is_feat_kind(o->kind))
+      feat_step(o, (int)ei, (const uint8_t*)actions + (size_t)ei * n);
+    else if (o->kind == CE_KIND_SELFDRIVE)
       sd_step(o, (int)ei, (const float*)actions + (size_t)ei * n, active ? active + (size_t)ei * n : NULL);
     else
       grid_step(o, (int)ei, (const uint8_t*)actions + (size_t)ei * n);
@@ -1498,6 +1910,10 @@ int orc_import_state(orc_t* o, uint32_t ei) {
   if (!o || ei >= o->cfg.num_envs) return CE_EINVAL;
   env_t* e = &o->envs[ei];
   int n = o->n;
+  if (is_feat_kind(o->kind)) {
+    feat_import(o, (int)ei);
+    return CE_OK;
+  }
   if (o->kind != CE_KIND_SELFDRIVE) {
     memcpy(e->grid, o->b.grid + (size_t)ei * o->cells, o->cells);
     for (int a = 0; a < n; a++) {

@@ -12,7 +12,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
-KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2}
+KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "cleanup_features": 4}
+FEAT_KINDS = ("harvest_features", "cleanup_features")
+FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
 FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION = 1, 2, 4, 8, 16
 
@@ -130,7 +132,16 @@ def buffer_views(b, kind):
     """numpy views (host memory) with the shapes documented in include/contracts_engine.h"""
     E, n = b.num_envs, b.num_agents
     v = {}
-    if kind != "selfdrive":
+    if kind in FEAT_KINDS:
+        st = _view(b.grid, np.uint8, (E, FEAT_STATE_BYTES))
+        v["grid"] = st  # raw state block; typed views below
+        v["apple_stamp"] = st[:, :2 * FEAT_APPLE_SLOTS].view(np.uint16)
+        v["waste_stamp"] = st[:, 2 * FEAT_APPLE_SLOTS:2 * (FEAT_APPLE_SLOTS + FEAT_WASTE_SLOTS)].view(np.uint16)
+        v["next_stamp"] = st[:, 2 * (FEAT_APPLE_SLOTS + FEAT_WASTE_SLOTS):].view(np.uint32)
+        v["agents"] = _view(b.agents, np.uint8, (E, n, 4))
+        v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
+        v["features"] = _view(b.features, np.int16, (E, n, b.num_features))
+    elif kind != "selfdrive":
         cells = b.grid_h * b.grid_w
         v["grid"] = _view(b.grid, np.uint8, (E, b.grid_env_stride))[:, :cells].reshape(E, b.grid_h, b.grid_w)  # dense in the oracle
         v["agents"] = _view(b.agents, np.uint8, (E, n, 4))

@@ -165,3 +165,82 @@ def replay_selfdrive(g, impl, env=0, sync=lambda: None, get=None, atol=1e-9):
             nc = int(st[4 * n + 1])
             crossed = [int(x) for x in st[4 * n + 2:4 * n + 2 + nc]]
             assert crossed == [int(x) for x in g["crossed"][t] if x >= 0], "crossed " + tag
+
+
+def feat_kwargs(g):
+    kind = str(g["kind"])
+    contract = None
+    if int(g["contract"]):
+        contract = "harvest_local" if kind == "harvest_features" else "cleanup"
+    return kind, int(g["n"]), dict(contract=contract, horizon=int(g["horizon"]))
+
+
+def _order_from_stamps(stamps, width):
+    """cell indices sorted by list-order stamp (0xffff = absent), padded with -1 like the fixture"""
+    present = np.nonzero(stamps != 0xffff)[0]
+    order = present[np.argsort(stamps[present], kind="stable")]
+    out = np.full((width,), -1, np.int16)
+    out[: len(order)] = order
+    return out
+
+
+def replay_feat(g, impl, env=0, sync=lambda: None, get=None):
+    """HarvestFeatures / CleanupFeatures fixture (tests/golden/feat_*.npz) through an Oracle/BatchedEnv-like impl"""
+    if get is None:
+        def get(name):
+            return getattr(impl, name)
+    kind, n = str(g["kind"]), int(g["n"])
+    E = impl.E
+    NA, NW = len(g["apple_points"]), len(g["waste_points"])
+
+    def fp(block):
+        rng = get("rng")[env]
+        w = rng[628 * block: 628 * block + 625]
+        return (int(w[624]), int(hashlib.sha256(w[:624].tobytes()).hexdigest()[:8], 16))
+
+    def check_lists(tag, apple_ref, waste_ref):
+        assert np.array_equal(_order_from_stamps(get("apple_stamp")[env][:NA], NA), apple_ref), "apple list " + tag
+        if NW:
+            assert np.array_equal(_order_from_stamps(get("waste_stamp")[env][:NW], NW), waste_ref), "waste list " + tag
+
+    impl.seed(np.full((E,), int(g["seed"]), np.uint64))
+    sync()
+    assert np.array_equal(get("agents")[env][:, :3], g["ctor_agents"]), "constructor agents"
+    assert fp(0) == tuple(int(x) for x in g["ctor_mt_np"]) and fp(1) == tuple(int(x) for x in g["ctor_mt_py"]), "constructor RNG"
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    for ep in range(len(g["ep_start"])):
+        impl.reset()
+        sync()
+        tag = "reset ep%d" % ep
+        assert np.array_equal(get("agents")[env][:, :3], g["reset_agents"][ep]), "agents " + tag
+        assert np.array_equal(get("features")[env].astype(np.float64), g["reset_obs"][ep]), "obs " + tag
+        check_lists(tag, g["reset_apple_order"][ep], g["reset_waste_order"][ep] if NW else None)
+        assert fp(0) == tuple(int(x) for x in g["reset_mt_np"][ep]), "numpy stream " + tag
+        assert fp(1) == tuple(int(x) for x in g["reset_mt_py"][ep]), "python stream " + tag
+        assert get("theta")[env] == g["theta"][ep], "theta " + tag
+        for t in range(ep_start[ep], ep_start[ep + 1]):
+            impl.step(np.broadcast_to(g["actions"][t], (E, n)))
+            sync()
+            tag = "step %d (ep %d)" % (t, ep)
+            assert np.array_equal(get("agents")[env][:, :3], g["agents"][t]), "agents " + tag
+            assert np.array_equal(get("base_reward")[env], g["base_rew"][t]), "base reward " + tag
+            np.testing.assert_allclose(get("reward")[env], g["rew"][t], rtol=0, atol=1e-9, err_msg="reward " + tag)
+            info = get("info")[env]
+            assert np.array_equal(info[:, 0], g["info0"][t]) and np.array_equal(info[:, 1], g["info1"][t]), "infos " + tag
+            assert np.array_equal(get("features")[env].astype(np.float64), g["feature_obs"][t]), "feature obs " + tag
+            assert int(get("done")[env]) == int(g["done"][t]), "done " + tag
+            check_lists(tag, g["apple_order"][t], g["waste_order"][t] if NW else None)
+            assert fp(1) == tuple(int(x) for x in g["mt_py"][t]), "python stream " + tag
+            assert fp(0) == tuple(int(x) for x in g["mt_np"][t]), "numpy stream " + tag
+        keys = str(g["metrics_keys_ep%d" % ep]).split(",")
+        vals = g["metrics_vals_ep%d" % ep]
+        final = "equality" in keys
+        mi = get("final_int_metrics" if final else "int_metrics")[env]
+        mf = get("final_f64_metrics" if final else "f64_metrics")[env]
+        md = {"total_apples_eaten": mi[0], "raw_env_rewards": mi[1], "dirt_cleaned": mi[2], "low_density_apples_eaten": mi[3],
+              "transfers": mf[0], "equality": mf[1], "sustainability": mf[2], "transfer_equality": mf[3],
+              "transfer_sustainability": mf[4]}
+        for k, v in zip(keys, vals):
+            if k.startswith("transfer") and int(g["contract"]) == 0:
+                continue
+            np.testing.assert_allclose(md[k], v, rtol=1e-12, atol=1e-9, err_msg="metric %s ep%d" % (k, ep))
