@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONTRACTS_AMD_LIB") or os.path.join(HERE, "csrc", "libcontracts_engine.so")
 
 CE_ABI_VERSION = 1
-KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2}
+KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "cleanup_features": 4}
+FEAT_KINDS = ("harvest_features", "cleanup_features")
+FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_* of the header
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
 FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION = 1, 2, 4, 8, 16
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4

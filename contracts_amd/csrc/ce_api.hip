@@ -160,16 +160,21 @@ struct ce_engine;
 static int sync_device_params(ce_engine* h);
 
 static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.kind == CE_KIND_HARVEST; }
+static bool is_feat(const ce_config& c) { return c.kind == CE_KIND_HARVEST_FEATURES || c.kind == CE_KIND_CLEANUP_FEATURES; }
+static bool u8_actions(const ce_config& c) { return is_grid(c) || is_feat(c); }  // one byte per agent (selfdrive: float32)
 
 extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (!cfg || !out) return CE_EINVAL;
   *out = nullptr;
-  if (cfg->abi_version != CE_ABI_VERSION || cfg->kind > CE_KIND_SELFDRIVE || cfg->num_envs == 0) return CE_EINVAL;
+  if (cfg->abi_version != CE_ABI_VERSION || cfg->kind > CE_KIND_CLEANUP_FEATURES || cfg->num_envs == 0) return CE_EINVAL;
   const uint32_t maxn = cfg->kind == CE_KIND_SELFDRIVE ? 10 : kMaxGridAgents;
   if (cfg->num_agents < 1 || cfg->num_agents > maxn) return CE_EINVAL;
   if (cfg->kind == CE_KIND_CLEANUP && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_CLEANUP) return CE_EINVAL;
   if (cfg->kind == CE_KIND_HARVEST && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
   if (cfg->kind == CE_KIND_SELFDRIVE && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_SELFDRIVE_DISTPROP) return CE_EINVAL;
+  if (cfg->kind == CE_KIND_CLEANUP_FEATURES && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_CLEANUP) return CE_EINVAL;
+  if (cfg->kind == CE_KIND_HARVEST_FEATURES && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
+  if (is_feat(*cfg) && (cfg->flags & (CE_FLAG_COLLECTIVE_REWARD | CE_FLAG_INEQUITY_AVERSE | CE_FLAG_FIRING_ENABLED))) return CE_EINVAL;
   if ((cfg->flags & CE_FLAG_INEQUITY_AVERSE) && cfg->num_agents < 2) return CE_EINVAL;  // map_env.py:294 assertion
 
   ce_engine* h = new (std::nothrow) ce_engine();
@@ -226,6 +231,20 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     A(rng, E * CE_RNG_WORDS_GRID);
     A(obs, E * b.obs_env_stride + 16);
     A(features, E * n * b.num_features);
+  } else if (is_feat(*cfg)) {
+    const bool cl = cfg->kind == CE_KIND_CLEANUP_FEATURES;
+    b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
+    b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
+    h->grid_stride = CE_FEAT_STATE_BYTES;
+    b.grid_env_stride = CE_FEAT_STATE_BYTES;
+    b.num_features = (uint32_t)(cl ? 12 + n : 10 + 2 * n);
+    b.rng_words = CE_RNG_WORDS_SELFDRIVE;
+    A(grid, E * CE_FEAT_STATE_BYTES);
+    A(agents, E * n * 4);
+    A(rng, E * CE_RNG_WORDS_SELFDRIVE);
+    A(features, E * n * b.num_features);
+  }
+  if (is_grid(*cfg) || is_feat(*cfg)) {
     // static tables (process-wide constants; re-uploading identical bytes is harmless)
     if (rc == CE_OK) {
       static GridTables t0, t1;
@@ -244,7 +263,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
           upload_grid_tables(CE_KIND_HARVEST, t1, pix.data(), (int)pix.size(), lut))
         rc = fail(h, CE_ENODEV, "constant table upload failed");
     }
-  } else {
+  }
+  if (!is_grid(*cfg) && !is_feat(*cfg)) {
     b.num_features = (uint32_t)(2 * n + 7);
     b.rng_words = CE_RNG_WORDS_SELFDRIVE;
     A(rng, E * CE_RNG_WORDS_SELFDRIVE);
@@ -268,8 +288,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_actions, E * n * 4);
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_active, E * n);
   if (rc == CE_OK) rc = dalloc(h, &h->d_debug, E * 16);
-  if (rc == CE_OK && is_grid(*cfg)) rc = dalloc(h, &h->d_gparams, 1);
-  if (rc == CE_OK && is_grid(*cfg)) rc = sync_device_params(h);
+  if (rc == CE_OK && u8_actions(*cfg)) rc = dalloc(h, &h->d_gparams, 1);
+  if (rc == CE_OK && u8_actions(*cfg)) rc = sync_device_params(h);
 #undef A
   return rc;
 }
@@ -289,7 +309,8 @@ extern "C" int ce_destroy(ce_handle h) {
 static int contract_ok(uint32_t kind, uint32_t contract) {
   if (contract == CE_CONTRACT_NONE) return 1;
   if (kind == CE_KIND_CLEANUP) return contract == CE_CONTRACT_CLEANUP;
-  if (kind == CE_KIND_HARVEST) return contract == CE_CONTRACT_HARVEST_LOCAL;
+  if (kind == CE_KIND_HARVEST || kind == CE_KIND_HARVEST_FEATURES) return contract == CE_CONTRACT_HARVEST_LOCAL;
+  if (kind == CE_KIND_CLEANUP_FEATURES) return contract == CE_CONTRACT_CLEANUP;
   return contract == CE_CONTRACT_SELFDRIVE_DISTPROP;
 }
 
@@ -427,6 +448,14 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
       p.mask = dmask;
       launch_grid_construct((int)h->cfg.kind, p, h->d_gparams, nullptr);
     }
+  } else if (is_feat(h->cfg)) {
+    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
+    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, CE_RNG_WORDS_GRID, h->d_seeds, dmask, E, 1, nullptr);
+    if (replay_constructor) {
+      GridParams p = grid_params(h);
+      p.mask = dmask;
+      launch_feat_construct((int)h->cfg.kind, p, h->d_gparams, nullptr);
+    }
   } else {
     if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
     if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, CE_RNG_WORDS_GRID, h->d_seeds, dmask, E, 1, nullptr);
@@ -451,6 +480,10 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
     GridParams p = grid_params(h);
     p.mask = dmask;
     launch_grid_reset((int)h->cfg.kind, p, h->d_gparams, stream);
+  } else if (is_feat(h->cfg)) {
+    GridParams p = grid_params(h);
+    p.mask = dmask;
+    launch_feat_reset((int)h->cfg.kind, p, h->d_gparams, stream);
   } else {
     SdParams p = sd_params(h);
     p.mask = dmask;
@@ -470,6 +503,12 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
     p.env_first = env_begin;
     p.env_count = env_count;
     launch_grid_step((int)h->cfg.kind, p, h->d_gparams, stream);
+  } else if (is_feat(h->cfg)) {
+    GridParams p = grid_params(h);
+    p.actions = (const uint8_t*)actions;
+    p.env_first = env_begin;
+    p.env_count = env_count;
+    launch_feat_step((int)h->cfg.kind, p, h->d_gparams, stream);
   } else {
     SdParams p = sd_params(h);
     p.actions = (const float*)actions;
@@ -485,7 +524,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
 extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
   if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   const uint32_t E = h->cfg.num_envs;
-  const size_t plane = (size_t)E * h->cfg.num_agents * (is_grid(h->cfg) ? 1 : 4);
+  const size_t plane = (size_t)E * h->cfg.num_agents * (u8_actions(h->cfg) ? 1 : 4);
   for (uint32_t t = 0; t < num_steps; ++t) {
     const char* a_t = (const char*)actions + (size_t)t * plane;
     for (uint32_t s = 0; s < num_slices; ++s) {
@@ -506,7 +545,7 @@ extern "C" int ce_step_host(ce_handle h, const void* host_actions, const uint8_t
   if (!h || !host_actions) return CE_EINVAL;
   (void)hipSetDevice(h->cfg.device);
   const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
-  const size_t abytes = cnt * (is_grid(h->cfg) ? 1 : 4);
+  const size_t abytes = cnt * (u8_actions(h->cfg) ? 1 : 4);
   hipError_t e = hipMemcpyAsync(h->d_stage_actions, host_actions, abytes, hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e == hipSuccess && host_active) e = hipMemcpyAsync(h->d_stage_active, host_active, cnt, hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);  // host buffers are the caller's again
@@ -518,7 +557,9 @@ extern "C" int ce_synth_actions(ce_handle h, uint64_t key, uint32_t t0, uint32_t
   if (!h || !out || T == 0) return CE_EINVAL;
   (void)hipSetDevice(h->cfg.device);
   const ce_config& c = h->cfg;
-  if (is_grid(c)) {
+  if (is_feat(c)) {  // Discrete(7) / Discrete(8) action spaces of the feature envs
+    launch_synth_actions_u8((uint8_t*)out, key, c.env_index_base, c.num_envs, c.num_agents, t0, T, c.kind == CE_KIND_HARVEST_FEATURES ? 7 : 8, stream);
+  } else if (is_grid(c)) {
     const bool firing = c.flags & CE_FLAG_FIRING_ENABLED;
     const uint32_t na = c.kind == CE_KIND_CLEANUP ? (firing ? 9 : 8) : (firing ? 8 : 7);
     launch_synth_actions_u8((uint8_t*)out, key, c.env_index_base, c.num_envs, c.num_agents, t0, T, na, stream);

@@ -1807,6 +1807,703 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   CE_REALSTAMP(15);
 }
 
+// ========================================================================================
+// Feature-vector envs: HarvestFeatures (harvest_features.py:60-336) and CleanupFeatures
+// (cleanup_features.py:48-309), BASELINE config 0 / SURVEY §8f.1.  Same maps and static tables as the two grid
+// kinds, none of the MapEnv logic: moves are claimed in dict order (stayers first), apples / wastes are Python
+// lists whose ORDER matters (np.argmin ties), respawn doubles and the spawn shuffle come from CPython's `random`,
+// orientations from np.random.  One wave per env; lane a = agent a; lane c + 64 r = apple / waste cell c + 64 r.
+// ========================================================================================
+template <int GK> struct alignas(16) FeatLds {
+  u32 mt_py[kMtN];  // CPython `random` stream
+  u32 mt_np[kMtN];  // np.random stream (orientations, theta)
+  u32 U[320];       // tempered words of the respawn doubles of one spawn pass
+  uint8_t pmap[Geo<GK>::PCELLS];  // padded map: walls + apples / wastes currently present
+};
+constexpr u32 kAbsent = CE_FEAT_ABSENT;
+
+template <int GK> struct FEnv {
+  FeatLds<GK>* L;
+  Rng py, np;
+  u32 lane, n, e;
+  bool is_agent;
+  u32 P, O;         // lane a: padded cell, orientation
+  u32 AP[3], AS[3];  // lane c, round r: packed apple cell c + 64 r and its list stamp (kAbsent = not present)
+  u32 WC[2], WS[2];  // cleanup: waste cells and stamps
+  u32 next_a, next_w;
+};
+
+DEVINL void rng_bind(Rng& r, u32* mt, u32 pos) {
+  r.mt = mt;
+  r.pos = rfl(pos);
+  r.cbase = 0;
+  r.ccount = 0;
+  r.cvalid = 0;
+  r.cache = 0;
+}
+// skip k stream words (k <= 624); the twist is taken only when the position moves past the generation end
+DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
+  rng_assert_uniform(r);
+  u32 np_ = r.pos + k;
+  if (np_ > (u32)kMtN) {
+    mt_twist(r.mt, lane);
+    np_ -= (u32)kMtN;
+  }
+  r.pos = np_;
+  r.ccount = 0;
+}
+
+template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool with_state) {
+  typedef Geo<GK> G;
+  const GridTables& T = c_tab[GK];
+  const u32 lane = E.lane;
+  const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
+  for (u32 k = lane; k < (u32)kMtN; k += 64) {
+    E.L->mt_np[k] = rsrc[k];
+    E.L->mt_py[k] = rsrc[CE_RNG_WORDS_GRID + k];
+  }
+  rng_bind(E.np, E.L->mt_np, rsrc[kMtN]);
+  rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
+  const u32* bsrc = (const u32*)T.base_pmap;
+  u32* pm32 = (u32*)E.L->pmap;
+  for (u32 k = lane; k < (u32)G::PCELLS / 4; k += 64) pm32[k] = bsrc[k];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const u32 idx = lane + 64 * r;
+    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+    E.AS[r] = kAbsent;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const u32 idx = lane + 64 * r;
+    E.WC[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+    E.WS[r] = kAbsent;
+  }
+  E.next_a = E.next_w = 0;
+  E.P = 0xffffu;
+  E.O = 0;
+  if (with_state) {
+    const auto st = (CE_GPTR(const uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (lane + 64 * r < (u32)G::NAPPLE) E.AS[r] = st[lane + 64 * r];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (lane + 64 * r < (u32)G::NWASTE) E.WS[r] = st[CE_FEAT_APPLE_SLOTS + lane + 64 * r];
+    const auto cnt = (CE_GPTR(const u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
+    E.next_a = rfl(cnt[0]);
+    E.next_w = rfl(cnt[1]);
+    if (E.is_agent) {
+      const u32 w = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, lane);
+      E.P = pad_of<GK>(w & 0xff, (w >> 8) & 0xff);
+      E.O = (w >> 16) & 3;
+    }
+  }
+  wave_sync();
+}
+// presence map: apple / waste cells carry their code only while present
+template <int GK> DEVINL void feat_paint(FEnv<GK>& E) {
+  typedef Geo<GK> G;
+  uint8_t* pm = E.L->pmap;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (E.lane + 64 * r < (u32)G::NAPPLE) pm[cell_pad(E.AP[r])] = E.AS[r] != kAbsent ? CE_CELL_APPLE : CE_CELL_EMPTY;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (E.lane + 64 * r < (u32)G::NWASTE) pm[cell_pad(E.WC[r])] = E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER;
+  wave_sync();
+}
+template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
+  typedef Geo<GK> G;
+  const u32 lane = E.lane;
+  wave_sync();
+  const auto rdst = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
+  for (u32 k = lane; k < (u32)kMtN; k += 64) {
+    rdst[k] = E.L->mt_np[k];
+    rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
+  }
+  if (lane == 0) {
+    rdst[kMtN] = E.np.pos;
+    rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
+  }
+  const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (lane + 64 * r < CE_FEAT_APPLE_SLOTS) st[lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NAPPLE ? E.AS[r] : kAbsent);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (lane + 64 * r < CE_FEAT_WASTE_SLOTS)
+      st[CE_FEAT_APPLE_SLOTS + lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NWASTE ? E.WS[r] : kAbsent);
+  const auto cnt = (CE_GPTR(u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
+  if (lane == 0) {
+    cnt[0] = E.next_a;
+    cnt[1] = E.next_w;
+  }
+  if (E.is_agent) GAT((CE_GPTR(u32))p.agents + (size_t)E.e * E.n, lane) = row_of<GK>(E.P) | (col_of<GK>(E.P) << 8) | (E.O << 16);
+}
+
+// initialize_arrays: harvest starts with every apple, cleanup with no apple and the H cells as waste
+template <int GK> DEVINL void feat_init_arrays(FEnv<GK>& E) {
+  typedef Geo<GK> G;
+  const GridTables& T = c_tab[GK];
+  E.next_a = E.next_w = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) E.AS[r] = kAbsent;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) E.WS[r] = kAbsent;
+  if (GK == CE_KIND_HARVEST) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (E.lane + 64 * r < (u32)G::NAPPLE) E.AS[r] = E.lane + 64 * r;
+    E.next_a = (u32)G::NAPPLE;
+  } else {
+    u32 base = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {  // waste_start_points: the 'H' cells in row-major order
+      const bool h = E.lane + 64 * r < (u32)G::NWASTE && T.base_pmap[cell_pad(E.WC[r])] == CE_CELL_WASTE;
+      const u64 hb = ballot(h);
+      if (h) E.WS[r] = base + popc64(hb & ((1ull << E.lane) - 1ull));
+      base += popc64(hb);
+    }
+    E.next_w = base;
+  }
+}
+// initialize_players: random.shuffle(list(range(len(spawn_points)))) with CPython's _randbelow_with_getrandbits
+// (top bits of one word per attempt, k = (i + 1).bit_length()), then np.random.randint(0, 4) per agent
+template <int GK> DEVINL void feat_init_players(FEnv<GK>& E) {
+  const GridTables& T = c_tab[GK];
+  const u32 L = GK == CE_KIND_HARVEST ? 20u : 10u;
+  u32 IDX = E.lane;
+  for (u32 i = L - 1; i >= 1; --i) {
+    const u32 nn = i + 1, k = 32u - (u32)__builtin_clz(nn);
+    u32 r = rng_next(E.py, E.lane) >> (32 - k);
+    while (r >= nn) r = rng_next(E.py, E.lane) >> (32 - k);
+    const u32 vi = rdl(IDX, i), vj = rdl(IDX, r);
+    IDX = wrl(vj, i, IDX);
+    IDX = wrl(vi, r, IDX);
+  }
+  const u32 cell = T.spawn[IDX < 20 ? IDX : 0];
+  E.P = E.is_agent ? cell_pad(cell) : 0xffffu;
+  u32 o = 0;
+  for (u32 a = 0; a < E.n; ++a) {
+    const u32 w = rng_next(E.np, E.lane) & 3u;  // legacy randint(0, 4): one masked word
+    if (E.lane == a) o = w;
+  }
+  E.O = o;
+}
+
+// r < p for a double given as tempered words (a, b): exact 53-bit integer compare against ceil(p * 2^53)
+DEVINL bool dbl_below(u32 a, u32 b, u64 thr) { return ((((u64)(a >> 5)) << 26) | (u64)(b >> 6)) < thr; }
+
+template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
+  typedef Geo<GK> G;
+  const GridTables& T = c_tab[GK];
+  const u32 lane = E.lane;
+  const u64 lt = (1ull << lane) - 1ull;
+  uint8_t* pm = E.L->pmap;
+  constexpr int AR = (G::NAPPLE + 63) / 64;
+  // agent presence on apple cells: `apple_pos not in self.agent_pos.values()`
+  bool elig[AR];
+  u32 ri[AR];
+  u32 nelig = 0;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    bool on = false;
+    const u32 cell = cell_pad(E.AP[r]);
+    for (u32 a = 0; a < E.n; ++a) on = on || rdl(E.P, a) == cell;
+    elig[r] = lane + 64 * r < (u32)G::NAPPLE && E.AS[r] == kAbsent && !on;
+    const u64 eb = ballot(elig[r]);
+    ri[r] = nelig + popc64(eb & lt);
+    nelig += popc64(eb);
+  }
+  u64 thr_uniform = 0;
+  bool waste_on = false;
+  u32 nwaste = 0;
+  if (GK == CE_KIND_CLEANUP) {  // compute_probabilities on the current waste count (same constants as cleanup_new)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) nwaste += popc64(ballot(lane + 64 * r < (u32)G::NWASTE && E.WS[r] != kAbsent));
+    const u64 te = T.apple_thresh[nwaste];
+    waste_on = (te & kWasteOnBit) != 0;
+    thr_uniform = te & ~kWasteOnBit;
+  }
+  // every eligible cell consumes exactly one random.random(): temper the 2 * nelig words in stream order
+  rng_bulk(E.py, E.L->U, nullptr, 2 * nelig, 2 * nelig, false, lane);
+  bool spawn[AR];
+  if (GK == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) spawn[r] = elig[r] && dbl_below(E.L->U[2 * (elig[r] ? ri[r] : 0)], E.L->U[2 * (elig[r] ? ri[r] : 0) + 1], thr_uniform);
+  } else {
+    // spawn_apples (harvest_features.py:139-151): the neighbour count of a cell includes apples spawned EARLIER in
+    // this very loop (row-major order).  More neighbours never lower the probability, so iterating the parallel
+    // decision from "no new apples" upwards converges to the sequential result (the system is triangular).
+    u32 a_w[AR], b_w[AR];
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      a_w[r] = E.L->U[2 * (elig[r] ? ri[r] : 0)];
+      b_w[r] = E.L->U[2 * (elig[r] ? ri[r] : 0) + 1];
+      spawn[r] = false;
+    }
+    for (;;) {
+      bool changed = false;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        u32 num = 0;
+        if (elig[r]) {
+          const i32 cell = (i32)cell_pad(E.AP[r]);
+          // earlier cells in row-major order: the row above and the left neighbour see this pass's spawns
+#pragma unroll
+          for (int j = -1; j <= 1; ++j)
+#pragma unroll
+            for (int k = -1; k <= 1; ++k) {
+              const uint8_t c = pm[cell + j * G::PW + k];
+              const bool earlier = j < 0 || (j == 0 && k < 0);
+              num += (c == CE_CELL_APPLE || (earlier && c == 0x42)) ? 1u : 0u;
+            }
+        }
+        const bool s2 = elig[r] && dbl_below(a_w[r], b_w[r], T.apple_thresh[num < 3 ? num : 3]);
+        changed = changed || (s2 != spawn[r]);
+        spawn[r] = s2;
+      }
+      if (ballot(changed) == 0) break;
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        if (elig[r]) pm[cell_pad(E.AP[r])] = spawn[r] ? (uint8_t)0x42 : (uint8_t)CE_CELL_EMPTY;  // 0x42 = spawned in this pass
+      wave_sync();
+    }
+  }
+  // append in row-major order: stamps continue the list
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const u64 sb = ballot(spawn[r]);
+    if (spawn[r]) {
+      E.AS[r] = E.next_a + popc64(sb & lt);
+      pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
+    }
+    E.next_a += popc64(sb);
+  }
+  if (GK == CE_KIND_CLEANUP) {
+    // at most one waste: walk the absent waste cells in row-major order, one random.random() each, stop at the
+    // first r < p_waste (p_waste is 0.5 or 0: decided by the sign of the tempered first word, or never)
+    bool cand[2];
+    u32 tq[2], ncand = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      cand[r] = lane + 64 * r < (u32)G::NWASTE && E.WS[r] == kAbsent;
+      const u64 cb = ballot(cand[r]);
+      tq[r] = ncand + popc64(cb & lt);
+      ncand += popc64(cb);
+    }
+    u32 done = 0, hit = 0xffffffffu;  // candidates walked so far; index of the successful one
+    while (done < ncand && hit == 0xffffffffu) {
+      rng_assert_uniform(E.py);
+      if (E.py.pos >= (u32)kMtN) {
+        mt_twist(E.py.mt, lane);
+        E.py.pos = 0;
+      }
+      rng_refill(E.py, lane);  // cache = tempered words pos .. pos + ccount - 1 (nothing consumed yet)
+      const u32 vis = (E.py.ccount + 1) / 2;  // doubles whose first word is in the cache
+      const u32 take = ncand - done < vis ? ncand - done : vis;
+      u64 sb = 0;
+      if (waste_on) sb = ballot(lane < 2 * take && (lane & 1u) == 0 && (i32)E.py.cache >= 0);  // u < 0.5 <=> bit 31 clear
+      u32 used = take;
+      if (sb) {
+        used = ctz64(sb) / 2 + 1;
+        hit = done + used - 1;
+      }
+      rng_skip(E.py, 2 * used, lane);
+      done += used;
+    }
+    if (hit != 0xffffffffu) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (cand[r] && tq[r] == hit) {
+          E.WS[r] = E.next_w;
+          pm[cell_pad(E.WC[r])] = CE_CELL_WASTE;
+        }
+      E.next_w += 1;
+    }
+  }
+  wave_sync();
+}
+
+// apples within j^2 + k^2 <= 5 of a padded cell (uniform), current presence map
+template <int GK> DEVINL u32 feat_close_count(FEnv<GK>& E, u32 cell) {
+  const GridTables& T = c_tab[CE_KIND_HARVEST];
+  const bool v = E.lane < 21 && E.L->pmap[(i32)cell + (i32)T.close_off[E.lane < 21 ? E.lane : 0]] == CE_CELL_APPLE;
+  return popc64(ballot(v));
+}
+
+// feature vector (also the observation); closest apple / waste = min over (manhattan, list stamp)
+template <int GK> DEVINL u32 feat_features(FEnv<GK>& E, const GridParams& p, u32 cleaned) {
+  typedef Geo<GK> G;
+  const u32 lane = E.lane, n = E.n, nf = p.num_features;
+  const auto f = p.features + ((size_t)E.e * n + (E.is_agent ? lane : 0)) * nf;
+  const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos: a0 -> a1, everyone else -> a0 (inf - inf = nan argmin)
+  const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
+  const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
+  u32 napples = 0, nwastes = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) napples += popc64(ballot(lane + 64 * r < (u32)G::NAPPLE && E.AS[r] != kAbsent));
+#pragma unroll
+  for (int r = 0; r < 2; ++r) nwastes += popc64(ballot(lane + 64 * r < (u32)G::NWASTE && E.WS[r] != kAbsent));
+  u32 ca = 0, cw = 0, close_now = 0;
+  for (u32 a = 0; a < n; ++a) {
+    const u32 pa = rdl(E.P, a);
+    const u32 prc = col_of<GK>(pa) | row_of<GK>(pa) << 8;
+    u32 key = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (lane + 64 * r < (u32)G::NAPPLE && E.AS[r] != kAbsent) {
+        const u32 k2 = __builtin_amdgcn_sad_u8(cell_rc(E.AP[r]), prc, 0u) << 24 | E.AS[r] << 8 | (u32)r << 6 | lane;
+        key = k2 < key ? k2 : key;
+      }
+    const u32 best = wave_min_u32(key);
+    u32 rc = 0;
+    if (best != 0xffffffffu) {
+      const u32 src = best & 63u, rr = (best >> 6) & 3u;
+      const u32 c0 = rdl(E.AP[0], src), c1 = rdl(E.AP[1], src), c2 = rdl(E.AP[2], src);
+      rc = cell_rc(rr == 0 ? c0 : rr == 1 ? c1 : c2);
+    }
+    if (lane == a) ca = rc;
+    if (GK == CE_KIND_CLEANUP) {
+      u32 keyw = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (lane + 64 * r < (u32)G::NWASTE && E.WS[r] != kAbsent) {
+          const u32 k2 = __builtin_amdgcn_sad_u8(cell_rc(E.WC[r]), prc, 0u) << 24 | E.WS[r] << 8 | (u32)r << 6 | lane;
+          keyw = k2 < keyw ? k2 : keyw;
+        }
+      const u32 bw = wave_min_u32(keyw);
+      u32 rcw = 0;
+      if (bw != 0xffffffffu) {
+        const u32 src = bw & 63u;
+        const u32 c0 = rdl(E.WC[0], src), c1 = rdl(E.WC[1], src);
+        rcw = cell_rc(((bw >> 6) & 1u) ? c1 : c0);
+      }
+      if (lane == a) cw = rcw;
+    } else {
+      const u32 cnt = feat_close_count(E, pa);
+      if (lane == a) close_now = cnt;
+    }
+  }
+  if (E.is_agent) {
+    f[0] = (int16_t)row_of<GK>(E.P);
+    f[1] = (int16_t)col_of<GK>(E.P);
+    f[2] = (int16_t)E.O;
+    f[3] = (int16_t)row_of<GK>(cpp);
+    f[4] = (int16_t)col_of<GK>(cpp);
+    f[5] = (int16_t)cpo;
+    f[6] = (int16_t)(ca >> 8);
+    f[7] = (int16_t)(ca & 0xffu);
+  }
+  if (GK == CE_KIND_CLEANUP) {
+    if (E.is_agent) {
+      f[8] = (int16_t)(cw >> 8);
+      f[9] = (int16_t)(cw & 0xffu);
+      f[10] = (int16_t)napples;
+      f[11] = (int16_t)nwastes;
+    }
+    for (u32 b = 0; b < n; ++b) {
+      const u32 cb = rdl(cleaned, b);
+      if (E.is_agent) f[12 + b] = (int16_t)cb;
+    }
+  } else if (E.is_agent) {
+    f[8] = (int16_t)close_now;
+    f[9] = (int16_t)napples;
+    for (u32 b = 0; b < 2 * n; ++b) f[10 + b] = 0;
+  }
+  return close_now;
+}
+
+template <int GK> DEVINL bool feat_begin(FEnv<GK>& E, const GridParams& p, FeatLds<GK>* lds, u32 env_first, u32 env_end) {
+  E.lane = lane_id();
+  E.e = rfl(env_first + blockIdx.x);
+  E.n = p.n;
+  E.is_agent = E.lane < E.n;
+  E.L = lds;
+  return E.e < env_end;
+}
+template <int GK> DEVINL void feat_zero_outputs(FEnv<GK>& E, const GridParams& p) {
+  const u32 nmi = CE_MI_COUNT(E.n), nmf = CE_MF_COUNT(E.n);
+  for (u32 k = E.lane; k < nmi; k += 64) p.int_metrics[(size_t)E.e * nmi + k] = 0;
+  for (u32 k = E.lane; k < nmf; k += 64) p.f64_metrics[(size_t)E.e * nmf + k] = 0.0;
+  if (E.is_agent) {
+    const size_t ea = (size_t)E.e * E.n;
+    (p.base_reward + ea)[E.lane] = 0;
+    (p.reward + ea)[E.lane] = 0.0;
+    (p.info + 2 * ea)[2 * E.lane] = 0;
+    (p.info + 2 * ea)[2 * E.lane + 1] = 0;
+  }
+}
+// reset(): initialize_arrays, initialize_players, spawn, metrics, theta (wrapper), observation
+template <int GK> DEVINL void feat_reset_env(FEnv<GK>& E, const GridParams& p, double& theta) {
+  feat_init_arrays(E);
+  feat_init_players(E);
+  feat_paint(E);
+  feat_spawn(E);
+  theta = 0.0;
+  if (p.contract != CE_CONTRACT_NONE) {  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
+    const double u0 = rng_double(E.np, E.lane);
+    if (u0 > p.null_prob) {
+      const double u1 = rng_double(E.np, E.lane);
+      theta = p.contract_low + (p.contract_high - p.contract_low) * u1;
+    } else {
+      theta = p.contract_low;
+    }
+  }
+}
+
+template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+                                                                        const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+  const GridParams& p = *pp;
+  __shared__ FeatLds<GK> lds;
+  FEnv<GK> E;
+  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
+  if (call_mask && call_mask[E.e] == 0) return;
+  feat_load(E, p, false);
+  feat_init_arrays(E);  // __init__: initialize_arrays, (compute_probabilities), initialize_players
+  feat_init_players(E);
+  feat_zero_outputs(E, p);
+  feat_store(E, p);
+  if (E.lane == 0) {
+    p.timestep[E.e] = 0;
+    p.theta[E.e] = 0.0;
+    p.done[E.e] = 0;
+    p.error_flags[E.e] = 0;
+  }
+}
+
+template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+                                                                    const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+  const GridParams& p = *pp;
+  __shared__ FeatLds<GK> lds;
+  FEnv<GK> E;
+  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
+  if (call_mask && call_mask[E.e] == 0) return;
+  feat_load(E, p, false);
+  double theta;
+  feat_reset_env(E, p, theta);
+  feat_zero_outputs(E, p);
+  feat_features(E, p, 0u);
+  feat_store(E, p);
+  if (E.lane == 0) {
+    p.timestep[E.e] = 0;
+    p.theta[E.e] = theta;
+    p.done[E.e] = 0;
+    p.error_flags[E.e] = 0;
+  }
+}
+
+template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+                                                                   const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+  typedef Geo<GK> G;
+  const GridParams& p = *pp;
+  __shared__ FeatLds<GK> lds;
+  FEnv<GK> E;
+  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
+  const u32 lane = E.lane, n = E.n;
+  const size_t ea = (size_t)E.e * n;
+  constexpr bool harvest = GK == CE_KIND_HARVEST;
+  const u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + ea, lane) : 4u;
+  if (ballot(E.is_agent && ACT > (harvest ? 7u : 8u)) != 0) {
+    if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
+    return;
+  }
+  feat_load(E, p, true);
+  feat_paint(E);
+  uint8_t* pm = E.L->pmap;
+  u32 t = (u32)p.timestep[E.e];
+  double theta = p.theta[E.e];
+
+  // ---- move_squares: an insertion-ordered dict — stayers first, then movers in key order; a mover is refused by
+  // a wall or by any square claimed so far (harvest_features.py:176-196 / cleanup_features.py:165-183) ----
+  const bool stay = E.is_agent && (harvest ? ACT > 3 : ACT == 4);
+  const bool mover = E.is_agent && ACT < 4;
+  const i32 delta = ACT == 0 ? -1 : ACT == 1 ? 1 : ACT == 2 ? -(i32)G::PW : (i32)G::PW;  // MOVE_ACTIONS
+  const u32 tgt = mover ? (u32)((i32)E.P + delta) : E.P;
+  const bool wall = mover && pm[mover ? tgt : 0] == CE_CELL_WALL;
+  u32 SQ = E.P;
+  u64 has = ballot(stay);
+  for (u64 it = ballot(mover); it; it &= it - 1) {
+    const u32 a = ctz64(it);
+    const u32 ta = rdl(tgt, a);
+    const bool blocked = bit(ballot(wall), a) || (ballot(bit(has, lane) && SQ == ta) != 0);
+    if (lane == a && !blocked) SQ = ta;
+    has |= 1ull << a;
+  }
+  if (bit(has, lane)) E.P = SQ;
+  if (!E.is_agent) E.P = 0xffffu;
+
+  // ---- consume apples in move_squares order (stayers, then movers) ----
+  u32 rew = 0, eaten = 0, eaten_close = 0, cleaned = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (u64 it = pass == 0 ? ballot(stay) : ballot(mover); it; it &= it - 1) {
+      const u32 a = ctz64(it);
+      const u32 pa = rdl(E.P, a);
+      if (pm[pa] != CE_CELL_APPLE) continue;
+      u32 close = 0;
+      if (harvest) close = feat_close_count(E, pa);  // counted before the apple is removed
+      if (lane == a) {
+        rew += 1;
+        if (harvest) {
+          eaten += 1;
+          if (close < 4) eaten_close += 1;
+        }
+      }
+      wave_sync();
+      if (lane == 0) pm[pa] = CE_CELL_EMPTY;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (lane + 64 * r < (u32)G::NAPPLE && cell_pad(E.AP[r]) == pa) E.AS[r] = kAbsent;
+      wave_sync();
+    }
+  // ---- rotations ----
+  if (E.is_agent && (ACT == 5 || ACT == 6)) E.O = (E.O + (ACT == 5 ? 1u : 3u)) & 3u;
+  // ---- clean beams (cleanup act 7): three rays of 6 cells starting in the agent's own row, through waste, until a wall ----
+  if (!harvest) {
+    for (u64 it = ballot(E.is_agent && ACT == 7); it; it &= it - 1) {
+      const u32 a = ctz64(it);
+      const u32 o = rdl(E.O, a), p0 = rdl(E.P, a);
+      const i32 dd = dir_delta(G::PW, o), ss = dir_delta(G::PW, (o + 1) & 3);  // FIRE_DIRECTIONS[o], [(o+1)%4]
+      const u32 ray = lane / 6, j = lane - 6 * ray;
+      const bool in_beam = lane < 18;
+      const i32 start = (i32)p0 + (ray == 1 ? ss : ray == 2 ? -ss : 0);
+      const u32 cell = in_beam ? (u32)(start + (i32)j * dd) : 0u;
+      const uint8_t code = pm[cell];
+      const u64 wb = ballot(in_beam && code == CE_CELL_WALL);
+      const u32 rb = (u32)(wb >> (6 * ray)) & 63u;
+      const u32 first_wall = rb ? (u32)__builtin_ctz(rb) : 6u;
+      const bool hitw = in_beam && j < first_wall && code == CE_CELL_WASTE;
+      const u32 c = popc64(ballot(hitw));
+      if (lane == a) cleaned = c;
+      wave_sync();
+      if (hitw) pm[cell] = CE_CELL_RIVER;
+      for (u64 hw = ballot(hitw); hw; hw &= hw - 1) {
+        const u32 cw = rdl(cell, ctz64(hw));
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (lane + 64 * r < (u32)G::NWASTE && cell_pad(E.WC[r]) == cw) E.WS[r] = kAbsent;
+      }
+      wave_sync();
+    }
+  }
+  // ---- spawn, features ----
+  feat_spawn(E);
+  const u32 feat8 = feat_features(E, p, cleaned);
+  t += 1;
+  const bool done = t == p.horizon;
+  // ---- metrics (same layout as the grid kinds) ----
+  const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
+  const auto mi = p.int_metrics + (size_t)E.e * nmi;
+  const auto mf = p.f64_metrics + (size_t)E.e * nmf;
+  u32 sum_eaten = 0, sum_close = 0, sum_clean = 0, sum_rew = 0;
+  for (u32 b = 0; b < n; ++b) {
+    sum_eaten += rdl(eaten, b);
+    sum_close += rdl(eaten_close, b);
+    sum_clean += rdl(cleaned, b);
+    sum_rew += rdl(rew, b);
+  }
+  if (lane == 0) {
+    mi[CE_MI_TOTAL_APPLES_EATEN] += sum_eaten;
+    mi[CE_MI_RAW_ENV_REWARDS] += sum_rew;
+    mi[CE_MI_DIRT_CLEANED] += sum_clean;
+    mi[CE_MI_LOW_DENSITY_APPLES] += sum_close;
+  }
+  double rw = (double)rew;
+  long long m_sr = 0, m_str = 0;
+  double f_sr = 0.0, f_str = 0.0;
+  if (E.is_agent) {
+    mi[CE_MI_AGENT(n, CE_MIA_A, lane)] += harvest ? eaten : cleaned;
+    if (harvest) mi[CE_MI_AGENT(n, CE_MIA_B, lane)] += eaten_close;
+    m_sr = mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] + rew;
+    m_str = mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] + (long long)(t - 1) * rew;
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] = m_sr;
+    mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] = m_str;
+  }
+  if (p.contract != CE_CONTRACT_NONE) {  // SeparateContractEnv.step two_stage_train.py:62-121
+    double tr;
+    if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;
+    else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;
+    double total = 0.0;
+    const double share = tr / (double)(n - 1);
+    for (u32 i = 0; i < n; ++i) {
+      const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
+      if (lane == i) rw -= ti;
+      else rw += qi;
+      total += ti;
+    }
+    if (lane == 0) mf[CE_MF_TRANSFERS] += total;
+    if (E.is_agent) {
+      f_sr = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] + rw;
+      f_str = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] + (double)(t - 1) * rw;
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] = f_sr;
+      mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] = f_str;
+    }
+  }
+  if (E.is_agent) {
+    (p.base_reward + ea)[lane] = (i32)rew;
+    (p.reward + ea)[lane] = rw;
+    (p.info + 2 * ea)[2 * lane] = (uint8_t)eaten;
+    (p.info + 2 * ea)[2 * lane + 1] = (uint8_t)(harvest ? eaten_close : cleaned);
+  }
+  bool did_reset = false;
+  if (done) {  // compute_equality / compute_sustainability (+ the transferred versions of the wrapper)
+    const long long sr = E.is_agent ? m_sr : 0, str_ = E.is_agent ? m_str : 0;
+    long long eq = 0, total = 0;
+    for (u32 i = 0; i < n; ++i) {
+      const long long ri = shfl_i64(sr, i);
+      for (u32 j = 0; j < n; ++j) {
+        const long long d = ri - shfl_i64(sr, j);
+        eq += d < 0 ? -d : d;
+      }
+      total += ri;
+    }
+    const double ts = total == 0 ? 0.001 : (double)total;
+    const double equality = 1.0 - (double)eq / ((double)(2 * n) * ts);
+    const long long den = sr < 1 ? 1 : sr;
+    const double sust = np_sum_lanes((double)str_ / (double)den, n) / (double)n;
+    double teq = 0.0, tsust = 0.0;
+    if (p.contract != CE_CONTRACT_NONE) {
+      const double fr = E.is_agent ? f_sr : 0.0, ftr = E.is_agent ? f_str : 0.0;
+      double e2 = 0.0, tot = 0.0;
+      for (u32 i = 0; i < n; ++i) {
+        const double ri = shfl_f64(fr, i);
+        for (u32 j = 0; j < n; ++j) e2 += fabs(ri - shfl_f64(fr, j));
+        tot += ri;
+      }
+      if (tot == 0.0) tot = 0.001;
+      teq = 1.0 - e2 / ((double)(2 * n) * tot);
+      const double dn = fr > 1.0 ? fr : 1.0;
+      tsust = np_sum_lanes(ftr / dn, n) / (double)n;
+    }
+    if (lane == 0) {
+      mf[CE_MF_EQUALITY] = equality;
+      mf[CE_MF_SUSTAINABILITY] = sust;
+      mf[CE_MF_TRANSFER_EQUALITY] = teq;
+      mf[CE_MF_TRANSFER_SUSTAINABILITY] = tsust;
+    }
+    __threadfence_block();
+    for (u32 k = lane; k < nmi; k += 64) p.final_int_metrics[(size_t)E.e * nmi + k] = mi[k];
+    for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
+    if (p.flags & CE_FLAG_AUTO_RESET) {
+      __threadfence_block();
+      feat_reset_env(E, p, theta);
+      for (u32 k = lane; k < nmi; k += 64) p.int_metrics[(size_t)E.e * nmi + k] = 0;
+      for (u32 k = lane; k < nmf; k += 64) p.f64_metrics[(size_t)E.e * nmf + k] = 0.0;
+      t = 0;
+      did_reset = true;
+    }
+  }
+  feat_store(E, p);
+  if (lane == 0) {
+    p.timestep[E.e] = (i32)t;
+    p.done[E.e] = done ? 1 : 0;
+    if (did_reset) p.theta[E.e] = theta;
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // MT seeding: one thread per env (sequential recurrence), numpy init_genrand or CPython
 // init_by_array([seed])
@@ -1978,6 +2675,20 @@ static unsigned extra_lds() {
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+
+#define CE_LAUNCH_FEAT(kern)                                                                                    \
+  do {                                                                                                          \
+    const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;                       \
+    if (kind == CE_KIND_HARVEST_FEATURES)                                                                       \
+      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, p.actions,   \
+                         p.mask, first, first + count);                                                         \
+    else                                                                                                        \
+      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, p.actions,   \
+                         p.mask, first, first + count);                                                         \
+  } while (0)
+void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_construct); }
+void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_reset); }
+void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_step); }
 
 void launch_synth_actions_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions,
                              void* stream) {

@@ -18,7 +18,8 @@ CONTRACT_SPACE = {
     "harvest_local": (0.0, 10.0),
     "selfdrive_distprop": (0.0, 100.0),
 }
-NUM_ACTIONS = {("cleanup", False): 8, ("cleanup", True): 9, ("harvest", False): 7, ("harvest", True): 8}
+NUM_ACTIONS = {("cleanup", False): 8, ("cleanup", True): 9, ("harvest", False): 7, ("harvest", True): 8,
+               ("harvest_features", False): 7, ("cleanup_features", False): 8}
 
 _FIELD_DTYPES = {
     "grid": np.uint8, "agents": np.uint8, "spawn_perm": np.uint8, "waste_perm": np.uint8, "rng": np.uint32,
@@ -179,7 +180,7 @@ class BatchedEnv:
         out = np.empty((cnt,) + self._env_shape(field), _FIELD_DTYPES[field])
         check(self._L.ce_download(self._h, field.encode(), env_begin, cnt, out.ctypes.data, out.nbytes), self._h,
               "ce_download(%s)" % field)
-        if raw:
+        if raw or (field == "grid" and self.kind in _lib.FEAT_KINDS):  # feature kinds: the raw list-stamp block
             return out
         if field == "grid":  # bordered image -> dense [cnt, H, W]
             return np.ascontiguousarray(self._grid_interior(out))
@@ -214,8 +215,11 @@ class BatchedEnv:
 
     def state_dict(self):
         """host copy of every persistent field: stepping from a restored state is bit-identical"""
-        fields = self._STATE_SD if self.kind == "selfdrive" else [
-            f for f in self._STATE_GRID if not (f == "waste_perm" and self.kind != "cleanup")]
+        if self.kind in _lib.FEAT_KINDS:
+            fields = [f for f in self._STATE_GRID if f not in ("spawn_perm", "waste_perm")]
+        else:
+            fields = self._STATE_SD if self.kind == "selfdrive" else [
+                f for f in self._STATE_GRID if not (f == "waste_perm" and self.kind != "cleanup")]
         out = {f: self.download(f, raw=True) for f in fields}
         out["_meta"] = np.array([_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon],
                                 np.int64)
@@ -237,7 +241,17 @@ class BatchedEnv:
         with np.load(path) as z:
             self.load_state_dict({k: z[k] for k in z.files})
 
+    def feature_state(self):
+        """feature kinds: (apple_stamp u16 [E, 160], waste_stamp u16 [E, 120], next_stamp u32 [E, 2]) — the rank of each
+        present cell in the reference's current_apple_points / current_waste_points list, 0xffff = absent"""
+        st = self.download("grid", raw=True)
+        a, w = 2 * _lib.FEAT_APPLE_SLOTS, 2 * _lib.FEAT_WASTE_SLOTS
+        return (np.ascontiguousarray(st[:, :a]).view(np.uint16), np.ascontiguousarray(st[:, a:a + w]).view(np.uint16),
+                np.ascontiguousarray(st[:, a + w:]).view(np.uint32))
+
     def __getattr__(self, name):  # oracle-compatible attribute access = fresh host copy
+        if name in ("apple_stamp", "waste_stamp", "next_stamp") and self.__dict__.get("kind") in _lib.FEAT_KINDS:
+            return self.feature_state()[("apple_stamp", "waste_stamp", "next_stamp").index(name)]
         if name in _FIELD_DTYPES and "b" in self.__dict__:
             return self.download(name)
         raise AttributeError(name)
@@ -253,7 +267,10 @@ class BatchedEnv:
         """{field: object with __cuda_array_interface__} over the engine's HBM buffers"""
         b, E, n = self.b, self.E, self.n
         out = {}
-        if self.kind != "selfdrive":
+        if self.kind in _lib.FEAT_KINDS:
+            out["features"] = _DevArray(b.features, (E, n, b.num_features), np.int16, None, self)
+            out["base_reward"] = _DevArray(b.base_reward, (E, n), np.int32, None, self)
+        elif self.kind != "selfdrive":
             out["obs"] = _DevArray(b.obs, (E, n, 15, 15, 3), np.uint8, (b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, 3, 1), self)
             out["grid"] = _DevArray(b.grid + b.grid_origin, (E, b.grid_h, b.grid_w), np.uint8,
                                     (b.grid_env_stride, b.grid_row_stride, 1), self)
