@@ -1,0 +1,207 @@
+"""HarvestFeatures / CleanupFeatures — drop-ins for environments/harvest_features.py:60-336 and
+environments/cleanup_features.py:48-309 (the `harvest` / `cleanup` envs of the configs; BASELINE config 0), stepped
+by the HIP engine.  Same constructor kwargs, spaces, `reset()` / `step()` dictionaries keyed 'a0'..'a{n-1}',
+`metrics`, `compute_equality` / `compute_sustainability`.
+
+The reference draws the spawn shuffle and the respawn doubles from the process-global `random` and the
+orientations from the process-global `np.random`; with rng="global" (default) both generator states are handed to
+the engine before every call and installed again afterwards, so seeded scripts reproduce.
+
+`image_obs=True` (a crop of the reference's incrementally painted colour map) is not accelerated."""
+import numpy as np
+
+from .. import spaces
+from ..engine import BatchedEnv
+from .map_env import _Base, pull_global_rng, push_global_rng
+
+HARVEST_SHAPE, CLEANUP_SHAPE = (16, 38), (25, 18)
+N_APPLE = {"harvest_features": 155, "cleanup_features": 103}
+POTENTIAL_WASTE_AREA = 119
+
+
+class _FeatureEnv(_Base):
+    KIND = None
+    N_ACTIONS = None
+
+    def __init__(self, num_agents=2, horizon=1000, image_obs=False, rng="global", device=0, **kwargs):
+        if image_obs:
+            raise NotImplementedError("image_obs=True of the feature envs is not accelerated (feature vectors only)")
+        self.num_agents = num_agents
+        self.horizon = horizon
+        self.image_obs = image_obs
+        self.timesteps = 0
+        self._keys = ["a%d" % i for i in range(num_agents)]
+        self._rng_mode, self._device = rng, device
+        self._engine = None
+        self._contract = (None, None, None, 0.0)
+        self.metrics = {}
+        self._build_spaces()
+        self._call(self._ensure_engine().construct)  # __init__ shuffles the spawn points and draws orientations
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = BatchedEnv(self.KIND, 1, self.num_agents, horizon=self.horizon, device=self._device)
+            c, lo, hi, null_prob = self._contract
+            if c is not None:
+                self._engine.set_contract(c, lo, hi, null_prob)
+            pending = getattr(self, "_pending_state", None)
+            if pending:
+                for f, arr in pending.items():
+                    self._engine.upload(f, arr)
+                self._pending_state = None
+        return self._engine
+
+    _STATE_FIELDS = ("grid", "agents", "rng", "timestep", "theta", "int_metrics", "f64_metrics", "final_int_metrics",
+                     "final_f64_metrics")
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        eng = d.pop("_engine", None)
+        if eng is not None:
+            d["_pending_state"] = {f: eng.download(f, raw=True) for f in self._STATE_FIELDS}
+        d["_engine"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    def _call(self, fn, *args):
+        eng = self._ensure_engine()
+        if self._rng_mode == "global":
+            st = push_global_rng(eng, python_random=True)
+            fn(*args)
+            pull_global_rng(eng, st, python_random=True)
+        else:
+            fn(*args)
+
+    def seed(self, seed=None):
+        if self._rng_mode == "global":
+            import random
+            np.random.seed(seed)
+            random.seed(seed)
+        else:
+            self._ensure_engine().seed(np.array([0 if seed is None else seed], np.uint64), replay_constructor=False)
+
+    # ------------------------------------------------------------------ reference-visible state
+    @property
+    def agent_pos(self):
+        a = self._engine.download("agents")[0]
+        return {k: [int(a[i, 0]), int(a[i, 1])] for i, k in enumerate(self._keys)}
+
+    @property
+    def agent_orientation(self):
+        a = self._engine.download("agents")[0]
+        return {k: int(a[i, 2]) for i, k in enumerate(self._keys)}
+
+    def _feature_obs(self, keys):
+        f = self._engine.download("features")[0].astype(np.float64)
+        return {k: f[int(k[1:])].copy() for k in keys}
+
+    def _refresh_metrics(self, final):
+        eng, n = self._engine, self.num_agents
+        mi = eng.download("final_int_metrics" if final else "int_metrics")[0]
+        mf = eng.download("final_f64_metrics" if final else "f64_metrics")[0]
+        self.metrics = self._metrics_dict(mi, mf)
+        if final:
+            self.metrics["equality"], self.metrics["sustainability"] = float(mf[1]), float(mf[2])
+            if self._contract[0] is not None:
+                self.metrics["transfer_equality"], self.metrics["transfer_sustainability"] = float(mf[3]), float(mf[4])
+        # total_reward_dict holds per-step lists in the reference; the engine keeps the two sums the metrics need
+        self._sum_r = [int(mi[4 + 2 * n + i]) for i in range(n)]
+
+    def reset(self):
+        self._call(self._ensure_engine().reset)
+        self.timesteps = 0
+        self._refresh_metrics(False)
+        return self._feature_obs(self._keys)
+
+    def step(self, acts):
+        keys = list(acts.keys())
+        if keys != self._keys:
+            raise KeyError("the engine steps all %d agents; got actions for %s" % (self.num_agents, keys))
+        a = np.array([[int(acts[k]) for k in self._keys]], np.int64)
+        if a.min() < 0 or a.max() > self.N_ACTIONS:
+            raise IndexError("action out of range for %s" % type(self).__name__)
+        self._call(self._ensure_engine().step, a.astype(np.uint8))
+        eng = self._engine
+        self.timesteps += 1
+        done = bool(eng.download("done")[0])
+        base = eng.download("base_reward")[0]
+        info = eng.download("info")[0]
+        obs = self._feature_obs(keys)
+        rewards = {k: float(base[i]) for i, k in enumerate(self._keys)}
+        infos = self._infos(info, obs)
+        dones = {"__all__": done, "a0": done, "a1": done}
+        self._refresh_metrics(done)
+        return obs, rewards, dones, infos
+
+    def render(self):
+        pass
+
+    # the reference computes these from total_reward_dict lists; kept for interface parity on dicts of lists
+    def compute_equality(self, reward_dict):
+        eq, total_sum = 0, 0
+        reward_dict = {k: sum(v) for k, v in reward_dict.items()}
+        n = len(reward_dict.keys())
+        for i in reward_dict.keys():
+            for j in reward_dict.keys():
+                eq += abs(reward_dict[i] - reward_dict[j])
+            total_sum += reward_dict[i]
+        if total_sum == 0:
+            total_sum = 0.001
+        return 1 - eq / (2 * n * total_sum)
+
+    def compute_sustainability(self, reward_dict):
+        avg_times = []
+        for k in reward_dict.keys():
+            t_sum = sum(t * i for t, i in enumerate(reward_dict[k]))
+            avg_times.append(t_sum / max(sum(reward_dict[k]), 1))
+        return np.mean(avg_times)
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+
+class HarvestFeatures(_FeatureEnv):
+    KIND = "harvest_features"
+    N_ACTIONS = 7  # Discrete(7); the code path also accepts 7 (a fire action without effect)
+
+    def _build_spaces(self):
+        H, W = HARVEST_SHAPE
+        na = N_APPLE[self.KIND]
+        self.observation_space = spaces.Box(low=np.array([0.0] * (10 + 2 * self.num_agents)),
+                                            high=np.array([H, W, 4, H, W, 4, H, W, na + 1, na + 1] + [1] * (2 * self.num_agents)))
+        self.action_space = spaces.Discrete(7)
+        self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(7,))
+
+    def _metrics_dict(self, mi, mf):
+        return {"total_apples_eaten": int(mi[0]), "low_density_apples_eaten": int(mi[3]), "raw_env_rewards": float(mi[1]),
+                "transfers": float(mf[0]) if self._contract[0] is not None else 0}
+
+    def _infos(self, info, obs):
+        return {k: {"eaten_apples": int(info[i, 0]), "eaten_close_apples": int(info[i, 1]), "feature_obs": obs[k]}
+                for i, k in enumerate(self._keys)}
+
+
+class CleanupFeatures(_FeatureEnv):
+    KIND = "cleanup_features"
+    N_ACTIONS = 8  # Discrete(8); the code path also accepts 8 (a beam without effect)
+
+    def _build_spaces(self):
+        H, W = CLEANUP_SHAPE
+        self.potential_waste_area = POTENTIAL_WASTE_AREA
+        self.observation_space = spaces.Box(low=np.array([0.0] * (12 + self.num_agents)),
+                                            high=np.array([H, W, 4, H, W, 4, H, W, H, W, N_APPLE[self.KIND] + 1,
+                                                           self.potential_waste_area + 1] + [np.inf] * self.num_agents))
+        self.action_space = spaces.Discrete(8)
+        self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(8,))
+
+    def _metrics_dict(self, mi, mf):
+        return {"dirt_cleaned": int(mi[2]), "raw_env_rewards": float(mi[1]),
+                "transfers": float(mf[0]) if self._contract[0] is not None else 0}
+
+    def _infos(self, info, obs):
+        return {k: {"cleaned_squares": int(info[i, 1])} for i, k in enumerate(self._keys)}

@@ -1,6 +1,7 @@
 """Registry: the reference's env tags (utils/env_creator_functions.py:12-60) -> HIP-backed classes.
 `register_env` is called when RLlib is importable, so `runner.py`-style configs resolve to these."""
 from ..environments.cleanup_new import CleanupEnv
+from ..environments.feature_envs import CleanupFeatures, HarvestFeatures
 from ..environments.harvest_new import HarvestEnv
 from ..environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
 from ..environments.two_stage_train import SeparateContractSubgameStage
@@ -10,9 +11,11 @@ _ACCELERATED = {
     "HarvestNew": HarvestEnv,
     "CleanupNew": CleanupEnv,
     "ContractWrapperSubgame": SeparateContractSubgameStage,
+    "Harvest": HarvestFeatures,   # `harvest`: the feature-vector env of BASELINE config 0 (harvest_features.py)
+    "Cleanup": CleanupFeatures,   # `cleanup` (cleanup_features.py)
 }
-# tags of the reference that are callers of the hot path or legacy envs, not the path itself
-_OUT_OF_SCOPE = ("Harvest", "Cleanup", "ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver", "JointEnv")
+# tags of the reference that are callers of the hot path, not the path itself
+_OUT_OF_SCOPE = ("ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver", "JointEnv")
 
 
 def env_creator(name, config):

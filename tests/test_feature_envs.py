@@ -64,3 +64,59 @@ def test_engine_feature_rollout_vs_oracle(kind, n, contract, horizon):
             assert ok, "field %s differs at step %d (envs %s)" % (f, t, np.nonzero((x != y).reshape(E, -1).any(axis=1))[0][:6])
     env.close()
     orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["feat_harvest_n2", "feat_cleanup_n5", "feat_harvest_n8_nocontract"])
+def test_feature_adapter_trace(name):
+    """the drop-in classes through their reference-shaped dict API, process-global `random` / `np.random` fidelity"""
+    import hashlib
+    import random
+    from contracts_amd.contract import contract_list
+    from contracts_amd.environments.feature_envs import CleanupFeatures, HarvestFeatures
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    g = gc.load(name)
+    kind, n, kw = gc.feat_kwargs(g)
+    seed = int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    if kind == "harvest_features":
+        env, con = HarvestFeatures(num_agents=n, horizon=kw["horizon"]), contract_list.HarvestFeaturemodLocalContract(n)
+    else:
+        env, con = CleanupFeatures(num_agents=n, horizon=kw["horizon"]), contract_list.CleanupContract(n)
+    top = SeparateContractSubgameStage(env, con, n, False) if kw["contract"] else env
+    keys = ["a%d" % i for i in range(n)]
+    nfeat = g["feature_obs"].shape[2]
+
+    def fps():
+        st, ps = np.random.get_state(), random.getstate()[1]
+        return ((int(st[2]), int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16)),
+                (int(ps[624]), int(hashlib.sha256(np.array(ps[:624], np.uint32).tobytes()).hexdigest()[:8], 16)))
+
+    assert fps() == (tuple(int(x) for x in g["ctor_mt_np"]), tuple(int(x) for x in g["ctor_mt_py"]))
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    steps = 160
+    for ep in range(len(g["ep_start"])):
+        o = top.reset()
+        assert fps() == (tuple(int(x) for x in g["reset_mt_np"][ep]), tuple(int(x) for x in g["reset_mt_py"][ep]))
+        for i, k in enumerate(keys):
+            assert np.array_equal(np.asarray(o[k])[:nfeat], g["reset_obs"][ep][i])
+            if kw["contract"]:
+                assert np.array_equal(np.asarray(o[k])[nfeat:], [g["theta"][ep], 0.0])
+        truncated = False
+        for t in range(ep_start[ep], min(ep_start[ep + 1], ep_start[ep] + steps)):
+            acts = {k: int(g["actions"][t][i]) for i, k in enumerate(keys)}
+            o, r, d, info = top.step(acts)
+            assert set(d.keys()) == {"__all__", "a0", "a1"} and d["__all__"] == bool(g["done"][t])
+            for i, k in enumerate(keys):
+                assert np.array_equal(np.asarray(o[k])[:nfeat], g["feature_obs"][t][i]), (t, k)
+                np.testing.assert_allclose(r[k], g["rew"][t][i], rtol=0, atol=1e-9)
+                if kind == "harvest_features":
+                    assert info[k]["eaten_apples"] == g["info0"][t][i] and info[k]["eaten_close_apples"] == g["info1"][t][i]
+                else:
+                    assert info[k]["cleaned_squares"] == g["info1"][t][i]
+            assert fps() == (tuple(int(x) for x in g["mt_np"][t]), tuple(int(x) for x in g["mt_py"][t])), t
+            truncated = t + 1 < ep_start[ep + 1]
+        if truncated:
+            break
+    env.close()
