@@ -9,6 +9,10 @@ import torch
 from contracts_amd.engine import BatchedEnv
 
 CONFIGS = [
+    # BASELINE config 0 (the reference's CPU plumbing case) batched: algorithmic bytes = list stamps + agents + accumulators
+    # read and written once, int16 feature rows, rewards, infos (same accounting as SURVEY §8d)
+    ("C1 harvest (HarvestFeatures) n=2 + HarvestFeaturemodLocalContract, 16384 envs", "harvest_features", 2, 16384, "harvest_local", 887),
+    ("C1b cleanup (CleanupFeatures) n=2 + CleanupContract, 16384 envs", "cleanup_features", 2, 16384, "cleanup", 1155),
     ("C2 cleanup_new n=4 + CleanupContract, 4096 envs", "cleanup", 4, 4096, "cleanup", 4211),
     ("C3 harvest_new n=8 + HarvestFeaturemodLocalContract, 16384 envs", "harvest", 8, 16384, "harvest_local", 7313),
     ("C4 cleanup_new n=8 + CleanupContract, 16384 envs (headline)", "cleanup", 8, 16384, "cleanup", 7235),
