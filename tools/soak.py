@@ -14,12 +14,13 @@ FIELDS = ["grid", "agents", "spawn_perm", "rng", "timestep", "theta", "obs", "ba
 t_end = time.time() + budget
 runs = steps_total = 0
 while time.time() < t_end:
-    kind = rs.choice(["cleanup", "harvest"])
-    n = int(rs.randint(1, 10))
-    firing = bool(rs.randint(2))
-    contract = None if rs.rand() < 0.3 else ("cleanup" if kind == "cleanup" else "harvest_local")
-    inequity = n > 1 and rs.rand() < 0.15
-    collective = (not inequity) and rs.rand() < 0.15
+    kind = rs.choice(["cleanup", "harvest", "cleanup", "harvest", "cleanup_features", "harvest_features"])
+    feat = kind.endswith("_features")
+    n = int(rs.randint(2 if feat else 1, 10))
+    firing = bool(rs.randint(2)) and not feat
+    contract = None if rs.rand() < 0.3 else ("cleanup" if kind.startswith("cleanup") else "harvest_local")
+    inequity = n > 1 and rs.rand() < 0.15 and not feat
+    collective = (not inequity) and rs.rand() < 0.15 and not feat
     horizon = int(rs.choice([7, 23, 60, 1000]))
     E = int(rs.choice([65, 128, 300]))
     kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, collective=collective, inequity=inequity,
@@ -29,9 +30,11 @@ while time.time() < t_end:
     for o in (env, orc):
         o.seed(seeds)
         o.reset()
-    na = env.num_actions
+    na = env.num_actions + (1 if feat else 0)  # the feature envs' code paths accept one more (effect-free) action
     p = rs.dirichlet(np.ones(na) * rs.choice([0.3, 1.0, 5.0]))
     fields = FIELDS + (["waste_perm"] if kind == "cleanup" else [])
+    if feat:
+        fields = [f for f in FIELDS if f not in ("spawn_perm", "obs")]
     T = int(rs.choice([40, 120]))
     ok = True
     for t in range(T):
@@ -39,9 +42,9 @@ while time.time() < t_end:
         env.step(a)
         orc.step(a)
         for f in fields:
-            x, y = env.download(f), getattr(orc, f)
+            x, y = (env.download(f, raw=True) if feat and f == "grid" else env.download(f)), getattr(orc, f)
             if f == "rng":
-                x, y = x[:, :625], y[:, :625]
+                x, y = x.reshape(E, -1, 628)[:, :, :625], y.reshape(E, -1, 628)[:, :, :625]
             same = np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
             if not same:
                 bad = np.nonzero((x != y).reshape(E, -1).any(axis=1))[0]
