@@ -250,17 +250,12 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
       static GridTables t0, t1;
       build_tables<CE_KIND_CLEANUP>(t0);
       build_tables<CE_KIND_HARVEST>(t1);
-      std::vector<uint16_t> pix(kMaxGridAgents * kPixPerAgent + 7, 0xF000);
-      for (int q = 0; q < kMaxGridAgents * kPixPerAgent; ++q) {
-        const int a = q / kPixPerAgent, pq = q % kPixPerAgent;
-        pix[q] = (uint16_t)(a << 8 | (pq / kWin) << 4 | (pq % kWin));
-      }
       const uint32_t lut[16] = {rgb(0, 0, 0),       rgb(180, 180, 180), rgb(0, 255, 0),     rgb(99, 156, 194),
                                 rgb(113, 75, 24),   rgb(113, 75, 24),   rgb(0, 0, 255),     rgb(2, 81, 154),
                                 rgb(204, 0, 204),   rgb(216, 30, 54),   rgb(254, 151, 0),   rgb(100, 255, 255),
                                 rgb(99, 99, 255),   rgb(250, 204, 255), rgb(238, 223, 16),  0};
-      if (upload_grid_tables(CE_KIND_CLEANUP, t0, pix.data(), (int)pix.size(), lut) ||
-          upload_grid_tables(CE_KIND_HARVEST, t1, pix.data(), (int)pix.size(), lut))
+      if (upload_grid_tables(CE_KIND_CLEANUP, t0, lut) ||
+          upload_grid_tables(CE_KIND_HARVEST, t1, lut))
         rc = fail(h, CE_ENODEV, "constant table upload failed");
     }
   }

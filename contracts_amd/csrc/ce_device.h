@@ -124,7 +124,7 @@ struct SdParams {
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
-int upload_grid_tables(int kind, const GridTables& t, const uint16_t* pix, int npix, const uint32_t* rgb16);
+int upload_grid_tables(int kind, const GridTables& t, const uint32_t* rgb16);
 void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,
                     const uint8_t* mask_dev, uint32_t E, int python_seeding, void* stream);
 // `p` carries the per-call pointers (actions / mask) and the batch size; `dp` is the device-resident copy of

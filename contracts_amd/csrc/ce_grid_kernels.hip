@@ -36,7 +36,6 @@ typedef int32_t i32;
 #define DEVINL __device__ __forceinline__
 
 __constant__ GridTables c_tab[2];
-__constant__ __attribute__((aligned(16))) uint16_t c_pix[kMaxGridAgents * kPixPerAgent + 7];  // env-wide pixel -> agent<<8 | i<<4 | j
 __constant__ u32 c_rgb[16];                                       // colour LUT, 0x00BBGGRR
 
 // ----------------------------------------------------------------------------------------
@@ -550,7 +549,6 @@ template <int KIND> struct alignas(16) WaveLds {
   u32 U[Geo<KIND>::UWORDS];
   uint8_t S[Geo<KIND>::SBYTES];
   uint8_t pmap[Geo<KIND>::PCELLS];
-  u32 view[12];  // per agent: o0 | A << 16 | B << 24 of the crop address off = o0 + i*A + j*B
   u32 rgb[16];
 };
 
@@ -1831,6 +1829,7 @@ template <int GK> struct FEnv {
   u32 AP[3], AS[3];  // lane c, round r: packed apple cell c + 64 r and its list stamp (kAbsent = not present)
   u32 WC[2], WS[2];  // cleanup: waste cells and stamps
   u32 next_a, next_w;
+  bool np_loaded;
 };
 
 DEVINL void rng_bind(Rng& r, u32* mt, u32 pos) {
@@ -1853,16 +1852,22 @@ DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
   r.ccount = 0;
 }
 
+// the np.random stream is only drawn from by resets: a plain step neither loads nor stores it
+template <int GK> DEVINL void feat_load_np(FEnv<GK>& E, const GridParams& p) {
+  const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
+  for (u32 k = E.lane; k < (u32)kMtN; k += 64) E.L->mt_np[k] = rsrc[k];
+  rng_bind(E.np, E.L->mt_np, rsrc[kMtN]);
+  E.np_loaded = true;
+  wave_sync();
+}
 template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool with_state) {
   typedef Geo<GK> G;
   const GridTables& T = c_tab[GK];
   const u32 lane = E.lane;
   const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  for (u32 k = lane; k < (u32)kMtN; k += 64) {
-    E.L->mt_np[k] = rsrc[k];
-    E.L->mt_py[k] = rsrc[CE_RNG_WORDS_GRID + k];
-  }
-  rng_bind(E.np, E.L->mt_np, rsrc[kMtN]);
+  for (u32 k = lane; k < (u32)kMtN; k += 64) E.L->mt_py[k] = rsrc[CE_RNG_WORDS_GRID + k];
+  E.np_loaded = false;
+  rng_bind(E.np, E.L->mt_np, 0);
   rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
   const u32* bsrc = (const u32*)T.base_pmap;
   u32* pm32 = (u32*)E.L->pmap;
@@ -1918,13 +1923,11 @@ template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
   const u32 lane = E.lane;
   wave_sync();
   const auto rdst = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  for (u32 k = lane; k < (u32)kMtN; k += 64) {
-    rdst[k] = E.L->mt_np[k];
-    rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
-  }
-  if (lane == 0) {
-    rdst[kMtN] = E.np.pos;
-    rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
+  for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
+  if (lane == 0) rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
+  if (E.np_loaded) {
+    for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[k] = E.L->mt_np[k];
+    if (lane == 0) rdst[kMtN] = E.np.pos;
   }
   const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
 #pragma unroll
@@ -2263,6 +2266,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const G
   if (!feat_begin(E, p, &lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
   feat_load(E, p, false);
+  feat_load_np(E, p);
   feat_init_arrays(E);  // __init__: initialize_arrays, (compute_probabilities), initialize_players
   feat_init_players(E);
   feat_zero_outputs(E, p);
@@ -2283,6 +2287,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   if (!feat_begin(E, p, &lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
   feat_load(E, p, false);
+  feat_load_np(E, p);
   double theta;
   feat_reset_env(E, p, theta);
   feat_zero_outputs(E, p);
@@ -2489,6 +2494,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
     for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
     if (p.flags & CE_FLAG_AUTO_RESET) {
       __threadfence_block();
+      feat_load_np(E, p);
       feat_reset_env(E, p, theta);
       for (u32 k = lane; k < nmi; k += 64) p.int_metrics[(size_t)E.e * nmi + k] = 0;
       for (u32 k = lane; k < nmf; k += 64) p.f64_metrics[(size_t)E.e * nmf + k] = 0.0;
@@ -2638,9 +2644,8 @@ __global__ void k_selftest(u32* out) {
 // ----------------------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------------------
-int upload_grid_tables(int kind, const GridTables& t, const uint16_t* pix, int npix, const u32* rgb16) {
+int upload_grid_tables(int kind, const GridTables& t, const u32* rgb16) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(GridTables), sizeof(GridTables) * kind) != hipSuccess) return -1;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_pix), pix, sizeof(uint16_t) * npix) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_rgb), rgb16, sizeof(u32) * 16) != hipSuccess) return -1;
   return 0;
 }
