@@ -389,6 +389,54 @@ template <bool TWO, int MODE = 0> DEVINL void shuffle_core(Rng& r, u32& L0, u32&
   L0 = l0;
   L1 = l1;
 }
+// The same walk for a list of at most 64 items held in one register, written as ONE flat loop (one exit, the
+// cache refill as a rare `continue`): the nested form above costs ~17 scalar instructions per draw in compiler
+// generated flag shuffling, this one ~10.  MODE as in shuffle_core.
+template <int MODE> DEVINL void shuffle_small(Rng& r, u32& L0, u32 len, u32 lane) {
+  if (len < 2) return;
+  rng_assert_uniform(r);
+  u32 i = rfl(len) - 1;
+  u32 l0 = L0;
+  u32 off = r.pos - r.cbase;
+  if (off >= r.ccount) {
+    rng_refill(r, lane);
+    off = 0;
+  }
+  u64 avail = r.cvalid & (~0ull << off);  // unread words of the cache
+  u32 nb = 1u << (31 - __builtin_clz(i));  // lowest index of the current mask segment
+  u32 v = r.cache & (2 * nb - 1);
+  for (;;) {
+    const u64 hit = ballot(v <= i) & avail;
+    if (hit == 0) {  // every remaining cached word is a rejected attempt for this i
+      r.pos = r.cbase + r.ccount;
+      rng_refill(r, lane);
+      avail = r.cvalid;
+      v = r.cache & (2 * nb - 1);
+      continue;
+    }
+    const u32 k = ctz64(hit);
+    avail &= (~1ull) << k;  // the words before k were rejected attempts, k is consumed
+    if (MODE == 1) {        // collect J[i] in lane i
+      l0 = wrl(rdl(v, k), i, l0);
+    } else if (MODE == 0) {
+      const u32 j = rdl(v, k);
+      const u32 vi = rdl(l0, i), vj = rdl(l0, j);
+      l0 = wrl(vj, i, l0);
+      l0 = wrl(vi, j, l0);
+    }
+    if (i == nb) {  // segment done: the next index uses the next smaller mask
+      if (i == 1) {
+        r.pos = r.cbase + k + 1;
+        break;
+      }
+      nb >>= 1;
+      v = r.cache & (2 * nb - 1);
+    }
+    --i;
+  }
+  L0 = l0;
+}
+
 // Lanes below `lane` that are set in a wave-uniform 64-bit mask (v_mbcnt)
 DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
@@ -444,8 +492,8 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
     if (v <= (i32)idx && a < used) J[idx] = (u32)v;
     i0 -= used;
   }
-  u32 JL = 0, dummy = 0;
-  shuffle_core<false, 1>(r, JL, dummy, i0 + 1, lane);
+  u32 JL = 0;
+  shuffle_small<1>(r, JL, i0 + 1, lane);
   if (lane >= 1 && lane <= i0) J[lane] = JL;
   wave_sync();
 }
@@ -537,8 +585,7 @@ DEVINL void shuffle_apply_par(u32& L0, u32& L1, u32 len, u32* scratch, u32 lane)
 }
 
 DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
-  u32 dummy = 0;
-  shuffle_core<false>(r, L0, dummy, len, lane);
+  shuffle_small<0>(r, L0, len, lane);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -802,8 +849,8 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
     const bool ma = ((mlo >> a) & 1u) != 0, mb = ((mlo >> b) & 1u) != 0;
     const bool clash = ma && a != b && b < E.n && (ta == pb || (mb && ta == tb));
     if (ballot(clash) == 0) {
-      u32 d0 = 0, d1 = 0;
-      shuffle_core<false, 2>(E.rng, d0, d1, m, lane);
+      u32 d0 = 0;
+      shuffle_small<2>(E.rng, d0, m, lane);
       if (mover) E.P = TGT0;
       return;
     }
@@ -1196,7 +1243,11 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
     d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
     d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
+#ifdef CE_ABLATE_OBSSTORE  // traffic experiment: the pixels are computed but not written
+    asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
+#else
     if (lane < 60) *(CE_GPTR(uint3))(dst + voff) = d;
+#endif
   }
 }
 
@@ -1608,8 +1659,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 #endif
       shuffle_lanes1(E.rng, IDS, n, lane);
     } else {
-      u32 d0 = 0, d1 = 0;
-      shuffle_core<false, 2>(E.rng, d0, d1, n, lane);  // same stream words, no swaps
+      u32 d0 = 0;
+      shuffle_small<2>(E.rng, d0, n, lane);  // same stream words, no swaps
     }
     if (firing != 0) {
       // positions of the shuffled list that hold a firing agent, visited in list order
@@ -1681,16 +1732,16 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     }
     transfers_total = total;
   }
-  // metric accumulators (loaded after the feature pass and the transfer arithmetic: holding them across either costs an occupancy step)
+  // ---------------- running metrics: read-modify-write only the rows this step really changes ----------------
+  // (most steps add zero to every accumulator; the rows are 64 B each, ~0.8 KB of traffic per env-step if touched
+  // blindly.  The done step needs the per-agent sums for equality / sustainability and loads them regardless.)
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
   const auto mi = p.int_metrics + (size_t)E.e * nmi;
   const auto mf = p.f64_metrics + (size_t)E.e * nmf;
-  const u32 la = E.is_agent ? lane : 0;
-  long long m_a = GAT(mi, CE_MI_AGENT(n, CE_MIA_A, la)), m_b = GAT(mi, CE_MI_AGENT(n, CE_MIA_B, la));
-  long long m_sr = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, la)), m_str = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, la));
-  double f_sr = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, la)), f_str = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, la));
-  long long g_m = lane < 4 ? GAT(mi, lane < 4 ? lane : 0) : 0;  // lane k < 4 holds global metric k
-  double f_transfers = mf[CE_MF_TRANSFERS];
+  const bool done = t == p.horizon;
+  const u32 inc_a = KIND == CE_KIND_CLEANUP ? cleaned : eaten;
+  long long m_sr = 0, m_str = 0;
+  double f_sr = 0.0, f_str = 0.0;
   CE_STAMP(6);
   {
     // eaten / eaten_close are 0/1 flags; cleaned and the base rewards are zero for most agents
@@ -1698,32 +1749,40 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     u32 sum_clean = 0;
     i32 sum_rew = 0;
     for (u64 it = ballot(cleaned != 0); it; it &= it - 1) sum_clean += rdl(cleaned, ctz64(it));
-    for (u64 it = ballot(E.is_agent && base_rew != 0); it; it &= it - 1) sum_rew += shfl_i32(base_rew, ctz64(it));
-    if (lane == CE_MI_TOTAL_APPLES_EATEN) g_m += sum_eaten;
-    if (lane == CE_MI_RAW_ENV_REWARDS) g_m += sum_rew;
-    if (lane == CE_MI_DIRT_CLEANED && KIND == CE_KIND_CLEANUP) g_m += sum_clean;
-    if (lane == CE_MI_LOW_DENSITY_APPLES && KIND == CE_KIND_HARVEST) g_m += sum_close;
-    m_a += KIND == CE_KIND_CLEANUP ? cleaned : eaten;
-    if (KIND == CE_KIND_HARVEST) m_b += eaten_close;
-    m_sr += base_rew;
-    m_str += (long long)(t - 1) * base_rew;
+    const u64 rew_lanes = ballot(E.is_agent && base_rew != 0);
+    for (u64 it = rew_lanes; it; it &= it - 1) sum_rew += shfl_i32(base_rew, ctz64(it));
+    if ((sum_eaten | sum_close | sum_clean) != 0 || sum_rew != 0) {
+      if (lane < 4) {
+        long long g_m = GAT(mi, lane);  // lane k < 4 holds global metric k
+        if (lane == CE_MI_TOTAL_APPLES_EATEN) g_m += sum_eaten;
+        if (lane == CE_MI_RAW_ENV_REWARDS) g_m += sum_rew;
+        if (lane == CE_MI_DIRT_CLEANED && KIND == CE_KIND_CLEANUP) g_m += sum_clean;
+        if (lane == CE_MI_LOW_DENSITY_APPLES && KIND == CE_KIND_HARVEST) g_m += sum_close;
+        GAT(mi, lane) = g_m;
+      }
+    }
+    if (ballot(inc_a != 0) != 0 && E.is_agent) GAT(mi, CE_MI_AGENT(n, CE_MIA_A, lane)) += inc_a;
+    if (KIND == CE_KIND_HARVEST && ballot(eaten_close != 0) != 0 && E.is_agent) GAT(mi, CE_MI_AGENT(n, CE_MIA_B, lane)) += eaten_close;
+    if ((rew_lanes != 0 || done) && E.is_agent) {
+      m_sr = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) + base_rew;
+      m_str = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) + (long long)(t - 1) * base_rew;
+      if (rew_lanes != 0) {
+        GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) = m_sr;
+        GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) = m_str;
+      }
+    }
   }
   if (p.contract != CE_CONTRACT_NONE) {
-    f_transfers += transfers_total;
-    f_sr += rew;
-    f_str += (double)(t - 1) * rew;
-  }
-  const bool done = t == p.horizon;
-  // running metrics back to HBM
-  if (lane < 4) GAT(mi, lane) = g_m;
-  if (lane == 0) mf[CE_MF_TRANSFERS] = f_transfers;
-  if (E.is_agent) {
-    GAT(mi, CE_MI_AGENT(n, CE_MIA_A, lane)) = m_a;
-    GAT(mi, CE_MI_AGENT(n, CE_MIA_B, lane)) = m_b;
-    GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) = m_sr;
-    GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) = m_str;
-    GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) = f_sr;
-    GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) = f_str;
+    if (transfers_total != 0.0 && lane == 0) mf[CE_MF_TRANSFERS] += transfers_total;
+    const bool any_rew = ballot(E.is_agent && rew != 0.0) != 0;  // adding +-0.0 leaves the (never -0.0) sums unchanged
+    if ((any_rew || done) && E.is_agent) {
+      f_sr = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) + rew;
+      f_str = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) + (double)(t - 1) * rew;
+      if (any_rew) {
+        GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) = f_sr;
+        GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) = f_str;
+      }
+    }
   }
   if (E.is_agent) {
     GAT(p.base_reward + ea, lane) = base_rew;
