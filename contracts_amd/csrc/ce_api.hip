@@ -215,8 +215,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     const bool cl = cfg->kind == CE_KIND_CLEANUP;
     b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
     b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
-    h->grid_stride = cl ? Geo<0>::GRID_STRIDE : Geo<1>::GRID_STRIDE;
-    b.grid_env_stride = h->grid_stride;
+    h->grid_stride = cl ? Geo<0>::IMAGE_STRIDE : Geo<1>::IMAGE_STRIDE;  // of the ce_download / ce_upload image
+    b.grid_env_stride = kGridStateBytes;                                  // of the packed state `grid` points to
     b.grid_row_stride = cl ? Geo<0>::PW : Geo<1>::PW;
     b.grid_origin = kView * b.grid_row_stride + kView;
     b.obs_row_stride = kObsRowStride;
@@ -224,7 +224,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     b.obs_env_stride = (uint32_t)(n * kObsAgentStride);
     b.num_features = (uint32_t)(cl ? 12 + n : 10 + 2 * n);
     b.rng_words = CE_RNG_WORDS_GRID;
-    A(grid, E * h->grid_stride);
+    A(grid, E * kGridStateBytes);
     A(agents, E * n * 4);
     A(spawn_perm, E * 20);
     A(waste_perm, E * 119 + 8);
@@ -634,6 +634,17 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
   FieldDesc f;
   if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  if (is_grid(h->cfg) && std::strcmp(field, "grid") == 0) {  // packed presence bits -> padded map image
+    uint8_t* tmp = nullptr;
+    hipError_t e2 = hipMalloc((void**)&tmp, (size_t)env_count * f.env_bytes);
+    if (e2 != hipSuccess) return fail(h, CE_ENOMEM, "grid image buffer", e2);
+    launch_grid_expand((int)h->cfg.kind, h->buf.grid, tmp, env_begin, env_count, nullptr);
+    e2 = hipDeviceSynchronize();
+    if (e2 == hipSuccess) e2 = hipMemcpy(dst, tmp, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e2 != hipSuccess) return fail(h, CE_ENODEV, "grid download", e2);
+    return CE_OK;
+  }
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "download", e);
@@ -646,6 +657,19 @@ extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uin
   FieldDesc f;
   if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs || src_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  if (is_grid(h->cfg) && std::strcmp(field, "grid") == 0) {  // padded map image -> packed presence bits (validated)
+    uint8_t* tmp = nullptr;
+    hipError_t e2 = hipMalloc((void**)&tmp, (size_t)env_count * f.env_bytes);
+    if (e2 != hipSuccess) return fail(h, CE_ENOMEM, "grid image buffer", e2);
+    e2 = hipMemcpy(tmp, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) {
+      launch_grid_pack((int)h->cfg.kind, tmp, h->buf.grid, h->buf.error_flags, env_begin, env_count, nullptr);
+      e2 = hipDeviceSynchronize();
+    }
+    (void)hipFree(tmp);
+    if (e2 != hipSuccess) return fail(h, CE_ENODEV, "grid upload", e2);
+    return CE_OK;
+  }
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy((char*)f.base + (size_t)env_begin * f.env_bytes, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "upload", e);

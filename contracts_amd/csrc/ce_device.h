@@ -16,6 +16,10 @@ constexpr int kMaxGridAgents = 9;
 // crop kernel tile rows exactly: 4 units per row, 60 per agent, no unit straddles a row or an agent
 constexpr int kObsRowStride = 48, kObsAgentStride = kWin * kObsRowStride, kObsUnitsPerAgent = kObsAgentStride / 12;
 constexpr int kMtN = 624, kMtM = 397;
+// Persistent map state per env: 8 dwords.  Bits 0..127 = "apple present" per apple cell (row-major index), bits
+// 128..246 = "waste present" per waste cell (harvest: apple bits 0..154), bit 255 = map still blank (constructed,
+// never reset).  Everything else on the map is static; the image is rebuilt from the constant base map.
+constexpr int kGridStateBytes = 32, kGridBlankBit = 255;
 constexpr int kRngStride = CE_RNG_WORDS_GRID;  // words per env row
 
 // Geometry of the two grid families.  The LDS copy of the map is padded by the view radius
@@ -31,13 +35,13 @@ template <> struct Geo<CE_KIND_CLEANUP> {
   static constexpr int UWORDS = 2 * 103, SBYTES = 224;
   // HBM keeps the map in the SAME bordered layout as LDS: loading / storing an env's map is a straight
   // dword copy (no per-cell index arithmetic, no separate border zeroing)
-  static constexpr int GRID_STRIDE = (PCELLS + 15) / 16 * 16;
+  static constexpr int IMAGE_STRIDE = (PCELLS + 15) / 16 * 16;  // bytes of the padded image ce_download("grid") returns
 };
 template <> struct Geo<CE_KIND_HARVEST> {
   static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
   static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
   static constexpr int UWORDS = 2 * 155, SBYTES = 16;
-  static constexpr int GRID_STRIDE = (PCELLS + 15) / 16 * 16;
+  static constexpr int IMAGE_STRIDE = (PCELLS + 15) / 16 * 16;  // bytes of the padded image ce_download("grid") returns
 };
 
 // Static per-family tables (host-built from the ASCII maps, uploaded to __constant__).
@@ -125,6 +129,8 @@ void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, 
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
 int upload_grid_tables(int kind, const GridTables& t, const uint32_t* rgb16);
+void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, uint32_t env_first, uint32_t env_count, void* stream);
+void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, uint32_t* error_flags, uint32_t env_first, uint32_t env_count, void* stream);
 void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,
                     const uint8_t* mask_dev, uint32_t E, int python_seeding, void* stream);
 // `p` carries the per-call pointers (actions / mask) and the batch size; `dp` is the device-resident copy of

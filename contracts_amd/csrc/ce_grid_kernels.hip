@@ -707,19 +707,50 @@ template <int KIND> DEVINL void zero_pmap(Env<KIND>& E) {
   wave_sync();
 }
 
-template <int KIND> DEVINL void load_grid(Env<KIND>& E, const GridParams& p) {
+// lane's bit of a wave-uniform 64-bit mask
+DEVINL bool lane_bit(u64 m, u32 lane) { return (((lane < 32 ? (u32)m : (u32)(m >> 32)) >> (lane & 31u)) & 1u) != 0; }
+
+// The map image in LDS = constant base map + the env's presence bits (apples; cleanup: waste vs river).
+// `bits` = the env's 8 state dwords in SGPRs (loaded by the caller with one scalar load).
+template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8]) {
   typedef Geo<KIND> G;
-  const u32* src = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
-  u32* dst = (u32*)E.L->pmap;
-  for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k];
-  wave_sync();
+  uint8_t* pm = E.L->pmap;
+  constexpr int AR = (G::NAPPLE + 63) / 64;
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const u64 m = (u64)bits[2 * r] | (u64)bits[2 * r + 1] << 32;
+    if (E.lane + 64 * r < (u32)G::NAPPLE) pm[cell_pad(E.AP[r])] = lane_bit(m, E.lane) ? CE_CELL_APPLE : CE_CELL_EMPTY;
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const u64 m = (u64)bits[4 + 2 * r] | (u64)bits[5 + 2 * r] << 32;
+      if (E.lane + 64 * r < (u32)G::NWASTE) pm[cell_pad(E.WS[r])] = lane_bit(m, E.lane) ? CE_CELL_WASTE : CE_CELL_RIVER;
+    }
+  }
 }
-template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p) {
+template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p, bool blank = false) {
   typedef Geo<KIND> G;
   wave_sync();
-  u32* dst = (u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
-  const u32* src = (const u32*)E.L->pmap;
-  for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k] & 0x7f7f7f7fu;  // strip the agent bits
+  const uint8_t* pm = E.L->pmap;
+  constexpr int AR = (G::NAPPLE + 63) / 64;
+  u32 w = 0;  // lane k < 8 assembles state dword k
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const u64 m = ballot(E.lane + 64 * r < (u32)G::NAPPLE && (pm[cell_pad(E.AP[r])] & kCodeMask) == CE_CELL_APPLE);
+    if (E.lane == 2 * r) w = (u32)m;
+    if (E.lane == 2 * r + 1) w = (u32)(m >> 32);
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const u64 m = ballot(E.lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE);
+      if (E.lane == 4 + 2 * r) w = (u32)m;
+      if (E.lane == 5 + 2 * r) w = (u32)(m >> 32);
+    }
+  }
+  if (blank && E.lane == 7) w |= 1u << (kGridBlankBit & 31);
+  if (E.lane < 8) GAT((CE_GPTR(u32))(p.grid + (size_t)E.e * kGridStateBytes), E.lane) = w;
 }
 
 template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
@@ -765,11 +796,18 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   uint4 r2 = make_uint4(0, 0, 0, 0);
   if (lane + 128 < kMtN / 4) r2 = rsrc[lane + 128];
   const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
-  const u32* gsrc = (const u32*)(p.grid + (size_t)E.e * G::GRID_STRIDE);
+  // map: the constant base image (L2-resident, shared by every env) + this env's 8 presence dwords (one scalar load)
+  const u32* gsrc = (const u32*)T.base_pmap;
   constexpr int GROUNDS = (G::PCELLS / 4 + 63) / 64;
   u32 gw[GROUNDS];
 #pragma unroll
   for (int r = 0; r < GROUNDS; ++r) gw[r] = lane + 64 * r < (u32)G::PCELLS / 4 ? gsrc[lane + 64 * r] : 0u;
+  u32 gbits[8];
+  {
+    const auto bsrc = (CE_GPTR(const u32))(p.grid + (size_t)E.e * kGridStateBytes);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gbits[k] = bsrc[k];
+  }
   u32 aw = 0;
   if (E.is_agent) aw = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, lane);
   E.SP = lane < 20 ? GAT(p.spawn_perm + (size_t)E.e * 20, lane) : 0;
@@ -795,6 +833,8 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
 #pragma unroll
   for (int r = 0; r < GROUNDS; ++r)
     if (lane + 64 * r < (u32)G::PCELLS / 4) pm32[lane + 64 * r] = gw[r];
+  wave_sync();
+  paint_presence(E, gbits);
   if (lane < 16) E.L->rgb[lane] = rgbv;
   uint4* mt4 = (uint4*)E.L->mt;
   mt4[lane] = r0;
@@ -1532,9 +1572,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   u32 fault = 0;
   if (!setup_agents(E, (u32)G::NSPAWN_CTOR)) fault |= CE_FAULT_NO_SPAWN;
   zero_pmap(E);  // world_map is blank until the first reset
-#ifndef CE_ABLATE_GRIDSTORE
-  store_grid(E, p);
-#endif
+  store_grid(E, p, true);
   store_agents(E, p);
   store_perms(E, p, true);
   store_rng(E, p);
@@ -2570,6 +2608,78 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
 }
 
 // ----------------------------------------------------------------------------------------
+// ce_download / ce_upload("grid"): packed presence bits <-> the padded map image (one wave per env)
+// ----------------------------------------------------------------------------------------
+template <int KIND> __global__ __launch_bounds__(64) void k_grid_expand(const uint8_t* __restrict__ state, uint8_t* __restrict__ image,
+                                                                     u32 env_first, u32 env_count) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  if (blockIdx.x >= env_count) return;
+  const u32 lane = lane_id(), e = env_first + blockIdx.x;
+  const u32* bits = (const u32*)(state + (size_t)e * kGridStateBytes);
+  u32* dst = (u32*)(image + (size_t)blockIdx.x * G::IMAGE_STRIDE);
+  const bool blank = (bits[7] >> (kGridBlankBit & 31)) & 1u;
+  const u32* base = (const u32*)T.base_pmap;
+  for (u32 k = lane; k < (u32)G::IMAGE_STRIDE / 4; k += 64) dst[k] = (blank || k >= (u32)G::PCELLS / 4) ? 0u : base[k];
+  if (blank) return;
+  __syncthreads();
+  uint8_t* img = image + (size_t)blockIdx.x * G::IMAGE_STRIDE;
+  for (u32 c = lane; c < (u32)G::NAPPLE; c += 64) img[cell_pad(T.apple[c])] = (bits[c >> 5] >> (c & 31)) & 1u ? CE_CELL_APPLE : CE_CELL_EMPTY;
+  if (KIND == CE_KIND_CLEANUP)
+    for (u32 c = lane; c < (u32)G::NWASTE; c += 64) img[cell_pad(T.waste[c])] = (bits[4 + (c >> 5)] >> (c & 31)) & 1u ? CE_CELL_WASTE : CE_CELL_RIVER;
+}
+template <int KIND> __global__ __launch_bounds__(64) void k_grid_pack(const uint8_t* __restrict__ image, uint8_t* __restrict__ state,
+                                                                   u32* __restrict__ error_flags, u32 env_first, u32 env_count) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+  if (blockIdx.x >= env_count) return;
+  __shared__ uint8_t chk[G::PCELLS];
+  const u32 lane = lane_id(), e = env_first + blockIdx.x;
+  const uint8_t* img = image + (size_t)blockIdx.x * G::IMAGE_STRIDE;
+  bool nonzero = false;
+  for (u32 k = lane; k < (u32)G::PCELLS; k += 64) {
+    chk[k] = img[k];
+    nonzero = nonzero || img[k] != 0;
+  }
+  const bool blank = ballot(nonzero) == 0;
+  __syncthreads();
+  u32 w = 0;
+  bool bad = false;
+  for (u32 r = 0; r < ((u32)G::NAPPLE + 63) / 64; ++r) {
+    const u32 c = lane + 64 * r;
+    const u32 cell = cell_pad(T.apple[c < (u32)G::NAPPLE ? c : 0]);
+    const uint8_t v = c < (u32)G::NAPPLE ? chk[cell] : (uint8_t)0;
+    const u64 m = ballot(c < (u32)G::NAPPLE && v == CE_CELL_APPLE);
+    bad = bad || (c < (u32)G::NAPPLE && v != CE_CELL_APPLE && v != CE_CELL_EMPTY);
+    if (lane == 2 * r) w = (u32)m;
+    if (lane == 2 * r + 1) w = (u32)(m >> 32);
+  }
+  if (KIND == CE_KIND_CLEANUP)
+    for (u32 r = 0; r < 2; ++r) {
+      const u32 c = lane + 64 * r;
+      const u32 cell = cell_pad(T.waste[c < (u32)G::NWASTE ? c : 0]);
+      const uint8_t v = c < (u32)G::NWASTE ? chk[cell] : (uint8_t)0;
+      const u64 m = ballot(c < (u32)G::NWASTE && v == CE_CELL_WASTE);
+      bad = bad || (c < (u32)G::NWASTE && v != CE_CELL_WASTE && v != CE_CELL_RIVER);
+      if (lane == 4 + 2 * r) w = (u32)m;
+      if (lane == 5 + 2 * r) w = (u32)(m >> 32);
+    }
+  __syncthreads();
+  // every other cell must be the static map: neutralise the variable cells, then compare with the base image
+  for (u32 c = lane; c < (u32)G::NAPPLE; c += 64) chk[cell_pad(T.apple[c])] = T.base_pmap[cell_pad(T.apple[c])];
+  if (KIND == CE_KIND_CLEANUP)
+    for (u32 c = lane; c < (u32)G::NWASTE; c += 64) chk[cell_pad(T.waste[c])] = T.base_pmap[cell_pad(T.waste[c])];
+  __syncthreads();
+  for (u32 k = lane; k < (u32)G::PCELLS; k += 64) bad = bad || chk[k] != T.base_pmap[k];
+  if (blank) {
+    w = lane == 7 ? 1u << (kGridBlankBit & 31) : 0u;
+    bad = false;
+  }
+  if (lane < 8) ((u32*)(state + (size_t)e * kGridStateBytes))[lane] = w;
+  if (ballot(bad) != 0 && lane == 0) error_flags[e] |= CE_FAULT_BAD_GRID;
+}
+
+// ----------------------------------------------------------------------------------------
 // MT seeding: one thread per env (sequential recurrence), numpy init_genrand or CPython
 // init_by_array([seed])
 // ----------------------------------------------------------------------------------------
@@ -2739,6 +2849,15 @@ static unsigned extra_lds() {
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+
+void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
+  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
+  else hipLaunchKernelGGL(k_grid_expand<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
+}
+void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error_flags, u32 env_first, u32 env_count, void* stream) {
+  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_pack<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count);
+  else hipLaunchKernelGGL(k_grid_pack<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count);
+}
 
 #define CE_LAUNCH_FEAT(kern)                                                                                    \
   do {                                                                                                          \

@@ -166,7 +166,7 @@ class BatchedEnv:
     def _env_shape(self, field):
         b, n = self.b, self.n
         return {
-            "grid": (b.grid_env_stride,), "agents": (n, 4), "spawn_perm": (20,), "waste_perm": (119,),
+            "grid": (self._grid_image_stride(),), "agents": (n, 4), "spawn_perm": (20,), "waste_perm": (119,),
             "rng": (b.rng_words,), "timestep": (), "theta": (), "sd_state": (5 * n + 3,),
             "obs": (b.obs_env_stride,), "obs_f64": (n, 2 * n + 7), "base_reward": (n,), "reward": (n,), "done": (),
             "done_agents": (n,), "info": (n, 2), "features": (n, b.num_features), "int_metrics": (b.num_int_metrics,),
@@ -190,6 +190,14 @@ class BatchedEnv:
                                         .reshape(cnt, self.n, 15, b.obs_row_stride)[:, :, :, :45]).reshape(cnt, self.n, 15, 15, 3)
         return out
 
+    def _grid_image_stride(self):
+        """bytes per env of the "grid" download / upload format: the padded map image for the grid kinds (the device
+        keeps 32 B of presence bits per env, ce_download expands them), the raw list-stamp block for the feature kinds"""
+        b = self.b
+        if self.kind in _lib.FEAT_KINDS or self.kind == "selfdrive":
+            return b.grid_env_stride
+        return ((b.grid_h + 14) * b.grid_row_stride + 15) // 16 * 16
+
     def _grid_interior(self, raw):
         """strided [cnt, H, W] view of the interior of raw bordered grid slices [cnt, grid_env_stride]"""
         b = self.b
@@ -200,7 +208,7 @@ class BatchedEnv:
         arr = np.asarray(array)
         cnt = arr.shape[0]
         if field == "grid" and arr.ndim == 3:
-            raw = np.zeros((cnt, self.b.grid_env_stride), np.uint8)
+            raw = np.zeros((cnt, self._grid_image_stride()), np.uint8)
             self._grid_interior(raw)[...] = arr
             arr = raw
         arr = np.ascontiguousarray(arr, _FIELD_DTYPES[field]).reshape((cnt,) + self._env_shape(field))
@@ -272,8 +280,7 @@ class BatchedEnv:
             out["base_reward"] = _DevArray(b.base_reward, (E, n), np.int32, None, self)
         elif self.kind != "selfdrive":
             out["obs"] = _DevArray(b.obs, (E, n, 15, 15, 3), np.uint8, (b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, 3, 1), self)
-            out["grid"] = _DevArray(b.grid + b.grid_origin, (E, b.grid_h, b.grid_w), np.uint8,
-                                    (b.grid_env_stride, b.grid_row_stride, 1), self)
+            out["grid_bits"] = _DevArray(b.grid, (E, 8), np.uint32, None, self)  # packed presence bits (see the header)
             out["features"] = _DevArray(b.features, (E, n, b.num_features), np.int16, None, self)
             out["base_reward"] = _DevArray(b.base_reward, (E, n), np.int32, None, self)
         else:

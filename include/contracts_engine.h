@@ -109,8 +109,11 @@ typedef struct ce_buffers {
                                     pitched to 16 pixels so a 4-pixel store unit never straddles a row) */
 
   /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
-  uint8_t* grid;        /* bordered image: cell (e, r, c) at e*grid_env_stride + grid_origin + r*grid_row_stride
-                           + c, cell codes CE_CELL_*; border bytes are 0; a zero-copy [E][H][W] strided view.
+  uint8_t* grid;        /* grid kinds: 32 bytes per env (grid_env_stride) — one "present" bit per apple cell (bits 0..)
+                           and per waste cell (bits 128..) in row-major cell order, bit 255 = blank map; the rest
+                           of the map is static.  ce_download / ce_upload("grid") convert from / to the padded
+                           IMAGE: cell (r, c) of an env at grid_origin + r*grid_row_stride + c, image stride
+                           round16((grid_h + 14) * grid_row_stride), cell codes CE_CELL_*, border bytes 0.
                            Feature kinds: CE_FEAT_STATE_BYTES per env instead (grid_env_stride) —
                            u16 apple_stamp[CE_FEAT_APPLE_SLOTS], u16 waste_stamp[CE_FEAT_WASTE_SLOTS], u32 next_apple_stamp,
                            u32 next_waste_stamp: the stamp of a cell is its rank in the reference's current_apple_points /
@@ -194,6 +197,7 @@ typedef struct ce_buffers {
 
 #define CE_FAULT_BAD_ACTION 0x1u     /* action id outside the family's table (Agent.py:161,198)
                                         — the reference raises KeyError                     */
+#define CE_FAULT_BAD_GRID 0x8u        /* ce_upload("grid"): a cell differs from the static map where only apples / waste may vary */
 #define CE_FAULT_NO_SPAWN 0x2u       /* map_env.py:826 assertion                             */
 #define CE_FAULT_STEP_AFTER_DONE 0x4u /* selfdrive step after __all__ (…accelerate.py:154-167
                                         raises AttributeError in the reference)              */
