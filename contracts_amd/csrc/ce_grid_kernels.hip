@@ -228,6 +228,7 @@ struct Rng {
   u32 cbase;   // uniform
   u32 ccount;  // uniform; 0 = cache invalid
   u64 cvalid;  // lanes < ccount
+  u32 twists;  // generations advanced since the state was loaded (uniform): 0 = the key words in HBM are still current
 };
 
 // The stream position / cache window are wave-uniform by construction, but after inlined helpers with several
@@ -244,6 +245,7 @@ DEVINL void rng_assert_uniform(Rng& r) {
 DEVINL void rng_refill(Rng& r, u32 lane) {
   if (r.pos >= (u32)kMtN) {
     mt_twist(r.mt, lane);
+    r.twists += 1;
     r.pos = 0;
   }
   r.cbase = r.pos;
@@ -273,6 +275,7 @@ DEVINL void rng_bulk(Rng& r, u32* U, uint8_t* S, u32 count, u32 keep, bool want_
   while (done < count) {
     if (r.pos >= (u32)kMtN) {
       mt_twist(r.mt, lane);
+      r.twists += 1;
       r.pos = 0;
     }
     u32 chunk = (u32)kMtN - r.pos;
@@ -628,6 +631,7 @@ template <int KIND> struct Env {
   u32 AP[3];
   u32 WS[2];
   unsigned long long* dbg;  // diagnostic builds only
+  bool waste_perm_dirty;    // the persistent waste list was shuffled in this launch
 };
 
 DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-index deltas
@@ -690,13 +694,16 @@ template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
   E.rng.ccount = 0;
   E.rng.cvalid = 0;
   E.rng.cache = 0;
+  E.rng.twists = 0;
   wave_sync();
 }
 template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   wave_sync();
-  uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
-  const uint4* src = (const uint4*)E.L->mt;
-  for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+  if (rfl(E.rng.twists) != 0) {  // the key words only change at a twist; otherwise just the position moves
+    uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
+    const uint4* src = (const uint4*)E.L->mt;
+    for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+  }
   if (E.lane == 0) p.rng[(size_t)E.e * kRngStride + kMtN] = E.rng.pos;
 }
 
@@ -776,9 +783,9 @@ template <int KIND> DEVINL void load_perms(Env<KIND>& E, const GridParams& p) {
     E.WP1 = E.lane + 64 < 119 ? GAT(wp, E.lane + 64) : 0;
   }
 }
-template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, bool spawn_too) {
+template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, bool spawn_too, bool waste_too = true) {
   if (spawn_too && E.lane < 20) GAT(p.spawn_perm + (size_t)E.e * 20, E.lane) = (uint8_t)E.SP;
-  if (KIND == CE_KIND_CLEANUP) {
+  if (KIND == CE_KIND_CLEANUP && waste_too) {
     const auto wp = p.waste_perm + (size_t)E.e * 119;
     GAT(wp, E.lane) = (uint8_t)E.WP0;
     if (E.lane + 64 < 119) GAT(wp, E.lane + 64) = (uint8_t)E.WP1;
@@ -846,6 +853,7 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   E.rng.ccount = 0;
   E.rng.cvalid = 0;
   E.rng.cache = 0;
+  E.rng.twists = 0;
   E.P = pad_of<KIND>(aw & 0xff, (aw >> 8) & 0xff);
   E.O = (aw >> 16) & 3;
   E.RW = 0;
@@ -1051,6 +1059,7 @@ template <int RANDW> DEVINL StreamWindow window_open(Rng& r, u32 lane) {
   rng_assert_uniform(r);
   if (r.pos >= (u32)kMtN) {
     mt_twist(r.mt, lane);
+    r.twists += 1;
     r.pos = 0;
   }
   StreamWindow w;
@@ -1145,6 +1154,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   }
   if (W.alen < (u32)G::RANDW) {  // the window runs into the next generation
     mt_twist(W.mt, lane);
+    E.rng.twists += 1;
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
       wa[r] = window_read_new(W, elig[r], sa[r], wa[r]);
@@ -1191,6 +1201,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #else
       // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
       // spills into S)
+      E.waste_perm_dirty = true;
       shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
       CE_SUBSTAMP(10);
 #ifdef CE_SERIAL_APPLY
@@ -1543,6 +1554,7 @@ constexpr int kWavesPerBlock = 1;
 template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds, u32 env_first, u32 env_end) {
   const u32 wave = threadIdx.x >> 6;
   E.lane = lane_id();
+  E.waste_perm_dirty = false;
   E.e = rfl(env_first + blockIdx.x * kWavesPerBlock + wave);
   E.n = p.n;
   E.is_agent = E.lane < E.n;
@@ -1884,7 +1896,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   store_grid(E, p);
 #endif
   store_agents(E, p);
-  store_perms(E, p, did_reset);
+  store_perms(E, p, did_reset, E.waste_perm_dirty);
 #ifndef CE_ABLATE_RNGSTORE
   store_rng(E, p);
 #endif
@@ -1936,6 +1948,7 @@ DEVINL void rng_bind(Rng& r, u32* mt, u32 pos) {
   r.ccount = 0;
   r.cvalid = 0;
   r.cache = 0;
+  r.twists = 0;
 }
 // skip k stream words (k <= 624); the twist is taken only when the position moves past the generation end
 DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
@@ -1943,6 +1956,7 @@ DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
   u32 np_ = r.pos + k;
   if (np_ > (u32)kMtN) {
     mt_twist(r.mt, lane);
+    r.twists += 1;
     np_ -= (u32)kMtN;
   }
   r.pos = np_;
@@ -2020,10 +2034,12 @@ template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
   const u32 lane = E.lane;
   wave_sync();
   const auto rdst = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
+  if (rfl(E.py.twists) != 0)
+    for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
   if (lane == 0) rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
   if (E.np_loaded) {
-    for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[k] = E.L->mt_np[k];
+    if (rfl(E.np.twists) != 0)
+      for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[k] = E.L->mt_np[k];
     if (lane == 0) rdst[kMtN] = E.np.pos;
   }
   const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
@@ -2200,6 +2216,7 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
       rng_assert_uniform(E.py);
       if (E.py.pos >= (u32)kMtN) {
         mt_twist(E.py.mt, lane);
+        E.py.twists += 1;
         E.py.pos = 0;
       }
       rng_refill(E.py, lane);  // cache = tempered words pos .. pos + ccount - 1 (nothing consumed yet)
