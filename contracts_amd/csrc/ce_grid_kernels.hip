@@ -1280,24 +1280,26 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   const bool padded = j0 == 12;  // column 15 is the row padding
   const u32 voff = __umul24(lane, 12u);
   const u32* rgb = E.L->rgb;
-  auto dst = (CE_GPTR(char))(p.obs + (size_t)E.e * p.obs_env_stride);
-  for (u32 a = 0; a < E.n; ++a, dst += kObsAgentStride) {
+  const auto dst_env = (CE_GPTR(char))(p.obs + (size_t)E.e * p.obs_env_stride);
+  for (u32 a = 0; a < E.n; ++a) {
     const u32 vw = rdl(VW, a);
-    const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24, B2 = 2 * B, B3 = 3 * B;
+    const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24;
     const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)(vw & 0xffffu);
+    const i32 off1 = off0 + B, off2 = off1 + B, off3 = off2 + B;  // a chain of adds with the scalar B
     const u32 c0 = rgb[pm[off0]];
-    const u32 c1 = rgb[pm[off0 + B]];
-    const u32 c2 = rgb[pm[off0 + B2]];
-    u32 c3 = rgb[pm[off0 + B3]];
+    const u32 c1 = rgb[pm[off1]];
+    const u32 c2 = rgb[pm[off2]];
+    u32 c3 = rgb[pm[off3]];
     c3 = padded ? 0u : c3;
     uint3 d;
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
     d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
     d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
+    const u32 doff = voff + __umul24(a, (u32)kObsAgentStride);  // 32-bit offset from the wave-uniform env base
 #ifdef CE_ABLATE_OBSSTORE  // traffic experiment: the pixels are computed but not written
     asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
 #else
-    if (lane < 60) *(CE_GPTR(uint3))(dst + voff) = d;
+    if (lane < 60) *(CE_GPTR(uint3))(dst_env + doff) = d;
 #endif
   }
 }

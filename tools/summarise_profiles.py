@@ -20,7 +20,7 @@ def find(sub, pat):
     got = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
     if not got:
         raise SystemExit("missing %s/%s" % (sub, pat))
-    return got[0]
+    return max(got, key=os.path.getmtime)  # gpurun merges into gpurun_out/: older runs' files may still be there
 
 
 def counter_means(sub):
