@@ -161,3 +161,34 @@ def test_state_checkpoint_roundtrip(tmp_path, kind, n, contract):
         assert np.array_equal(b.download("obs_f64" if kind == "selfdrive" else "obs"), ref[t][1], equal_nan=True), t
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cleanup", "harvest"])
+def test_packed_grid_roundtrip_and_validation(kind):
+    """the device keeps 32 B of presence bits per env; ce_download / ce_upload("grid") expand to / pack from the map
+    image: round trip is the identity, a blank (constructed, never reset) map reads as zeros, and an image that differs
+    from the static map anywhere but on apple / waste cells raises CE_FAULT_BAD_GRID"""
+    from contracts_amd.engine import BatchedEnv
+    env = BatchedEnv(kind, 4, 3)
+    env.seed(np.arange(4).astype(np.uint64) + 3)
+    assert not env.download("grid").any()  # world_map is blank until the first reset
+    env.reset()
+    g = env.download("grid")
+    assert g.any() and env.b.grid_env_stride == 32
+    env.upload("grid", g)
+    assert np.array_equal(env.download("grid"), g) and not env.download("error_flags").any()
+    bits = env.download("grid")  # flip one legal cell and one illegal one
+    apple = np.argwhere(np.isin(g[0], (0, 2)) & (np.arange(g.shape[2])[None, :] > 0))
+    h = g.copy()
+    if kind == "cleanup":
+        waste = np.argwhere(g[1] == 3)[0]
+        h[1, waste[0], waste[1]] = 4  # waste -> river on a waste cell: legal
+    wall = np.argwhere(g[2] == 1)[5]
+    h[2, wall[0], wall[1]] = 0        # a wall removed: illegal
+    env.upload("grid", h)
+    flags = env.download("error_flags")
+    assert flags[2] & 8 and not flags[0] and not flags[1] and not flags[3]
+    back = env.download("grid")
+    assert np.array_equal(back[1], h[1]) and np.array_equal(back[2], g[2])  # the static map wins on env 2
+    env.close()
