@@ -293,13 +293,6 @@ DEVINL void rng_bulk(Rng& r, u32* U, uint8_t* S, u32 count, u32 keep, bool want_
   wave_sync();
 }
 
-// the 53-bit integer X with random_sample() == X / 2^53, from words 2r and 2r+1 of U
-DEVINL u64 u53(const u32* U, u32 r) {
-  u32 a = U[2 * r] >> 5, b = U[2 * r + 1] >> 6;
-  return ((u64)a << 26) | (u64)b;
-}
-DEVINL double u53_to_double(u64 x) { return (double)x / 9007199254740992.0; }
-
 DEVINL double rng_double(Rng& r, u32 lane) {
   u32 a = rng_next(r, lane) >> 5;
   u32 b = rng_next(r, lane) >> 6;
@@ -609,8 +602,6 @@ constexpr uint8_t kAgentBit = 0x80;
 constexpr u32 kCodeMask = 0x7fu;
 constexpr u32 kCellPadMask = 0x7ffu;
 DEVINL u32 cell_pad(u32 packed) { return packed & kCellPadMask; }
-DEVINL u32 cell_row(u32 packed) { return packed >> 24; }
-DEVINL u32 cell_col(u32 packed) { return (packed >> 16) & 0xffu; }
 DEVINL u32 cell_rc(u32 packed) { return packed >> 16; }  // col | row << 8: one byte per coordinate
 
 // env context: everything a wave keeps in registers for its env
@@ -641,9 +632,6 @@ DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-i
 template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return __umul24(row + kView, (u32)Geo<KIND>::PW) + col + kView; }
 // Exact small-range divisions by multiply-shift with 24-bit multiplies (v_mul_u32_u24 is full rate, the
 // 32-bit v_mul_lo/hi the compiler emits for `/ constant` are quarter rate): valid for idx < 640 / pad < 1600.
-template <int KIND> DEVINL u32 div_w(u32 idx) {  // idx / W
-  return KIND == CE_KIND_CLEANUP ? (__umul24(idx, 3641u) >> 16) : (__umul24(idx, 1725u) >> 16);
-}
 template <int KIND> DEVINL u32 div_pw(u32 pad) {  // pad / PW
   return KIND == CE_KIND_CLEANUP ? (pad >> 5) : (__umul24(pad, 1261u) >> 16);
 }
@@ -1704,11 +1692,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   {  // update_custom_moves: always shuffles the n ids, then fires in that order
     u32 IDS = lane;
     const u64 firing = ballot(E.is_agent && ACT >= 7);
-#ifdef CE_OLD_NSHUFFLE
-    if (true) {
-#else
     if (firing & (firing - 1)) {  // the shuffled order only matters between two or more beams
-#endif
       shuffle_lanes1(E.rng, IDS, n, lane);
     } else {
       u32 d0 = 0;
