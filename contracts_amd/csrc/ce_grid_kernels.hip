@@ -1749,6 +1749,15 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 #else
   const u32 feat8 = 0;
 #endif
+  // The observation (the bulk of the step's stores) goes out as early as the map allows, so that its stores drain
+  // under the epilogue's arithmetic instead of at the wave's very end.  It paints the agents over the map bytes,
+  // hence after the feature pass and after the map state is packed; a done step with auto-reset writes the reset
+  // observation instead and keeps the late path.
+  const bool obs_early = t != p.horizon;
+  if (obs_early) {
+    store_grid(E, p);
+    write_obs(E, p, true);
+  }
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   double transfers_total = 0.0;
   if (p.contract != CE_CONTRACT_NONE) {
@@ -1877,10 +1886,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   }
 
   CE_STAMP(7);
-  // ---------------- state out, then the observation ----------------
-#ifndef CE_ABLATE_GRIDSTORE
-  store_grid(E, p);
-#endif
+  // ---------------- state out ----------------
+  if (!obs_early) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, did_reset, E.waste_perm_dirty);
 #ifndef CE_ABLATE_RNGSTORE
@@ -1893,9 +1900,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     if (fault) p.error_flags[E.e] |= fault;
   }
   CE_STAMP(8);
-#ifndef CE_ABLATE_OBS
-  write_obs(E, p, !did_reset);
-#endif
+  if (!obs_early) write_obs(E, p, !did_reset);
   CE_STAMP(9);
   CE_REALSTAMP(15);
 }
