@@ -192,3 +192,79 @@ def test_packed_grid_roundtrip_and_validation(kind):
     back = env.download("grid")
     assert np.array_equal(back[1], h[1]) and np.array_equal(back[2], g[2])  # the static map wins on env 2
     env.close()
+
+
+@pytest.mark.gpu
+def test_full_size_partition_invariance_and_oracle_sample():
+    """BASELINE's full single-GPU size (cleanup n=8 + contract, 16384 envs): the result of a rollout does not depend
+    on how the env axis is cut — one launch per step, two slices on two streams (bench.py's mode), or two engines
+    that each own half of the global index range (the 8-GPU shard rule) — and a random sample of envs agrees with
+    the CPU oracle stepping the same seeds and actions."""
+    import hashlib
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    from oracle.pyoracle import Oracle
+    E, n, T, seed0 = 16384, 8, 30, 73907
+    kw = dict(contract="cleanup", horizon=12, auto_reset=True)  # several in-launch auto-resets inside the window
+
+    def digest(envs):
+        h = hashlib.sha256()
+        for f in ("obs", "reward", "grid", "agents", "rng", "waste_perm", "features", "int_metrics", "f64_metrics", "theta"):
+            for env in envs:
+                h.update(np.ascontiguousarray(env.download(f, raw=True)).tobytes())
+        return h.hexdigest()
+
+    whole = BatchedEnv("cleanup", E, n, **kw)
+    acts = torch.empty((T, E, n), dtype=torch.uint8, device="cuda")
+    whole.synth_actions(seed0 + 1, 0, T, acts.data_ptr())
+    whole.synchronize()
+    plane = E * n
+
+    def run(mode):
+        if mode == "halves":
+            envs = [BatchedEnv("cleanup", E // 2, n, env_index_base=k * (E // 2), **kw) for k in range(2)]
+        else:
+            envs = [BatchedEnv("cleanup", E, n, **kw)]
+        for env in envs:
+            env.seed(seed0=seed0)
+            env.reset()
+        if mode == "single":
+            for t in range(T):
+                envs[0].step_device(acts.data_ptr() + t * plane)
+        elif mode == "streams":
+            streams = [torch.cuda.Stream() for _ in range(2)]
+            envs[0].rollout_device(acts.data_ptr(), T, [s.cuda_stream for s in streams])
+        else:
+            half = acts.reshape(T, 2, E // 2, n)
+            for k, env in enumerate(envs):
+                a_k = half[:, k].contiguous()
+                env.rollout_device(a_k.data_ptr(), T, None)
+        torch.cuda.synchronize()
+        for env in envs:
+            env.check_faults()
+        return envs
+
+    ref_envs = run("single")
+    d0 = digest(ref_envs)
+    for mode in ("streams", "halves"):
+        envs = run(mode)
+        assert digest(envs) == d0, mode
+        for env in envs:
+            env.close()
+    # oracle on a sample of the global index range
+    rs = np.random.RandomState(4)
+    pick = np.sort(rs.choice(E, size=48, replace=False))
+    orc = Oracle("cleanup", len(pick), n, **kw)
+    orc.seed((pick + seed0).astype(np.uint64))
+    orc.reset()
+    a_host = acts.cpu().numpy()
+    for t in range(T):
+        orc.step(a_host[t][pick])
+    ref = ref_envs[0]
+    for f in ("obs", "agents", "grid", "features", "base_reward", "waste_perm", "int_metrics"):
+        assert np.array_equal(ref.download(f)[pick], getattr(orc, f)), f
+    np.testing.assert_allclose(ref.download("reward")[pick], orc.reward, rtol=0, atol=1e-9)
+    assert np.array_equal(ref.download("rng")[pick][:, :625], orc.rng[:, :625])
+    ref.close()
+    whole.close()
+    orc.close()
