@@ -128,10 +128,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # functional-test knobs (tests/test_bench_multirank_gpu.py): several ranks on ONE GPU with a gloo rendezvous —
+    # exercises the sharding / reduction / reporting path where only a single-GPU box is available; never for numbers
+    backend = os.environ.get("CONTRACTS_BENCH_BACKEND", "nccl")
+    if os.environ.get("CONTRACTS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from contracts_amd.engine import BatchedEnv
     kind, n, E = a.kind, a.agents, a.envs_per_gpu
@@ -193,7 +201,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     env.check_faults()
