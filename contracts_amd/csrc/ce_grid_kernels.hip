@@ -1914,22 +1914,25 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 // ========================================================================================
 template <int GK> struct alignas(16) FeatLds {
   u32 mt_py[kMtN];  // CPython `random` stream
-  u32 mt_np[kMtN];  // np.random stream (orientations, theta)
-  u32 U[320];       // tempered words of the respawn doubles of one spawn pass
-  uint8_t pmap[Geo<GK>::PCELLS];  // padded map: walls + apples / wastes currently present
+  union {           // the np.random stream is only needed for a moment at a reset (orientations, theta): it borrows
+    u32 mt_np[kMtN];  // the space of the per-step working set
+    struct {
+      u32 U[320];                     // tempered words of the respawn doubles of one spawn pass
+      uint8_t pmap[Geo<GK>::PCELLS];  // padded map: walls + apples / wastes currently present
+    } w;
+  };
 };
 constexpr u32 kAbsent = CE_FEAT_ABSENT;
 
 template <int GK> struct FEnv {
   FeatLds<GK>* L;
-  Rng py, np;
+  Rng py;
   u32 lane, n, e;
   bool is_agent;
   u32 P, O;         // lane a: padded cell, orientation
   u32 AP[3], AS[3];  // lane c, round r: packed apple cell c + 64 r and its list stamp (kAbsent = not present)
   u32 WC[2], WS[2];  // cleanup: waste cells and stamps
   u32 next_a, next_w;
-  bool np_loaded;
 };
 
 DEVINL void rng_bind(Rng& r, u32* mt, u32 pos) {
@@ -1954,12 +1957,40 @@ DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
   r.ccount = 0;
 }
 
-// the np.random stream is only drawn from by resets: a plain step neither loads nor stores it
-template <int GK> DEVINL void feat_load_np(FEnv<GK>& E, const GridParams& p) {
+template <int GK> DEVINL void feat_base_map(FEnv<GK>& E) {
+  const u32* bsrc = (const u32*)c_tab[GK].base_pmap;
+  u32* pm32 = (u32*)E.L->w.pmap;
+  for (u32 k = E.lane; k < (u32)Geo<GK>::PCELLS / 4; k += 64) pm32[k] = bsrc[k];
+}
+// The np.random draws of a reset — n orientations (one masked word each), then the wrapper's theta — taken in one go
+// on the stream loaded into the borrowed LDS block and written straight back: the two generators are independent,
+// so taking these before the `random` draws of the same reset changes nothing.  Call before the working set is built.
+template <int GK> DEVINL void feat_np_draws(FEnv<GK>& E, const GridParams& p, bool with_theta, u32& orient, double& theta) {
   const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
+  wave_sync();
   for (u32 k = E.lane; k < (u32)kMtN; k += 64) E.L->mt_np[k] = rsrc[k];
-  rng_bind(E.np, E.L->mt_np, rsrc[kMtN]);
-  E.np_loaded = true;
+  Rng np;
+  rng_bind(np, E.L->mt_np, rsrc[kMtN]);
+  wave_sync();
+  orient = 0;
+  for (u32 a = 0; a < E.n; ++a) {
+    const u32 w = rng_next(np, E.lane) & 3u;  // legacy randint(0, 4): one masked word
+    if (E.lane == a) orient = w;
+  }
+  theta = 0.0;
+  if (with_theta && p.contract != CE_CONTRACT_NONE) {  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
+    const double u0 = rng_double(np, E.lane);
+    if (u0 > p.null_prob) {
+      const double u1 = rng_double(np, E.lane);
+      theta = p.contract_low + (p.contract_high - p.contract_low) * u1;
+    } else {
+      theta = p.contract_low;
+    }
+  }
+  wave_sync();
+  if (rfl(np.twists) != 0)
+    for (u32 k = E.lane; k < (u32)kMtN; k += 64) rsrc[k] = E.L->mt_np[k];
+  if (E.lane == 0) rsrc[kMtN] = np.pos;
   wave_sync();
 }
 template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool with_state) {
@@ -1968,12 +1999,8 @@ template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool w
   const u32 lane = E.lane;
   const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
   for (u32 k = lane; k < (u32)kMtN; k += 64) E.L->mt_py[k] = rsrc[CE_RNG_WORDS_GRID + k];
-  E.np_loaded = false;
-  rng_bind(E.np, E.L->mt_np, 0);
   rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
-  const u32* bsrc = (const u32*)T.base_pmap;
-  u32* pm32 = (u32*)E.L->pmap;
-  for (u32 k = lane; k < (u32)G::PCELLS / 4; k += 64) pm32[k] = bsrc[k];
+  feat_base_map(E);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const u32 idx = lane + 64 * r;
@@ -2011,7 +2038,7 @@ template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool w
 // presence map: apple / waste cells carry their code only while present
 template <int GK> DEVINL void feat_paint(FEnv<GK>& E) {
   typedef Geo<GK> G;
-  uint8_t* pm = E.L->pmap;
+  uint8_t* pm = E.L->w.pmap;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
     if (E.lane + 64 * r < (u32)G::NAPPLE) pm[cell_pad(E.AP[r])] = E.AS[r] != kAbsent ? CE_CELL_APPLE : CE_CELL_EMPTY;
@@ -2028,11 +2055,6 @@ template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
   if (rfl(E.py.twists) != 0)
     for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
   if (lane == 0) rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
-  if (E.np_loaded) {
-    if (rfl(E.np.twists) != 0)
-      for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[k] = E.L->mt_np[k];
-    if (lane == 0) rdst[kMtN] = E.np.pos;
-  }
   const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -2077,7 +2099,7 @@ template <int GK> DEVINL void feat_init_arrays(FEnv<GK>& E) {
 }
 // initialize_players: random.shuffle(list(range(len(spawn_points)))) with CPython's _randbelow_with_getrandbits
 // (top bits of one word per attempt, k = (i + 1).bit_length()), then np.random.randint(0, 4) per agent
-template <int GK> DEVINL void feat_init_players(FEnv<GK>& E) {
+template <int GK> DEVINL void feat_init_players(FEnv<GK>& E, u32 orient) {
   const GridTables& T = c_tab[GK];
   const u32 L = GK == CE_KIND_HARVEST ? 20u : 10u;
   u32 IDX = E.lane;
@@ -2091,12 +2113,7 @@ template <int GK> DEVINL void feat_init_players(FEnv<GK>& E) {
   }
   const u32 cell = T.spawn[IDX < 20 ? IDX : 0];
   E.P = E.is_agent ? cell_pad(cell) : 0xffffu;
-  u32 o = 0;
-  for (u32 a = 0; a < E.n; ++a) {
-    const u32 w = rng_next(E.np, E.lane) & 3u;  // legacy randint(0, 4): one masked word
-    if (E.lane == a) o = w;
-  }
-  E.O = o;
+  E.O = orient;  // np.random.randint(0, 4) per agent, drawn by feat_np_draws
 }
 
 // r < p for a double given as tempered words (a, b): exact 53-bit integer compare against ceil(p * 2^53)
@@ -2107,7 +2124,7 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
   const GridTables& T = c_tab[GK];
   const u32 lane = E.lane;
   const u64 lt = (1ull << lane) - 1ull;
-  uint8_t* pm = E.L->pmap;
+  uint8_t* pm = E.L->w.pmap;
   constexpr int AR = (G::NAPPLE + 63) / 64;
   // agent presence on apple cells: `apple_pos not in self.agent_pos.values()`
   bool elig[AR];
@@ -2134,11 +2151,11 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
     thr_uniform = te & ~kWasteOnBit;
   }
   // every eligible cell consumes exactly one random.random(): temper the 2 * nelig words in stream order
-  rng_bulk(E.py, E.L->U, nullptr, 2 * nelig, 2 * nelig, false, lane);
+  rng_bulk(E.py, E.L->w.U, nullptr, 2 * nelig, 2 * nelig, false, lane);
   bool spawn[AR];
   if (GK == CE_KIND_CLEANUP) {
 #pragma unroll
-    for (int r = 0; r < AR; ++r) spawn[r] = elig[r] && dbl_below(E.L->U[2 * (elig[r] ? ri[r] : 0)], E.L->U[2 * (elig[r] ? ri[r] : 0) + 1], thr_uniform);
+    for (int r = 0; r < AR; ++r) spawn[r] = elig[r] && dbl_below(E.L->w.U[2 * (elig[r] ? ri[r] : 0)], E.L->w.U[2 * (elig[r] ? ri[r] : 0) + 1], thr_uniform);
   } else {
     // spawn_apples (harvest_features.py:139-151): the neighbour count of a cell includes apples spawned EARLIER in
     // this very loop (row-major order).  More neighbours never lower the probability, so iterating the parallel
@@ -2146,8 +2163,8 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
     u32 a_w[AR], b_w[AR];
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      a_w[r] = E.L->U[2 * (elig[r] ? ri[r] : 0)];
-      b_w[r] = E.L->U[2 * (elig[r] ? ri[r] : 0) + 1];
+      a_w[r] = E.L->w.U[2 * (elig[r] ? ri[r] : 0)];
+      b_w[r] = E.L->w.U[2 * (elig[r] ? ri[r] : 0) + 1];
       spawn[r] = false;
     }
     for (;;) {
@@ -2239,7 +2256,7 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
 // apples within j^2 + k^2 <= 5 of a padded cell (uniform), current presence map
 template <int GK> DEVINL u32 feat_close_count(FEnv<GK>& E, u32 cell) {
   const GridTables& T = c_tab[CE_KIND_HARVEST];
-  const bool v = E.lane < 21 && E.L->pmap[(i32)cell + (i32)T.close_off[E.lane < 21 ? E.lane : 0]] == CE_CELL_APPLE;
+  const bool v = E.lane < 21 && E.L->w.pmap[(i32)cell + (i32)T.close_off[E.lane < 21 ? E.lane : 0]] == CE_CELL_APPLE;
   return popc64(ballot(v));
 }
 
@@ -2346,21 +2363,11 @@ template <int GK> DEVINL void feat_zero_outputs(FEnv<GK>& E, const GridParams& p
   }
 }
 // reset(): initialize_arrays, initialize_players, spawn, metrics, theta (wrapper), observation
-template <int GK> DEVINL void feat_reset_env(FEnv<GK>& E, const GridParams& p, double& theta) {
+template <int GK> DEVINL void feat_reset_env(FEnv<GK>& E, const GridParams& p, u32 orient) {
   feat_init_arrays(E);
-  feat_init_players(E);
+  feat_init_players(E, orient);
   feat_paint(E);
   feat_spawn(E);
-  theta = 0.0;
-  if (p.contract != CE_CONTRACT_NONE) {  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
-    const double u0 = rng_double(E.np, E.lane);
-    if (u0 > p.null_prob) {
-      const double u1 = rng_double(E.np, E.lane);
-      theta = p.contract_low + (p.contract_high - p.contract_low) * u1;
-    } else {
-      theta = p.contract_low;
-    }
-  }
 }
 
 template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
@@ -2370,10 +2377,12 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const G
   FEnv<GK> E;
   if (!feat_begin(E, p, &lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
+  u32 orient;
+  double theta_unused;
+  feat_np_draws(E, p, false, orient, theta_unused);
   feat_load(E, p, false);
-  feat_load_np(E, p);
   feat_init_arrays(E);  // __init__: initialize_arrays, (compute_probabilities), initialize_players
-  feat_init_players(E);
+  feat_init_players(E, orient);
   feat_zero_outputs(E, p);
   feat_store(E, p);
   if (E.lane == 0) {
@@ -2391,10 +2400,11 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   FEnv<GK> E;
   if (!feat_begin(E, p, &lds, env_first, env_end)) return;
   if (call_mask && call_mask[E.e] == 0) return;
-  feat_load(E, p, false);
-  feat_load_np(E, p);
+  u32 orient;
   double theta;
-  feat_reset_env(E, p, theta);
+  feat_np_draws(E, p, true, orient, theta);
+  feat_load(E, p, false);
+  feat_reset_env(E, p, orient);
   feat_zero_outputs(E, p);
   feat_features(E, p, 0u);
   feat_store(E, p);
@@ -2423,7 +2433,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
   }
   feat_load(E, p, true);
   feat_paint(E);
-  uint8_t* pm = E.L->pmap;
+  uint8_t* pm = E.L->w.pmap;
   u32 t = (u32)p.timestep[E.e];
   double theta = p.theta[E.e];
 
@@ -2599,8 +2609,11 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
     for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
     if (p.flags & CE_FLAG_AUTO_RESET) {
       __threadfence_block();
-      feat_load_np(E, p);
-      feat_reset_env(E, p, theta);
+      u32 orient;
+      feat_np_draws(E, p, true, orient, theta);  // the step's working set is dead by now: the block is free to borrow
+      feat_base_map(E);
+      wave_sync();
+      feat_reset_env(E, p, orient);
       for (u32 k = lane; k < nmi; k += 64) p.int_metrics[(size_t)E.e * nmi + k] = 0;
       for (u32 k = lane; k < nmf; k += 64) p.f64_metrics[(size_t)E.e * nmf + k] = 0.0;
       t = 0;
