@@ -1287,7 +1287,11 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
 #ifdef CE_ABLATE_OBSSTORE  // traffic experiment: the pixels are computed but not written
     asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
 #else
-    if (lane < 60) *(CE_GPTR(uint3))(dst_env + doff) = d;
+    // streaming (nontemporal) store: the observation is write-once output and the bulk of the step's bytes; keeping it
+    // out of L2 / Infinity Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536)
+    typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 dv = {d.x, d.y, d.z};
+    if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_env + doff));
 #endif
   }
 }
