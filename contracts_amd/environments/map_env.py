@@ -185,6 +185,7 @@ class GridEnvAdapter(_Base):
     def reset(self):
         self._call(self._ensure_engine().reset)
         self._engine.check_faults()
+        self._agents_painted = False
         self._refresh_metrics(final=False)
         return self._obs_dict()
 
@@ -198,6 +199,7 @@ class GridEnvAdapter(_Base):
             a[0, i] = v
         self._call(self._ensure_engine().step, a)
         self._engine.check_faults()
+        self._agents_painted = True
 
     def step(self, acts):
         self._step_engine(acts)
@@ -247,8 +249,19 @@ class GridEnvAdapter(_Base):
     def render(self, filename=None, mode="human"):
         return self.full_map_to_colors()
 
+    def global_view(self):
+        """map_env.py:394-395: the colour map without its padding.  reset() leaves the agents unpainted, a step paints
+        them (later agent wins), exactly as the egocentric crops see it."""
+        grid = self._engine.download("grid")[0]
+        rgb = CELL_RGB[grid]
+        if getattr(self, "_agents_painted", False):
+            rgb = rgb.copy()
+            for i, a in enumerate(self._engine.download("agents")[0]):
+                rgb[a[0], a[1]] = AGENT_RGB[i]
+        return rgb
+
     def get_global_obs(self):
-        return {"image": self.full_map_to_colors().astype(np.uint8) / 255}
+        return {"image": self.global_view() / 255}
 
     # ------------------------------------------------------------------ metrics
     def compute_equality(self, reward_dict):

@@ -4,18 +4,19 @@ from ..environments.cleanup_new import CleanupEnv
 from ..environments.feature_envs import CleanupFeatures, HarvestFeatures
 from ..environments.harvest_new import HarvestEnv
 from ..environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
-from ..environments.two_stage_train import SeparateContractSubgameStage
+from ..environments.two_stage_train import JointEnv, SeparateContractSubgameStage
 
 _ACCELERATED = {
     "SelfDrive": SelfAcceleratingCarEnv,
     "HarvestNew": HarvestEnv,
     "CleanupNew": CleanupEnv,
     "ContractWrapperSubgame": SeparateContractSubgameStage,
+    "JointEnv": JointEnv,
     "Harvest": HarvestFeatures,   # `harvest`: the feature-vector env of BASELINE config 0 (harvest_features.py)
     "Cleanup": CleanupFeatures,   # `cleanup` (cleanup_features.py)
 }
 # tags of the reference that are callers of the hot path, not the path itself
-_OUT_OF_SCOPE = ("ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver", "JointEnv")
+_OUT_OF_SCOPE = ("ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver")
 
 
 def env_creator(name, config):

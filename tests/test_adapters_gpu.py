@@ -167,3 +167,41 @@ def test_reference_config_file_drives_the_engine():
             assert o["a0"]["image"].shape == (15, 15, 3)
             assert ("contract" in o["a0"]) == (not job.get("separate"))
         base.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["joint_cleanup_n3_global", "joint_cleanup_n3_concat", "joint_harvest_n2_global"])
+def test_joint_env_trace(name):
+    """JointEnv (centralised agent over the pixel envs; global-map and concatenated-view observations) against
+    fixtures produced by the reference's own JointEnv (tests/golden/make_joint_golden.py)"""
+    import hashlib
+    import random
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    from contracts_amd.environments.two_stage_train import JointEnv
+    g = np.load("%s/%s.npz" % (gc.GOLDEN_DIR, name))
+    kind, n, seed, mode = str(g["kind"]), int(g["n"]), int(g["seed"]), str(g["mode"])
+    np.random.seed(seed)
+    random.seed(seed)
+    base = (CleanupEnv if kind == "cleanup" else HarvestEnv)(num_agents=n)
+    env = JointEnv(base, num_agents=n, global_obs=mode == "global", concatenated_obs=mode == "concat")
+    assert tuple(env.observation_space["image"].shape) == tuple(g["obs_space_shape"])
+    assert list(env.action_space.nvec) == list(g["act_nvec"])
+    o = env.reset()
+    assert np.array_equal(o["a0"]["image"], g["reset_obs"] / 255)
+    for t in range(len(g["actions"])):
+        o, r, d, info = env.step({"a0": g["actions"][t]})
+        img = o["a0"]["image"]
+        u = np.rint(img * 255).astype(np.uint8)
+        assert np.array_equal(u / 255, img)
+        if t < len(g["obs"]):
+            assert np.array_equal(u, g["obs"][t]), t
+        assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(u).tobytes()).digest(), np.uint8), g["obs_sha"][t]), t
+        assert float(r["a0"]) == g["rew"][t] and d["__all__"] == bool(g["done"][t]) and d["a0"] == d["__all__"]
+        keys = sorted(info["a0"].keys())
+        assert ",".join(keys) == str(g["info_keys"][t])
+        vals = np.concatenate([np.atleast_1d(np.asarray(info["a0"][k], np.float64)).ravel() for k in keys])
+        assert np.array_equal(vals, g["info_vals"][t]), t
+        st = np.random.get_state()
+        assert (int(st[2]), int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16)) == tuple(int(x) for x in g["mt"][t])
+    base.close()
