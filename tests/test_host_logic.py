@@ -13,7 +13,7 @@ def test_registry_tags():
     with pytest.raises(ValueError):
         ecf.env_creator("Nope", {})
     with pytest.raises(NotImplementedError):
-        ecf.env_creator("JointEnv", {})
+        ecf.env_creator("NegotiationSolver", {})
 
 
 def test_contract_specs():
