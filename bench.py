@@ -6,7 +6,7 @@ Workload (BASELINE.json north star / configs[3]): CleanupEnv `cleanup_new`, 8 ag
 collectives), horizon 1000 with in-engine auto-reset, uniform i.i.d. synthetic actions generated on
 device by the counter hash keyed (seed, global env index, t, agent) and resident in HBM before the
 timed region.  A "step" = one pass of the hot path over the whole env batch of this rank (MapEnv.step +
-obs crop + contract transfer for every env), issued as `--streams` (default 2) ce_step_range launches over
+obs crop + contract transfer for every env), issued as `--streams` (default 3) ce_step_range launches over
 contiguous env slices on separate HIP streams: slices are independent, so one slice's kernel tail overlaps
 the other's head (the same double buffering an RL sampler uses to overlap policy inference with stepping).
 
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--agents", type=int, default=N_AGENTS)
     ap.add_argument("--kind", default="cleanup", choices=["cleanup", "harvest"])
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="split each rank's env batch into this many contiguous slices stepped on separate HIP streams "
                          "(slices are independent; one slice's kernel tail overlaps the next slice's head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,9 +221,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    tj = json.load(open(tpath))
-                    if tj.get("envs_per_launch") == E // S and tj.get("agents") == n and tj.get("kind") == kind:
-                        traffic = tj.get("hbm_bytes_per_launch")
+                    tj = json.load(open(tpath))  # PMC bytes per env-step (traffic is linear in the envs of a launch)
+                    if tj.get("agents") == n and tj.get("kind") == kind:
+                        traffic = int(round(tj["hbm_bytes_per_env_step"] * (E // S)))
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -43,7 +43,7 @@ for sub in ("pmc1", "pmc2", "fetch", "write"):
     m, mm = counter_means(sub)
     per.update(m)
     meta = meta or mm
-waves = per["SQ_WAVES"]
+waves = per["SQ_WAVES"]  # mean over the dispatches of the step kernel (slices differ by one env)
 envs = int(round(waves))
 fetch_b = per["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reports half of wide coalesced reads
 write_b = per["WRITE_SIZE"] * 1024
@@ -69,8 +69,8 @@ out = {
     "round": int(tag[1:]),
     "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 50 --no-cpu-baseline ; "
                "PMC: separate `rocprofv3 --pmc <set>` passes of `python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline` "
-               "(bench default: 2 env slices of 8192 on 2 HIP streams)",
-    "kernel": "ce::k_grid_step<0> (cleanup_new n=8 + CleanupContract, %d envs per launch, one 64-lane workgroup per env, 2 launches in flight)" % envs,
+               "(bench default: the rank's 16384 envs as 3 contiguous slices on 3 HIP streams)",
+    "kernel": "ce::k_grid_step<0> (cleanup_new n=8 + CleanupContract, ~%d envs per launch, one 64-lane workgroup per env, 3 launches in flight)" % envs,
     "per_dispatch_mean": per,
     "dispatch_meta": meta,
     "per_wave": {c: round(v / waves, 1) for c, v in per.items() if c.startswith("SQ_")},
@@ -81,7 +81,8 @@ out = {
     "kernel_trace": kt,
 }
 json.dump(out, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
-json.dump({"kind": "cleanup", "envs_per_launch": envs, "agents": 8, "hbm_bytes_per_launch": traffic,
+json.dump({"kind": "cleanup", "agents": 8, "hbm_bytes_per_env_step": traffic / envs, "measured_envs_per_launch": envs,
+           "hbm_bytes_per_launch": traffic,
            "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the "
                      "gfx950 correction)" % tag}, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({"traffic": traffic, "algo": ALGO * envs, "kt": kt, "per_wave": out["per_wave"]}, indent=1))
