@@ -2002,7 +2002,11 @@ template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool w
   const GridTables& T = c_tab[GK];
   const u32 lane = E.lane;
   const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  for (u32 k = lane; k < (u32)kMtN; k += 64) E.L->mt_py[k] = rsrc[CE_RNG_WORDS_GRID + k];
+  {  // 624 words as 156 x 16 B
+    const auto src4 = (CE_GPTR(const uint4))(rsrc + CE_RNG_WORDS_GRID);
+    uint4* dst4 = (uint4*)E.L->mt_py;
+    for (u32 k = lane; k < (u32)kMtN / 4; k += 64) dst4[k] = src4[k];
+  }
   rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
   feat_base_map(E);
 #pragma unroll
@@ -2056,8 +2060,11 @@ template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
   const u32 lane = E.lane;
   wave_sync();
   const auto rdst = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  if (rfl(E.py.twists) != 0)
-    for (u32 k = lane; k < (u32)kMtN; k += 64) rdst[CE_RNG_WORDS_GRID + k] = E.L->mt_py[k];
+  if (rfl(E.py.twists) != 0) {
+    const auto dst4 = (CE_GPTR(uint4))(rdst + CE_RNG_WORDS_GRID);
+    const uint4* src4 = (const uint4*)E.L->mt_py;
+    for (u32 k = lane; k < (u32)kMtN / 4; k += 64) dst4[k] = src4[k];
+  }
   if (lane == 0) rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
   const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
 #pragma unroll
