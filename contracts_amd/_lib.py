@@ -14,7 +14,7 @@ KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "clea
 FEAT_KINDS = ("harvest_features", "cleanup_features")
 FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_* of the header
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
-FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION = 1, 2, 4, 8, 16
+FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FLAG_EXTERNAL_THETA = 1, 2, 4, 8, 16, 32
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4
 ERRORS = {-22: "CE_EINVAL", -12: "CE_ENOMEM", -19: "CE_ENODEV", -5: "CE_EIO", -34: "CE_ERANGE"}
 
@@ -57,6 +57,7 @@ EXPORTS = {
     "ce_create": (C.c_int, [C.POINTER(CeConfig), C.POINTER(C.c_void_p)]),
     "ce_destroy": (C.c_int, [C.c_void_p]),
     "ce_set_contract": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "ce_set_flags": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "ce_seed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "ce_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

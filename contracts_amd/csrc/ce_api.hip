@@ -320,6 +320,14 @@ extern "C" int ce_set_contract(ce_handle h, uint32_t contract, double contract_l
   return sync_device_params(h);
 }
 
+extern "C" int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
+  if (!h) return CE_EINVAL;
+  if (mask & ~(CE_FLAG_AUTO_RESET | CE_FLAG_EXTERNAL_THETA)) return fail(h, CE_EINVAL, "only AUTO_RESET and EXTERNAL_THETA can change on a live handle");
+  h->cfg.flags = (h->cfg.flags & ~mask) | (value & mask);
+  (void)hipSetDevice(h->cfg.device);
+  return sync_device_params(h);
+}
+
 static GridParams grid_params(ce_engine* h) {
   GridParams p;
   std::memset(&p, 0, sizeof(p));

@@ -1362,6 +1362,10 @@ template <int KIND> DEVINL bool setup_agents(Env<KIND>& E, u32 list_len) {
 
 template <int KIND> DEVINL void sample_theta(Env<KIND>& E, const GridParams& p, double& theta) {
   // SeparateContractSubgameStage.reset two_stage_train.py:163-166
+  if (p.flags & CE_FLAG_EXTERNAL_THETA) {  // the caller owns the theta buffer: a reset neither draws nor changes it
+    theta = p.theta[E.e];
+    return;
+  }
   if (p.contract == CE_CONTRACT_NONE) {
     theta = 0.0;
     return;
@@ -1981,8 +1985,8 @@ template <int GK> DEVINL void feat_np_draws(FEnv<GK>& E, const GridParams& p, bo
     const u32 w = rng_next(np, E.lane) & 3u;  // legacy randint(0, 4): one masked word
     if (E.lane == a) orient = w;
   }
-  theta = 0.0;
-  if (with_theta && p.contract != CE_CONTRACT_NONE) {  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
+  theta = (p.flags & CE_FLAG_EXTERNAL_THETA) ? p.theta[E.e] : 0.0;  // external: the caller owns the theta buffer
+  if (with_theta && p.contract != CE_CONTRACT_NONE && !(p.flags & CE_FLAG_EXTERNAL_THETA)) {  // SeparateContractSubgameStage.reset two_stage_train.py:163-166
     const double u0 = rng_double(np, E.lane);
     if (u0 > p.null_prob) {
       const double u1 = rng_double(np, E.lane);

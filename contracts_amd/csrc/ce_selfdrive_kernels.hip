@@ -138,7 +138,9 @@ template <int N> DEVINL void sd_reset_env(const SdParams& p, u32 e, Cars<N>& c, 
   c.done_all = false;
   c.ncross = 0;
   c.transfers = 0.0;
-  if (p.contract == CE_CONTRACT_NONE) {
+  if (p.flags & CE_FLAG_EXTERNAL_THETA) {  // the caller owns the theta buffer: a reset neither draws nor changes it
+    theta = p.theta[e];
+  } else if (p.contract == CE_CONTRACT_NONE) {
     theta = 0.0;
   } else {
     const double u0 = mtg_double(np_mt);

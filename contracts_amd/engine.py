@@ -32,7 +32,7 @@ _FIELD_DTYPES = {
 
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
-                env_index_base=0, device=0, contract_low=None, contract_high=None,
+                env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
                 low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8):
     cfg = CeConfig()
     cfg.abi_version = _lib.CE_ABI_VERSION
@@ -41,7 +41,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.contract = _lib.CONTRACT[contract]
     cfg.flags = (_lib.FLAG_FIRING * bool(firing) | _lib.FLAG_AUTO_RESET * bool(auto_reset)
                  | _lib.FLAG_COLLECTIVE * bool(collective) | _lib.FLAG_INEQUITY * bool(inequity)
-                 | _lib.FLAG_COLLISION * bool(collision_on))
+                 | _lib.FLAG_COLLISION * bool(collision_on) | _lib.FLAG_EXTERNAL_THETA * bool(external_theta))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
@@ -104,6 +104,16 @@ class BatchedEnv:
               "ce_set_contract")
         self.cfg.contract, self.cfg.contract_low, self.cfg.contract_high = _lib.CONTRACT[contract], lo, hi
         self.cfg.null_prob = float(null_prob)
+
+    def set_flags(self, auto_reset=None, external_theta=None):
+        """flip the run-time flags of the live handle (see ce_set_flags)"""
+        mask = value = 0
+        for flag, v in ((_lib.FLAG_AUTO_RESET, auto_reset), (_lib.FLAG_EXTERNAL_THETA, external_theta)):
+            if v is not None:
+                mask |= flag
+                value |= flag * bool(v)
+        check(self._L.ce_set_flags(self._h, mask, value), self._h, "ce_set_flags")
+        self.cfg.flags = (self.cfg.flags & ~mask) | value
 
     # ---- reference-protocol entry points ---------------------------------------------
     def seed(self, seeds=None, seed0=0, mask=None, replay_constructor=True):

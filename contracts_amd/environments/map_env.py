@@ -98,6 +98,8 @@ class GridEnvAdapter(_Base):
             c, lo, hi, null_prob = self._contract
             if c is not None:
                 self._engine.set_contract(c, lo, hi, null_prob)
+            if getattr(self, "_external_theta", False):
+                self._engine.set_flags(external_theta=True)
             pending = getattr(self, "_pending_state", None)
             if pending:
                 for field, arr in pending.items():

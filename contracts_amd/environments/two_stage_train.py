@@ -8,8 +8,15 @@ engine's step kernel, switched on for the base env's handle (ce_set_contract).
 global-map, concatenated-views or duplicated-feature observation — is a thin re-keying of the base env's dictionaries
 and is provided too.
 
-Out of scope: SeparateContractNegotiateStage, SeparateContractCombinedStage,
-NegotiationSolver — RL-algorithm logic that calls this path but is not it."""
+`SeparateContractNegotiateStage` / `SeparateContractCombinedStage` (two_stage_train.py:188-470) — propose a contract,
+accept or reject it, then play the subgame under it — are host-side protocol around the same engine path; the contract
+parameter is written into the engine's `theta` buffer (CE_FLAG_EXTERNAL_THETA: resets draw nothing).  The negotiate
+stage rolls the whole subgame inside one outer step with frozen policies: any object with RLlib's
+`compute_single_action(obs, policy_id=...)` serves (`trainer_factory`), `ray`'s PPOTrainer when it is installed.
+
+Out of scope (SURVEY.md §8f next #3): NegotiationSolver (needs the frozen policies' value heads)."""
+import copy
+import random
 import numpy as np
 
 from .. import spaces
@@ -33,6 +40,7 @@ class SeparateContractEnv(_Base):
         base_env._contract = contract.engine_spec(null_prob)
         if base_env._engine is not None:
             base_env._engine.set_contract(*base_env._contract)
+        self._external_theta(False)
         if self.convolutional:
             contract_space = spaces.Box(low=np.concatenate((self.contract_low, np.array([0.0]))),
                                         high=np.concatenate((self.contract_high, np.array([3.0]))))
@@ -50,6 +58,15 @@ class SeparateContractEnv(_Base):
 
     def _theta(self):
         return np.array([float(self.base_env._engine.download("theta")[0])])
+
+    def _external_theta(self, on):
+        """stages that take the contract parameter from an agent's action: the engine draws nothing at reset"""
+        self.base_env._external_theta = bool(on)
+        if self.base_env._engine is not None:
+            self.base_env._engine.set_flags(external_theta=bool(on))
+
+    def _set_theta(self, value):
+        self.base_env._ensure_engine().upload("theta", np.array([float(np.asarray(value).reshape(-1)[0])]))
 
     def _with_contract(self, obs, keys):
         theta = self.params["a0"]
@@ -153,3 +170,141 @@ class JointEnv(_Base):
 
     def render(self, mode="rgb"):
         return self.base_env.render()
+
+
+class _ProposalStages(SeparateContractEnv):
+    """what the negotiate and the combined stage share: contract_state 2 = propose, 3 = accept / reject, 0 = play"""
+
+    def _stage_reset(self, first_state):
+        base_obs = self.base_env.reset()
+        self._set_theta(0.0)
+        self.obs = copy.deepcopy(base_obs)
+        self.last_seen_obs = copy.deepcopy(base_obs)
+        self.params = None
+        self.contract_state = {"a" + str(i): first_state for i in range(self.num_agents)}
+        self.transferred_reward_dict = {"a" + str(i): [] for i in range(self.num_agents)}
+        zeros = np.zeros(self.contract_low.shape)
+        return self._stage_obs(self.obs, {k: zeros for k in self.contract_state})
+
+    def _stage_obs(self, source, params):
+        out = {}
+        for i in range(self.num_agents):
+            key = "a" + str(i)
+            tail = np.concatenate((params[key], np.array([self.contract_state[key]])))
+            if self.convolutional:
+                out[key] = source[key]
+                out[key].update({"contract": tail})
+            else:
+                out[key] = np.concatenate((source[key], tail))
+        return out
+
+    def _propose(self, proposal, acts):
+        self.params = {key: proposal for key in acts.keys()}
+        self.contract_state = {"a" + str(i): 3 for i in range(self.num_agents)}
+
+    def _decide(self, acts):
+        """two random responders (all of them when there are at most two) accept jointly with the product of their
+        acceptance probabilities; a rejected proposal plays as the null contract"""
+        responders = random.sample(range(1, self.num_agents), 2) if self.num_agents > 3 else range(1, self.num_agents)
+        prob = 1
+        for term in [acts["a" + str(i)][-1] for i in responders]:
+            prob *= term
+        decision = 1 if random.random() < prob else 0
+        null = np.zeros(shape=self.contract_low.shape)
+        for i in range(self.num_agents):
+            key = "a" + str(i)
+            self.contract_state[key] = 0
+            self.params[key] = self.params[key] if decision == 1 else null
+        self._set_theta(self.params["a0"])
+        return decision
+
+    def _zero(self):
+        return ({"a" + str(i): 0.0 for i in range(self.num_agents)}, {"a" + str(i): {} for i in range(self.num_agents)})
+
+
+class SeparateContractNegotiateStage(_ProposalStages):
+    def __init__(self, base_env, contract, num_agents, horizon, trainer_config, trainer_env, trainer_path, convolutional,
+                 shared, env_params=None, trainer_factory=None, **kwargs):
+        super().__init__(base_env, contract, num_agents, convolutional)
+        self._external_theta(True)
+        self.horizon = horizon
+        if trainer_factory is None:
+            try:  # pragma: no cover - RLlib is absent in the build image
+                from ray.rllib.agents import ppo
+                trainer_factory = ppo.PPOTrainer
+            except Exception as exc:
+                raise ImportError("the negotiate stage needs frozen subgame policies: install ray[rllib] or pass "
+                                  "trainer_factory=<callable returning an object with compute_single_action>") from exc
+        self.frozen_trainer = trainer_factory(config=trainer_config, env=trainer_env)
+        self.frozen_trainer.load_checkpoint(trainer_path)
+        self.shared = shared
+        self.action_space = spaces.Box(low=np.concatenate((self.contract_low, np.array([0.0]))),
+                                       high=np.concatenate((self.contract_high, np.array([1.0]))))
+        self.metrics = {"contract": -1, "accepted": 0}
+
+    def reset(self):
+        self.metrics = {"contract": -1, "accepted": 0}
+        return self._stage_reset(2)
+
+    def _policy_obs(self, key):
+        tail = np.concatenate((self.params[key], np.array([0])))
+        if self.convolutional:
+            obs = self.obs[key]
+            obs.update({"contract": tail})
+            return obs
+        return np.concatenate((self.obs[key], tail))
+
+    def step(self, acts):
+        rews, infos = self._zero()
+        if self.contract_state["a0"] == 2:
+            self.metrics["contract"] = acts["a0"][:-1]
+            self._propose(acts["a0"][:-1], acts)
+            dones = {"__all__": False}
+        else:
+            self.metrics["accepted"] = self._decide(acts)
+            dones = {"__all__": True}  # the negotiation ends here; the subgame is played out inside this step
+            env_dones = {"__all__": False}
+            active = ["a" + str(i) for i in range(self.num_agents)]
+            played = 0
+            while not env_dones["__all__"] and played < self.horizon:
+                act_dict = {key: self.frozen_trainer.compute_single_action(self._policy_obs(key), policy_id="policy" if self.shared else key)
+                            for key in active}
+                _, env_rews, env_dones, infos = super().step(act_dict)
+                self.last_seen_obs = {"a" + str(i): self.obs["a" + str(i)] if "a" + str(i) in self.obs else self.last_seen_obs["a" + str(i)]
+                                      for i in range(self.num_agents)}
+                played += 1
+                for key in active:
+                    rews[key] += env_rews[key]
+                active = [key for key in active if not env_dones.get(key, False)]
+        return self._stage_obs(self.last_seen_obs, self.params), rews, dones, infos
+
+
+class SeparateContractCombinedStage(_ProposalStages):
+    def __init__(self, base_env, contract, num_agents, convolutional, **kwargs):
+        super().__init__(base_env, contract, num_agents, convolutional)
+        self._external_theta(True)
+        self.continuous_action_space = hasattr(self.base_env, "continuous_action_space")
+        base_space = self.base_env.continuous_action_space if self.continuous_action_space else self.base_env.action_space
+        self._base_width = base_space.shape[0]
+        self.action_space = spaces.Box(low=np.concatenate((base_space.low, self.contract_low, np.array([0.0]))),
+                                       high=np.concatenate((base_space.high, self.contract_high, np.array([1.0]))))
+
+    def reset(self):
+        return self._stage_reset(2)
+
+    def step(self, acts):
+        state = self.contract_state["a0"]
+        if state == 2:
+            self._propose(acts["a0"][self._base_width:-1], acts)
+        elif state == 3:
+            self._decide(acts)
+        else:
+            if self.continuous_action_space:  # logits -> one sampled discrete action per agent (np.random, as the reference)
+                import scipy.special
+                base_acts = {key: int(np.argmax(np.random.multinomial(1, scipy.special.softmax(acts[key][:self._base_width].astype(np.float64)))))
+                             for key in acts.keys()}
+            else:
+                base_acts = {key: acts[key][:self._base_width] for key in acts.keys()}
+            return super().step(base_acts)
+        rews, infos = self._zero()
+        return self._stage_obs(self.last_seen_obs, self.params), rews, {"__all__": False}, infos

@@ -4,7 +4,8 @@ from ..environments.cleanup_new import CleanupEnv
 from ..environments.feature_envs import CleanupFeatures, HarvestFeatures
 from ..environments.harvest_new import HarvestEnv
 from ..environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
-from ..environments.two_stage_train import JointEnv, SeparateContractSubgameStage
+from ..environments.two_stage_train import (JointEnv, SeparateContractCombinedStage, SeparateContractNegotiateStage,
+                                            SeparateContractSubgameStage)
 
 _ACCELERATED = {
     "SelfDrive": SelfAcceleratingCarEnv,
@@ -12,11 +13,13 @@ _ACCELERATED = {
     "CleanupNew": CleanupEnv,
     "ContractWrapperSubgame": SeparateContractSubgameStage,
     "JointEnv": JointEnv,
+    "ContractWrapperNegotiate": SeparateContractNegotiateStage,
+    "ContractWrapperCombined": SeparateContractCombinedStage,
     "Harvest": HarvestFeatures,   # `harvest`: the feature-vector env of BASELINE config 0 (harvest_features.py)
     "Cleanup": CleanupFeatures,   # `cleanup` (cleanup_features.py)
 }
 # tags of the reference that are callers of the hot path, not the path itself
-_OUT_OF_SCOPE = ("ContractWrapperNegotiate", "ContractWrapperCombined", "NegotiationSolver")
+_OUT_OF_SCOPE = ("NegotiationSolver",)
 
 
 def env_creator(name, config):

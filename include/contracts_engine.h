@@ -65,6 +65,9 @@ enum ce_contract {
 #define CE_FLAG_COLLECTIVE_REWARD 0x4u /* map_env.py:289-292                                */
 #define CE_FLAG_INEQUITY_AVERSE 0x8u   /* map_env.py:293-301 (alpha, beta)                  */
 #define CE_FLAG_COLLISION_ON 0x10u     /* self_driving_car_accelerate.py:195-215            */
+#define CE_FLAG_EXTERNAL_THETA 0x20u   /* the contract parameter is set by the caller (write the `theta` buffer) instead of
+                                         being drawn at reset (resets leave it untouched): the negotiate / combined stages of two_stage_train.py
+                                         (:215-358, :373-470) reset the base env only and take theta from an agent's action */
 
 typedef struct ce_config {
   uint32_t abi_version;    /* CE_ABI_VERSION                                               */
@@ -218,6 +221,9 @@ int ce_destroy(ce_handle h);
  * (two_stage_train.py:34-44,152-157): switches the fused contract epilogue of an existing
  * handle on/off and sets the contract space + null_prob.  Takes effect at the next reset/step. */
 int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob);
+/* flips run-time flags of a live handle: flags = (flags & ~mask) | (value & mask); only CE_FLAG_AUTO_RESET and
+ * CE_FLAG_EXTERNAL_THETA may change after ce_create */
+int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value);
 
 /* Replaces: np.random.seed(s) (+ random.seed(s)) followed by CONSTRUCTING the env
  * (MapEnv.__init__ -> setup_agents consumes RNG: map_env.py:131,816-832; CleanupEnv then

@@ -875,6 +875,7 @@ static void grid_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
 
 static void sample_theta(orc_t* o, env_t* e) {
   /* SeparateContractSubgameStage.reset two_stage_train.py:163-166 */
+  if (o->cfg.flags & CE_FLAG_EXTERNAL_THETA) return; /* the caller owns theta: a reset neither draws nor changes it */
   if (o->cfg.contract == CE_CONTRACT_NONE) {
     e->theta = 0;
     return;

@@ -16,7 +16,7 @@ KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "clea
 FEAT_KINDS = ("harvest_features", "cleanup_features")
 FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
-FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION = 1, 2, 4, 8, 16
+FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FLAG_EXTERNAL_THETA = 1, 2, 4, 8, 16, 32
 
 
 class CeConfig(C.Structure):
@@ -61,7 +61,7 @@ CONTRACT_SPACE = {
 
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
-                env_index_base=0, device=0, contract_low=None, contract_high=None):
+                env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False):
     cfg = CeConfig()
     cfg.abi_version = 1
     cfg.kind = KIND[kind]
@@ -70,7 +70,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.horizon = horizon
     cfg.contract = CONTRACT[contract]
     cfg.flags = (FLAG_FIRING * bool(firing) | FLAG_AUTO_RESET * bool(auto_reset) | FLAG_COLLECTIVE * bool(collective)
-                 | FLAG_INEQUITY * bool(inequity) | FLAG_COLLISION * bool(collision_on))
+                 | FLAG_INEQUITY * bool(inequity) | FLAG_COLLISION * bool(collision_on) | FLAG_EXTERNAL_THETA * bool(external_theta))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))

@@ -142,3 +142,33 @@ def load_reference():
     ns.SeparateContractSubgameStage = SeparateContractSubgameStage
     ns.contract_list = contract_list
     return ns
+
+
+class StubPPOTrainer:
+    """Deterministic stand-in for `ray.rllib.agents.ppo.PPOTrainer` (frozen subgame policies of the negotiate stage):
+    actions come from a counter-seeded RandomState, independent of the observation, so that the reference stage and
+    the rebuilt one — both handed this class — ask for the same action sequence."""
+
+    def __init__(self, config=None, env=None):
+        self.n_act = int(config["n_act"])
+        self.rs = np.random.RandomState(int(config["seed"]))
+        self.calls = []
+
+    def load_checkpoint(self, path):
+        pass
+
+    restore = load_checkpoint
+
+    def compute_single_action(self, obs, policy_id=None, **kw):
+        self.calls.append(policy_id)
+        return int(self.rs.randint(self.n_act))
+
+
+def install_stub_trainer():
+    """make `from ray.rllib.agents import ppo; ppo.PPOTrainer` resolve to StubPPOTrainer inside the reference"""
+    _install_stubs()
+    ppo = types.ModuleType("ray.rllib.agents.ppo")
+    ppo.PPOTrainer = StubPPOTrainer
+    sys.modules["ray.rllib.agents.ppo"] = ppo
+    sys.modules["ray.rllib.agents"].ppo = ppo
+    return ppo

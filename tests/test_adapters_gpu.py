@@ -205,3 +205,76 @@ def test_joint_env_trace(name):
         st = np.random.get_state()
         assert (int(st[2]), int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16)) == tuple(int(x) for x in g["mt"][t])
     base.close()
+
+
+def _fps():
+    st, ps = np.random.get_state(), random.getstate()[1]
+    return [int(st[2]), int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16),
+            int(ps[624]), int(hashlib.sha256(np.array(ps[:624], np.uint32).tobytes()).hexdigest()[:8], 16)]
+
+
+def _check_stage_obs(o, keys, sha_ref, contract_ref, tag):
+    img = np.stack([np.rint(np.asarray(o[k]["image"]) * 255).astype(np.uint8) for k in keys])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(img.tobytes()).digest(), np.uint8), sha_ref), "image " + tag
+    assert np.array_equal(np.stack([np.asarray(o[k]["contract"], np.float64) for k in keys]), contract_ref), "contract obs " + tag
+
+
+@pytest.mark.gpu
+def test_combined_stage_trace():
+    """SeparateContractCombinedStage (propose / accept / play in one action space) against the reference's own trace"""
+    from contracts_amd.contract import contract_list
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractCombinedStage
+    g = np.load("%s/stage_combined_cleanup_n4.npz" % gc.GOLDEN_DIR)
+    n, seed, horizon = int(g["n"]), int(g["seed"]), int(g["horizon"])
+    np.random.seed(seed)
+    random.seed(seed)
+    base = CleanupEnv(num_agents=n, horizon=horizon)
+    env = SeparateContractCombinedStage(base, contract_list.CleanupContract(n), n, True)
+    assert np.array_equal(env.action_space.low, g["action_low"]) and np.array_equal(env.action_space.high, g["action_high"])
+    keys = ["a%d" % i for i in range(n)]
+    o = env.reset()
+    _check_stage_obs(o, keys, g["reset_sha"], g["reset_contract"], "reset")
+    for t in range(len(g["actions"])):
+        o, r, d, info = env.step({k: g["actions"][t][i] for i, k in enumerate(keys)})
+        _check_stage_obs(o, keys, g["obs_sha"][t], g["contract_obs"][t], "step %d" % t)
+        np.testing.assert_allclose([float(r[k]) for k in keys], g["rew"][t], rtol=0, atol=1e-9)
+        assert d["__all__"] == bool(g["done"][t]) and _fps() == list(g["fp"][t]), t
+        if d["__all__"]:
+            env.reset()
+    base.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stage_negotiate_cleanup_n4", "stage_negotiate_cleanup_n2"])
+def test_negotiate_stage_trace(name):
+    """SeparateContractNegotiateStage: the subgame is rolled to termination inside one outer step with frozen policies
+    (the harness's deterministic StubPPOTrainer on both sides)"""
+    import sys
+    sys.path.insert(0, gc.GOLDEN_DIR)
+    from ref_harness import StubPPOTrainer
+    from contracts_amd.contract import contract_list
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractNegotiateStage
+    g = np.load("%s/%s.npz" % (gc.GOLDEN_DIR, name))
+    n, seed, horizon = int(g["n"]), int(g["seed"]), int(g["horizon"])
+    np.random.seed(seed)
+    random.seed(seed)
+    base = CleanupEnv(num_agents=n, horizon=horizon)
+    env = SeparateContractNegotiateStage(base, contract_list.CleanupContract(n), n, horizon, {"n_act": 8, "seed": seed + 7},
+                                         "stub-env", "stub-path", True, False, trainer_factory=StubPPOTrainer)
+    assert np.array_equal(env.action_space.low, g["action_low"]) and np.array_equal(env.action_space.high, g["action_high"])
+    keys = ["a%d" % i for i in range(n)]
+    t = 0
+    for ep in range(len(g["accepted"])):
+        env.reset()
+        for stage in range(2):
+            o, r, d, info = env.step({k: g["actions"][t][i] for i, k in enumerate(keys)})
+            _check_stage_obs(o, keys, g["obs_sha"][t], g["contract_obs"][t], "ep %d stage %d" % (ep, stage))
+            np.testing.assert_allclose([float(r[k]) for k in keys], g["rew"][t], rtol=0, atol=1e-9)
+            assert d["__all__"] == bool(g["done"][t]) and _fps() == list(g["fp"][t]), (ep, stage)
+            t += 1
+        assert int(env.metrics["accepted"]) == int(g["accepted"][ep])
+        assert np.array_equal(np.asarray(env.metrics["contract"], np.float64), g["proposed"][ep])
+        assert len(env.frozen_trainer.calls) == int(g["trainer_calls"][ep])
+    base.close()

@@ -268,3 +268,38 @@ def test_full_size_partition_invariance_and_oracle_sample():
     ref.close()
     whole.close()
     orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,contract", [("cleanup", 4, "cleanup"), ("harvest", 5, "harvest_local"), ("cleanup_features", 3, "cleanup")])
+def test_external_theta_one_contract_per_env(kind, n, contract):
+    """CE_FLAG_EXTERNAL_THETA: the caller writes one contract parameter per env (batched evaluation of many sampled
+    contracts at once); resets draw nothing from np.random and leave the parameters alone"""
+    from contracts_amd.engine import BatchedEnv
+    from oracle.pyoracle import Oracle
+    E, T = 128, 70
+    kw = dict(contract=contract, horizon=23, auto_reset=True, external_theta=True)
+    env, orc = BatchedEnv(kind, E, n, **kw), Oracle(kind, E, n, **kw)
+    rs = np.random.RandomState(12)
+    thetas = rs.uniform(0.0, 0.2 if contract == "cleanup" else 10.0, size=E)
+    for o in (env, orc):
+        o.seed(seed0=4242)
+    env.upload("theta", thetas)
+    orc.theta[...] = thetas
+    orc.import_state()
+    for o in (env, orc):
+        o.reset()
+    assert np.array_equal(env.download("theta"), thetas) and np.array_equal(orc.theta, thetas)
+    na = env.num_actions
+    p = np.array([.1, .1, .15, .1, .05, .1, .1, .3]) if contract == "cleanup" else None
+    for t in range(T):
+        a = rs.choice(na, size=(E, n), p=p).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        np.testing.assert_allclose(env.download("reward"), orc.reward, rtol=0, atol=1e-9)
+        assert np.array_equal(env.download("rng").reshape(E, -1, 628)[:, :, :625], orc.rng.reshape(E, -1, 628)[:, :, :625])
+        assert np.array_equal(env.download("theta"), thetas)
+        np.testing.assert_allclose(env.download("f64_metrics"), orc.f64_metrics, rtol=0, atol=1e-9)
+    assert np.abs(env.download("final_f64_metrics")[:, 0]).max() > 0  # transfers did happen
+    env.close()
+    orc.close()
