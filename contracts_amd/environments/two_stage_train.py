@@ -14,7 +14,10 @@ parameter is written into the engine's `theta` buffer (CE_FLAG_EXTERNAL_THETA: r
 stage rolls the whole subgame inside one outer step with frozen policies: any object with RLlib's
 `compute_single_action(obs, policy_id=...)` serves (`trainer_factory`), `ray`'s PPOTrainer when it is installed.
 
-Out of scope (SURVEY.md §8f next #3): NegotiationSolver (needs the frozen policies' value heads)."""
+`NegotiationSolver` (two_stage_train.py:619-776) picks the contract at reset instead of learning to propose one: it
+scores the null contract and `contract_samples` random ones with the frozen policies' value heads
+(`trainer.get_policy(id).model.value_function()` after a forward pass) and keeps the best under the 'max' or the
+'majority' rule; the episode then runs on the engine under that parameter."""
 import copy
 import random
 import numpy as np
@@ -228,15 +231,7 @@ class SeparateContractNegotiateStage(_ProposalStages):
         super().__init__(base_env, contract, num_agents, convolutional)
         self._external_theta(True)
         self.horizon = horizon
-        if trainer_factory is None:
-            try:  # pragma: no cover - RLlib is absent in the build image
-                from ray.rllib.agents import ppo
-                trainer_factory = ppo.PPOTrainer
-            except Exception as exc:
-                raise ImportError("the negotiate stage needs frozen subgame policies: install ray[rllib] or pass "
-                                  "trainer_factory=<callable returning an object with compute_single_action>") from exc
-        self.frozen_trainer = trainer_factory(config=trainer_config, env=trainer_env)
-        self.frozen_trainer.load_checkpoint(trainer_path)
+        self.frozen_trainer = _frozen_trainer(trainer_factory, trainer_config, trainer_env, trainer_path, "the negotiate stage")
         self.shared = shared
         self.action_space = spaces.Box(low=np.concatenate((self.contract_low, np.array([0.0]))),
                                        high=np.concatenate((self.contract_high, np.array([1.0]))))
@@ -277,6 +272,94 @@ class SeparateContractNegotiateStage(_ProposalStages):
                     rews[key] += env_rews[key]
                 active = [key for key in active if not env_dones.get(key, False)]
         return self._stage_obs(self.last_seen_obs, self.params), rews, dones, infos
+
+
+def _frozen_trainer(trainer_factory, trainer_config, trainer_env, trainer_path, what):
+    if trainer_factory is None:
+        try:  # pragma: no cover - RLlib is absent in the build image
+            from ray.rllib.agents import ppo
+            trainer_factory = ppo.PPOTrainer
+        except Exception as exc:
+            raise ImportError("%s needs frozen subgame policies: install ray[rllib] or pass "
+                              "trainer_factory=<callable returning an object with compute_single_action>" % what) from exc
+    trainer = trainer_factory(config=trainer_config, env=trainer_env)
+    trainer.load_checkpoint(trainer_path)
+    return trainer
+
+
+class NegotiationSolver(SeparateContractEnv):
+    """Contract chosen by search over the frozen value functions (reference two_stage_train.py:619-776).
+
+    reset(): base reset, then V_i(s0, c) for the null contract and `contract_samples` draws of
+    `Box(contract_low, contract_high).sample()`; decision_rule 'max' keeps the draw with the largest welfare
+    sum_i V_i, 'majority' first drops draws that fewer than half of the agents strictly prefer to the null contract
+    (the null contract always stays a candidate).  Ties go to the earliest candidate (np.argmax)."""
+
+    def __init__(self, base_env, contract, num_agents, horizon, trainer_config, trainer_env, trainer_path, convolutional,
+                 shared, env_params=None, contract_samples=50, decision_rule="majority", trainer_factory=None, **kwargs):
+        super().__init__(base_env, contract, num_agents, convolutional)
+        self._external_theta(True)
+        self.horizon = horizon
+        self.frozen_trainer = _frozen_trainer(trainer_factory, trainer_config, trainer_env, trainer_path, "NegotiationSolver")
+        self.shared = shared
+        self.contract_param_space = spaces.Box(low=contract.contract_space.low, high=contract.contract_space.high)
+        self.num_samples = contract_samples
+        self.decision_rule = decision_rule
+        self.config = trainer_config
+        self.action_space = self.base_env.action_space
+        self._agents = ["a" + str(i) for i in range(num_agents)]
+
+    def reset(self):
+        self.metrics = {"contract": -1, "accepted": 0}
+        base_obs = self.base_env.reset()
+        self.obs = copy.deepcopy(base_obs)
+        self.last_seen_obs = copy.deepcopy(base_obs)
+        self.params = None
+        self.contract_state = {k: 0 for k in self._agents}
+        self.transferred_reward_dict = {k: [] for k in self._agents}
+        self.contract_param = self.negotiate()
+        self.params = {k: self.contract_param for k in self._agents}
+        self._set_theta(self.contract_param)
+        return self._with_contract(self.obs, self._agents)
+
+    def compute_vals(self, obs):
+        vals = {}
+        for key in obs:
+            policy_id = "policy" if self.shared else key
+            self.frozen_trainer.compute_single_action(obs[key], policy_id=policy_id)  # forward pass fills the value head
+            vals[key] = self.frozen_trainer.get_policy(policy_id).model.value_function().item()
+        return vals
+
+    def _candidate_obs(self, param):
+        tail = np.concatenate((param, np.array([0])))
+        if self.convolutional:
+            out = {}
+            for key in self._agents:
+                out[key] = self.obs[key]
+                out[key].update({"contract": tail})
+            return out
+        return {key: np.concatenate((self.obs[key], tail)) for key in self.contract_state.keys()}
+
+    def negotiate(self):
+        params, vals = [self.contract_low], [self.compute_vals(self._candidate_obs(self.contract_low))]
+        for _ in range(self.num_samples):
+            params.append(self.contract_param_space.sample())
+            vals.append(self.compute_vals(self._candidate_obs(params[-1])))
+        return self.compute_best_param(vals, params)
+
+    def compute_best_param(self, all_vals, all_params, dec_rule=None):
+        rule = self.decision_rule if dec_rule is None else dec_rule
+        if rule == "max":
+            return all_params[int(np.argmax([sum(v.values()) for v in all_vals]))]
+        if rule == "majority":
+            null = all_vals[0]
+            keep = [0]
+            for v in all_vals[1:]:
+                ayes = sum(1 for k in v if v[k] > null[k])
+                if ayes >= len(v) - ayes:
+                    keep.append(all_vals.index(v))  # first candidate with these values, as the reference resolves it
+            return self.compute_best_param([all_vals[i] for i in keep], [all_params[i] for i in keep], dec_rule="max")
+        return None
 
 
 class SeparateContractCombinedStage(_ProposalStages):

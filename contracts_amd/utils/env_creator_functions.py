@@ -4,8 +4,8 @@ from ..environments.cleanup_new import CleanupEnv
 from ..environments.feature_envs import CleanupFeatures, HarvestFeatures
 from ..environments.harvest_new import HarvestEnv
 from ..environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
-from ..environments.two_stage_train import (JointEnv, SeparateContractCombinedStage, SeparateContractNegotiateStage,
-                                            SeparateContractSubgameStage)
+from ..environments.two_stage_train import (JointEnv, NegotiationSolver, SeparateContractCombinedStage,
+                                            SeparateContractNegotiateStage, SeparateContractSubgameStage)
 
 _ACCELERATED = {
     "SelfDrive": SelfAcceleratingCarEnv,
@@ -15,18 +15,15 @@ _ACCELERATED = {
     "JointEnv": JointEnv,
     "ContractWrapperNegotiate": SeparateContractNegotiateStage,
     "ContractWrapperCombined": SeparateContractCombinedStage,
+    "NegotiationSolver": NegotiationSolver,
     "Harvest": HarvestFeatures,   # `harvest`: the feature-vector env of BASELINE config 0 (harvest_features.py)
     "Cleanup": CleanupFeatures,   # `cleanup` (cleanup_features.py)
 }
-# tags of the reference that are callers of the hot path, not the path itself
-_OUT_OF_SCOPE = ("NegotiationSolver",)
 
 
 def env_creator(name, config):
     if name in _ACCELERATED:
         return _ACCELERATED[name](**config)
-    if name in _OUT_OF_SCOPE:
-        raise NotImplementedError("env tag %r is outside the accelerated hot path (SURVEY.md §8f)" % name)
     raise ValueError("Environment not found")
 
 

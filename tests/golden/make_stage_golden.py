@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden fixtures for the negotiate / combined stages of two_stage_train.py (:188-470) over CleanupEnv, produced by
+"""Golden fixtures for the negotiate / combined stages and the NegotiationSolver of two_stage_train.py (:188-470, :619-776) over CleanupEnv, produced by
 RUNNING the upstream reference (ref_harness.py).  The frozen subgame policies of the negotiate stage are the harness's
 StubPPOTrainer (deterministic, observation-independent).  Build-container only."""
 import hashlib
@@ -93,11 +93,47 @@ def run_negotiate(R, n, seed, horizon, episodes):
     return out
 
 
+def run_solver(R, n, seed, horizon, episodes, rule, samples, steps):
+    import environments.two_stage_train as tst
+    tst.ppo = install_stub_trainer()
+    np.random.seed(seed)
+    random.seed(seed)
+    base = R.CleanupEnv(num_agents=n, horizon=horizon)
+    con = R.contract_list.CleanupContract(n)
+    env = tst.NegotiationSolver(base, con, n, horizon, {"n_act": 8, "seed": seed + 7}, "stub-env", "stub-path", True, False,
+                                contract_samples=samples, decision_rule=rule)
+    keys = ["a%d" % i for i in range(n)]
+    ars = np.random.RandomState(seed + 1)
+    rec = {k: [] for k in ("actions", "obs_sha", "contract_obs", "rew", "done", "fp", "chosen", "reset_sha", "reset_contract")}
+    out = {"kind": "cleanup", "n": n, "seed": seed, "horizon": horizon, "rule": rule, "samples": samples, "steps": steps}
+    for ep in range(episodes):
+        o = env.reset()
+        sha, c = pack_obs(o, keys)
+        rec["reset_sha"].append(sha)
+        rec["reset_contract"].append(c)
+        rec["chosen"].append(np.asarray(env.contract_param, np.float64))
+        for t in range(steps):
+            a = ars.randint(0, 8, size=n)
+            o, r, d, info = env.step({k: int(a[i]) for i, k in enumerate(keys)})
+            sha, c = pack_obs(o, keys)
+            rec["actions"].append(a)
+            rec["obs_sha"].append(sha)
+            rec["contract_obs"].append(c)
+            rec["rew"].append([float(r[k]) for k in keys])
+            rec["done"].append(np.uint8(d["__all__"]))
+            rec["fp"].append(fps())
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    return out
+
+
 def main():
     R = load_reference()
     for name, out in (("stage_combined_cleanup_n4", run_combined(R, 4, 75001, 30, 100)),
                       ("stage_negotiate_cleanup_n4", run_negotiate(R, 4, 75002, 25, 4)),
-                      ("stage_negotiate_cleanup_n2", run_negotiate(R, 2, 75003, 20, 3))):
+                      ("stage_negotiate_cleanup_n2", run_negotiate(R, 2, 75003, 20, 3)),
+                      ("stage_solver_majority_cleanup_n4", run_solver(R, 4, 75004, 40, 3, "majority", 12, 40)),
+                      ("stage_solver_max_cleanup_n3", run_solver(R, 3, 75005, 30, 4, "max", 25, 30))):
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print("%-30s %6.1f KB  steps %d" % (name, os.path.getsize(path) / 1024, len(out["actions"])))

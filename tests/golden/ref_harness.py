@@ -161,7 +161,23 @@ class StubPPOTrainer:
 
     def compute_single_action(self, obs, policy_id=None, **kw):
         self.calls.append(policy_id)
+        self._last = (obs, policy_id)
         return int(self.rs.randint(self.n_act))
+
+    # value head of the "policy" that just ran (NegotiationSolver reads trainer.get_policy(id).model.value_function()):
+    # a smooth function of the contract parameter in the observation, different per policy, plus seeded noise
+    def get_policy(self, policy_id):
+        return self
+
+    @property
+    def model(self):
+        return self
+
+    def value_function(self):
+        obs, policy_id = self._last
+        c = float(obs["contract"][0]) if isinstance(obs, dict) else float(np.asarray(obs)[-2])
+        idx = 0 if policy_id == "policy" else int(policy_id[1:])
+        return np.float32(3.0 * np.sin(23.0 * c + 1.7 * idx + 4.0) + 0.05 * self.rs.standard_normal())
 
 
 def install_stub_trainer():

@@ -278,3 +278,37 @@ def test_negotiate_stage_trace(name):
         assert np.array_equal(np.asarray(env.metrics["contract"], np.float64), g["proposed"][ep])
         assert len(env.frozen_trainer.calls) == int(g["trainer_calls"][ep])
     base.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stage_solver_majority_cleanup_n4", "stage_solver_max_cleanup_n3"])
+def test_negotiation_solver_trace(name):
+    """NegotiationSolver: the contract is searched at reset over the frozen value heads (the harness's stub on both
+    sides), then the episode runs under it — chosen parameter, observations, transferred rewards and both RNG streams"""
+    import sys
+    sys.path.insert(0, gc.GOLDEN_DIR)
+    from ref_harness import StubPPOTrainer
+    from contracts_amd.contract import contract_list
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.two_stage_train import NegotiationSolver
+    g = np.load("%s/%s.npz" % (gc.GOLDEN_DIR, name))
+    n, seed, horizon, steps = int(g["n"]), int(g["seed"]), int(g["horizon"]), int(g["steps"])
+    np.random.seed(seed)
+    random.seed(seed)
+    base = CleanupEnv(num_agents=n, horizon=horizon)
+    env = NegotiationSolver(base, contract_list.CleanupContract(n), n, horizon, {"n_act": 8, "seed": seed + 7}, "stub-env",
+                            "stub-path", True, False, contract_samples=int(g["samples"]), decision_rule=str(g["rule"]),
+                            trainer_factory=StubPPOTrainer)
+    keys = ["a%d" % i for i in range(n)]
+    t = 0
+    for ep in range(len(g["chosen"])):
+        o = env.reset()
+        assert np.array_equal(np.asarray(env.contract_param, np.float64), g["chosen"][ep]), ep
+        _check_stage_obs(o, keys, g["reset_sha"][ep], g["reset_contract"][ep], "ep %d reset" % ep)
+        for s in range(steps):
+            o, r, d, info = env.step({k: int(g["actions"][t][i]) for i, k in enumerate(keys)})
+            _check_stage_obs(o, keys, g["obs_sha"][t], g["contract_obs"][t], "ep %d step %d" % (ep, s))
+            np.testing.assert_allclose([float(r[k]) for k in keys], g["rew"][t], rtol=0, atol=1e-6)
+            assert d["__all__"] == bool(g["done"][t]) and _fps() == list(g["fp"][t]), (ep, s)
+            t += 1
+    base.close()
