@@ -15,6 +15,8 @@ FEAT_KINDS = ("harvest_features", "cleanup_features")
 FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_* of the header
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
 FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FLAG_EXTERNAL_THETA = 1, 2, 4, 8, 16, 32
+FLAG_BEAM_TRACE = 64
+BEAM_NONE, BEAM_FIRE, BEAM_CLEAN = 0, 1, 2
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4
 ERRORS = {-22: "CE_EINVAL", -12: "CE_ENOMEM", -19: "CE_ENODEV", -5: "CE_EIO", -34: "CE_ERANGE"}
 
@@ -46,7 +48,7 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P),
+        ("error_flags", _P), ("beam_map", _P),
     ]
 
 

@@ -176,6 +176,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (cfg->kind == CE_KIND_HARVEST_FEATURES && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
   if (is_feat(*cfg) && (cfg->flags & (CE_FLAG_COLLECTIVE_REWARD | CE_FLAG_INEQUITY_AVERSE | CE_FLAG_FIRING_ENABLED))) return CE_EINVAL;
   if ((cfg->flags & CE_FLAG_INEQUITY_AVERSE) && cfg->num_agents < 2) return CE_EINVAL;  // map_env.py:294 assertion
+  if ((cfg->flags & CE_FLAG_BEAM_TRACE) && !is_grid(*cfg)) return CE_EINVAL;
 
   ce_engine* h = new (std::nothrow) ce_engine();
   if (!h) return CE_ENOMEM;
@@ -231,6 +232,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     A(rng, E * CE_RNG_WORDS_GRID);
     A(obs, E * b.obs_env_stride + 16);
     A(features, E * n * b.num_features);
+    A(beam_map, E * b.grid_h * b.grid_w);
   } else if (is_feat(*cfg)) {
     const bool cl = cfg->kind == CE_KIND_CLEANUP_FEATURES;
     b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
@@ -322,7 +324,9 @@ extern "C" int ce_set_contract(ce_handle h, uint32_t contract, double contract_l
 
 extern "C" int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
   if (!h) return CE_EINVAL;
-  if (mask & ~(CE_FLAG_AUTO_RESET | CE_FLAG_EXTERNAL_THETA)) return fail(h, CE_EINVAL, "only AUTO_RESET and EXTERNAL_THETA can change on a live handle");
+  if (mask & ~(CE_FLAG_AUTO_RESET | CE_FLAG_EXTERNAL_THETA | CE_FLAG_BEAM_TRACE))
+    return fail(h, CE_EINVAL, "only AUTO_RESET, EXTERNAL_THETA and BEAM_TRACE can change on a live handle");
+  if ((mask & value & CE_FLAG_BEAM_TRACE) && !is_grid(h->cfg)) return fail(h, CE_EINVAL, "BEAM_TRACE belongs to the grid kinds");
   h->cfg.flags = (h->cfg.flags & ~mask) | (value & mask);
   (void)hipSetDevice(h->cfg.device);
   return sync_device_params(h);
@@ -351,6 +355,7 @@ static GridParams grid_params(ce_engine* h) {
   p.final_f64_metrics = b.final_f64_metrics;
   p.error_flags = b.error_flags;
   p.debug = h->d_debug;
+  p.beam_map = b.beam_map;
   p.E = h->cfg.num_envs;
   p.n = h->cfg.num_agents;
   p.horizon = h->cfg.horizon;
@@ -625,6 +630,7 @@ static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
       {"final_int_metrics", b.final_int_metrics, (size_t)b.num_int_metrics * 8},
       {"final_f64_metrics", b.final_f64_metrics, (size_t)b.num_f64_metrics * 8},
       {"error_flags", b.error_flags, 4},
+      {"beam_map", b.beam_map, (size_t)b.grid_h * b.grid_w},
       {"debug", h->d_debug, 128},
   };
   for (const FieldDesc& f : fields)

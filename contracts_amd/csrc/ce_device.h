@@ -92,6 +92,7 @@ struct GridParams {
   CE_GPTR(double) final_f64_metrics;
   CE_GPTR(uint32_t) error_flags;
   CE_GPTR(unsigned long long) debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
+  CE_GPTR(uint8_t) beam_map;          // [E][H*W] CE_BEAM_*, written under CE_FLAG_BEAM_TRACE only
   // inputs
   CE_GPTR(const uint8_t) actions;  // [E][n]
   CE_GPTR(const uint8_t) mask;     // [E] or null (seed/reset)

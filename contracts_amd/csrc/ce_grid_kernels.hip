@@ -989,7 +989,15 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
 // beams (update_map_fire map_env.py:721-814); lanes 0..14 = 3 rays x 5 cells
 // returns number of cells cleaned (CLEAN) — hits are applied to E.RW (FIRE)
 // ----------------------------------------------------------------------------------------
-template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean) {
+// render support (CE_FLAG_BEAM_TRACE): MapEnv.beam_pos as a per-cell map, cleared at step entry and by reset()
+template <int KIND> DEVINL void clear_beam_map(Env<KIND>& E, const GridParams& p) {
+  typedef Geo<KIND> G;
+  const auto bm = p.beam_map + (size_t)E.e * (G::H * G::W);
+  for (u32 k = E.lane; k < (u32)(G::H * G::W); k += 64) GAT(bm, k) = CE_BEAM_NONE;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the beams of this step overwrite these bytes from other lanes
+}
+
+template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, const GridParams& p, u32 firer, bool is_clean) {
   typedef Geo<KIND> G;
   const u32 lane = E.lane;
   const u32 o = rdl(E.O, firer), p0 = rdl(E.P, firer);
@@ -1009,6 +1017,11 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, u32 firer, bool is_clean)
   const u32 rb = (u32)(S >> (5 * ray)) & 31u;
   const u32 f = rb ? (u32)__builtin_ctz(rb) : 5u;  // first stopping cell of this ray
   const bool processed = in_beam && (step < f || (step == f && !invalid));
+  if (p.flags & CE_FLAG_BEAM_TRACE) {  // firing_points (map_env.py:788,813); the walls around the map keep them inside
+    const auto bm = p.beam_map + (size_t)E.e * (G::H * G::W);
+    if (processed) GAT(bm, __umul24(row_of<KIND>(cell), (u32)G::W) + col_of<KIND>(cell)) = is_clean ? CE_BEAM_CLEAN : CE_BEAM_FIRE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a later beam of this step overwrites in list order
+  }
   u32 cleaned = 0;
   if (is_clean) {
     const bool upd = processed && code == CE_CELL_WASTE;
@@ -1392,6 +1405,7 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
   }
   mark_agents(E);
   zero_metrics(E, p);
+  if (p.flags & CE_FLAG_BEAM_TRACE) clear_beam_map(E, p);  // self.beam_pos = [] (map_env.py:316)
   custom_map_update(E);
   t = 0;
   sample_theta(E, p, theta);
@@ -1662,6 +1676,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 
   // ---------------- MapEnv.step ----------------
   t += 1;
+  if (p.flags & CE_FLAG_BEAM_TRACE) clear_beam_map(E, p);  // self.beam_pos = [] (map_env.py:231)
   CE_STAMP(1);
 #ifndef CE_ABLATE_MOVES
   update_moves(E, ACT);
@@ -1714,11 +1729,11 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
         const u32 a = rdl(IDS, k);
         const u32 act = rdl(act_at, k);
         if (KIND == CE_KIND_CLEANUP && act == 7) {
-          const u32 c = fire_beam(E, a, true);
+          const u32 c = fire_beam(E, p, a, true);
           if (lane == a) cleaned = c;
         } else {
           if (lane == a) E.RW -= 1;  // fire_beam(b"F")
-          fire_beam(E, a, false);
+          fire_beam(E, p, a, false);
         }
       }
     }

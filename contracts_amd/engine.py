@@ -27,13 +27,14 @@ _FIELD_DTYPES = {
     "base_reward": np.int32, "reward": np.float64, "done": np.uint8, "done_agents": np.uint8, "info": np.uint8,
     "features": np.int16, "int_metrics": np.int64, "f64_metrics": np.float64, "final_int_metrics": np.int64,
     "final_f64_metrics": np.float64, "error_flags": np.uint32, "debug": np.uint64,
+    "beam_map": np.uint8,
 }
 
 
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
-                low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8):
+                beam_trace=False, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8):
     cfg = CeConfig()
     cfg.abi_version = _lib.CE_ABI_VERSION
     cfg.kind = _lib.KIND[kind]
@@ -41,7 +42,8 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.contract = _lib.CONTRACT[contract]
     cfg.flags = (_lib.FLAG_FIRING * bool(firing) | _lib.FLAG_AUTO_RESET * bool(auto_reset)
                  | _lib.FLAG_COLLECTIVE * bool(collective) | _lib.FLAG_INEQUITY * bool(inequity)
-                 | _lib.FLAG_COLLISION * bool(collision_on) | _lib.FLAG_EXTERNAL_THETA * bool(external_theta))
+                 | _lib.FLAG_COLLISION * bool(collision_on) | _lib.FLAG_EXTERNAL_THETA * bool(external_theta)
+                 | _lib.FLAG_BEAM_TRACE * bool(beam_trace))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
@@ -105,10 +107,11 @@ class BatchedEnv:
         self.cfg.contract, self.cfg.contract_low, self.cfg.contract_high = _lib.CONTRACT[contract], lo, hi
         self.cfg.null_prob = float(null_prob)
 
-    def set_flags(self, auto_reset=None, external_theta=None):
+    def set_flags(self, auto_reset=None, external_theta=None, beam_trace=None):
         """flip the run-time flags of the live handle (see ce_set_flags)"""
         mask = value = 0
-        for flag, v in ((_lib.FLAG_AUTO_RESET, auto_reset), (_lib.FLAG_EXTERNAL_THETA, external_theta)):
+        for flag, v in ((_lib.FLAG_AUTO_RESET, auto_reset), (_lib.FLAG_EXTERNAL_THETA, external_theta),
+                        (_lib.FLAG_BEAM_TRACE, beam_trace)):
             if v is not None:
                 mask |= flag
                 value |= flag * bool(v)
@@ -182,6 +185,7 @@ class BatchedEnv:
             "done_agents": (n,), "info": (n, 2), "features": (n, b.num_features), "int_metrics": (b.num_int_metrics,),
             "f64_metrics": (b.num_f64_metrics,), "final_int_metrics": (b.num_int_metrics,),
             "final_f64_metrics": (b.num_f64_metrics,), "error_flags": (), "debug": (16,),
+            "beam_map": (b.grid_h, b.grid_w),
         }[field]
 
     def download(self, field, env_begin=0, env_count=None, raw=False):

@@ -28,6 +28,7 @@ VIEW = 7
 CELL_RGB = np.array([[0, 0, 0], [180, 180, 180], [0, 255, 0], [99, 156, 194], [113, 75, 24], [113, 75, 24]], np.uint8)
 AGENT_RGB = np.array([[0, 0, 255], [2, 81, 154], [204, 0, 204], [216, 30, 54], [254, 151, 0], [100, 255, 255],
                       [99, 99, 255], [250, 204, 255], [238, 223, 16]], np.uint8)
+BEAM_RGB = {1: (255, 255, 0), 2: (100, 255, 255)}  # CE_BEAM_FIRE b"F" (map_env.py:30), CE_BEAM_CLEAN b"C" (cleanup_new.py:43)
 CELL_CHARS = np.array([b" ", b"@", b"A", b"H", b"R", b"S"], dtype="S1")
 ORIENT_NAMES = ["UP", "RIGHT", "DOWN", "LEFT"]
 
@@ -94,7 +95,7 @@ class GridEnvAdapter(_Base):
             self._engine = BatchedEnv(
                 self.KIND, 1, self.num_agents, horizon=self.horizon, firing=not self.disable_firing,
                 collective=self.use_collective_reward, inequity=self.inequity_averse_reward, alpha=self.alpha,
-                beta=self.beta, device=self._device)
+                beta=self.beta, device=self._device, beam_trace=True)  # render() overlays the step's beams
             c, lo, hi, null_prob = self._contract
             if c is not None:
                 self._engine.set_contract(c, lo, hi, null_prob)
@@ -117,7 +118,7 @@ class GridEnvAdapter(_Base):
             fn(*args)
 
     _STATE_FIELDS = ("grid", "agents", "spawn_perm", "waste_perm", "rng", "timestep", "theta", "int_metrics",
-                     "f64_metrics", "final_int_metrics", "final_f64_metrics")
+                     "f64_metrics", "final_int_metrics", "final_f64_metrics", "beam_map")
 
     def __getstate__(self):
         # the instance is shipped inside RLlib's env_config (ray_config_utils.py:198-202): drop the device
@@ -241,15 +242,30 @@ class GridEnvAdapter(_Base):
         return CELL_CHARS[self._engine.download("grid")[0]]
 
     def full_map_to_colors(self):
-        """map_env.py:389-392 (beams are never on the map when this is called between steps)"""
+        """map_env.py:354-392: the map, the agents in agent order, then the beams the last step fired (`beam_pos`,
+        kept by the engine under CE_FLAG_BEAM_TRACE) — what run_render.py:41 collects frame by frame"""
         grid = self._engine.download("grid")[0]
         rgb = CELL_RGB[grid].astype(int)
         for i, a in enumerate(self._engine.download("agents")[0]):
             rgb[a[0], a[1]] = AGENT_RGB[i]
+        beam = self._engine.download("beam_map")[0]
+        for code, colour in BEAM_RGB.items():
+            rgb[beam == code] = colour
         return rgb
 
     def render(self, filename=None, mode="human"):
-        return self.full_map_to_colors()
+        """map_env.py:460-475: 'human' draws (or saves) with matplotlib and returns None, any other mode returns the array"""
+        rgb_arr = self.full_map_to_colors()
+        if mode == "human":
+            import matplotlib.pyplot as plt
+            plt.cla()
+            plt.imshow(rgb_arr, interpolation="nearest")
+            if filename is None:
+                plt.show(block=False)
+            else:
+                plt.savefig(filename)
+            return None
+        return rgb_arr
 
     def global_view(self):
         """map_env.py:394-395: the colour map without its padding.  reset() leaves the agents unpainted, a step paints

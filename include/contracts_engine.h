@@ -68,6 +68,9 @@ enum ce_contract {
 #define CE_FLAG_EXTERNAL_THETA 0x20u   /* the contract parameter is set by the caller (write the `theta` buffer) instead of
                                          being drawn at reset (resets leave it untouched): the negotiate / combined stages of two_stage_train.py
                                          (:215-358, :373-470) reset the base env only and take theta from an agent's action */
+#define CE_FLAG_BEAM_TRACE 0x40u       /* grid kinds: every step also writes `beam_map`, the cells the step's FIRE / CLEAN beams
+                                         covered (MapEnv.beam_pos, map_env.py:231,813) — what render() / full_map_to_colors()
+                                         overlay on the map (map_env.py:371-373); off by default, rollouts do not need it */
 
 typedef struct ce_config {
   uint32_t abi_version;    /* CE_ABI_VERSION                                               */
@@ -152,7 +155,14 @@ typedef struct ce_buffers {
   int64_t* final_int_metrics; /* same layout, latched at the step that returned done        */
   double* final_f64_metrics;
   uint32_t* error_flags; /* [E] per-env fault bits (CE_FAULT_*), sticky until the env is reset    */
+  uint8_t* beam_map;     /* grid kinds: [E][grid_h][grid_w] CE_BEAM_* of the last step's beams (a later beam of the
+                            shuffled firing order overwrites an earlier one, as the reference's beam_pos list does);
+                            written only under CE_FLAG_BEAM_TRACE, zeroed by a reset                        */
 } ce_buffers;
+
+#define CE_BEAM_NONE 0
+#define CE_BEAM_FIRE 1  /* 'F' */
+#define CE_BEAM_CLEAN 2 /* 'C' */
 
 /* cell codes of `grid` (reference world_map chars) */
 #define CE_CELL_EMPTY 0 /* ' ' */
@@ -221,8 +231,8 @@ int ce_destroy(ce_handle h);
  * (two_stage_train.py:34-44,152-157): switches the fused contract epilogue of an existing
  * handle on/off and sets the contract space + null_prob.  Takes effect at the next reset/step. */
 int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob);
-/* flips run-time flags of a live handle: flags = (flags & ~mask) | (value & mask); only CE_FLAG_AUTO_RESET and
- * CE_FLAG_EXTERNAL_THETA may change after ce_create */
+/* flips run-time flags of a live handle: flags = (flags & ~mask) | (value & mask); only CE_FLAG_AUTO_RESET,
+ * CE_FLAG_EXTERNAL_THETA and CE_FLAG_BEAM_TRACE may change after ce_create */
 int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value);
 
 /* Replaces: np.random.seed(s) (+ random.seed(s)) followed by CONSTRUCTING the env

@@ -676,6 +676,8 @@ static int fire_beam(orc_t* o, env_t* e, int firer, int is_clean, int* upd_idx) 
     for (int i = 0; i < 5; i++) { /* fire_len = all_actions["FIRE"] = 5 for both beams */
       if (in_bounds(o, r, c) && e->grid[r * o->W + c] != CE_CELL_WALL) {
         int idx = r * o->W + c;
+        if (o->cfg.flags & CE_FLAG_BEAM_TRACE) /* firing_points -> beam_pos (map_env.py:788,813): later entries win */
+          o->b.beam_map[(size_t)(e - o->envs) * o->cells + idx] = is_clean ? CE_BEAM_CLEAN : CE_BEAM_FIRE;
         if (is_clean && e->grid[idx] == CE_CELL_WASTE) upd_idx[nupd++] = idx; /* cell_types=[H] -> R */
         pt_t p = {r, c};
         if (pos_occupied(o, e, p)) {
@@ -894,6 +896,7 @@ static void grid_reset(orc_t* o, int ei) {
   /* MapEnv.reset map_env.py:306-342 */
   if (setup_agents(o, e, 20)) o->b.error_flags[ei] |= CE_FAULT_NO_SPAWN;
   memcpy(e->grid, o->base_cell, o->cells); /* reset_map: walls + custom_reset */
+  if (o->cfg.flags & CE_FLAG_BEAM_TRACE) memset(o->b.beam_map + (size_t)ei * o->cells, CE_BEAM_NONE, o->cells); /* beam_pos = [] :316 */
   latch_zero_metrics(o, ei);               /* custom_reset re-creates metrics / total_reward_dict */
   custom_map_update(o, e);
   e->timesteps = 0;
@@ -972,6 +975,7 @@ static void grid_step(orc_t* o, int ei, const uint8_t* act) {
 
   /* ---- MapEnv.step map_env.py:216-304 ---- */
   e->timesteps += 1;
+  if (o->cfg.flags & CE_FLAG_BEAM_TRACE) memset(o->b.beam_map + (size_t)ei * o->cells, CE_BEAM_NONE, o->cells); /* beam_pos = [] :231 */
   update_moves(o, e, act);
   for (int a = 0; a < n; a++) { /* consume map_env.py:244-247 */
     int idx = e->pos[a].row * W + e->pos[a].col;
@@ -1815,6 +1819,7 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     ALLOC(rng, uint32_t, E * CE_RNG_WORDS_GRID);
     ALLOC(obs, uint8_t, E * o->b.obs_env_stride);
     ALLOC(features, int16_t, E * n * o->b.num_features);
+    ALLOC(beam_map, uint8_t, E * o->cells);
   } else {
     o->b.num_features = 2 * n + 7;
     o->b.rng_words = CE_RNG_WORDS_SELFDRIVE;
@@ -1843,7 +1848,7 @@ int orc_destroy(orc_t* o) {
   void* ptrs[] = {o->b.grid, o->b.agents, o->b.spawn_perm, o->b.waste_perm, o->b.rng, o->b.timestep, o->b.theta,
                   o->b.sd_state, o->b.obs, o->b.obs_f64, o->b.base_reward, o->b.reward, o->b.done, o->b.done_agents,
                   o->b.info, o->b.features, o->b.int_metrics, o->b.f64_metrics, o->b.final_int_metrics,
-                  o->b.final_f64_metrics, o->b.error_flags};
+                  o->b.final_f64_metrics, o->b.error_flags, o->b.beam_map};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(ptrs[i]);
   free(o->envs);
   free(o);

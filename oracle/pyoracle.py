@@ -46,7 +46,7 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P),
+        ("error_flags", _P), ("beam_map", _P),
     ]
 
 
@@ -61,7 +61,8 @@ CONTRACT_SPACE = {
 
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
-                env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False):
+                env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
+                beam_trace=False):
     cfg = CeConfig()
     cfg.abi_version = 1
     cfg.kind = KIND[kind]
@@ -70,7 +71,8 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.horizon = horizon
     cfg.contract = CONTRACT[contract]
     cfg.flags = (FLAG_FIRING * bool(firing) | FLAG_AUTO_RESET * bool(auto_reset) | FLAG_COLLECTIVE * bool(collective)
-                 | FLAG_INEQUITY * bool(inequity) | FLAG_COLLISION * bool(collision_on) | FLAG_EXTERNAL_THETA * bool(external_theta))
+                 | FLAG_INEQUITY * bool(inequity) | FLAG_COLLISION * bool(collision_on) | FLAG_EXTERNAL_THETA * bool(external_theta)
+                 | 64 * bool(beam_trace))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
@@ -150,6 +152,7 @@ def buffer_views(b, kind):
         v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
         v["obs"] = obs_view(_view(b.obs, np.uint8, (E, b.obs_env_stride)), n, b.obs_agent_stride, b.obs_row_stride)
         v["features"] = _view(b.features, np.int16, (E, n, b.num_features))
+        v["beam_map"] = _view(b.beam_map, np.uint8, (E, b.grid_h, b.grid_w))
     else:
         v["rng"] = _view(b.rng, np.uint32, (E, b.rng_words))
         v["sd_state"] = _view(b.sd_state, np.float64, (E, 5 * n + 3))

@@ -244,3 +244,51 @@ def replay_feat(g, impl, env=0, sync=lambda: None, get=None):
             if k.startswith("transfer") and int(g["contract"]) == 0:
                 continue
             np.testing.assert_allclose(md[k], v, rtol=1e-12, atol=1e-9, err_msg="metric %s ep%d" % (k, ep))
+
+
+# colours of the reference's render (map_env.py:24-42, cleanup_new.py:42-47): cell codes, agents '1'..'9', beams F / C
+RENDER_CELL_RGB = np.array([[0, 0, 0], [180, 180, 180], [0, 255, 0], [99, 156, 194], [113, 75, 24], [113, 75, 24]], np.uint8)
+RENDER_AGENT_RGB = np.array([[0, 0, 255], [2, 81, 154], [204, 0, 204], [216, 30, 54], [254, 151, 0], [100, 255, 255],
+                             [99, 99, 255], [250, 204, 255], [238, 223, 16]], np.uint8)
+RENDER_BEAM_RGB = {1: (255, 255, 0), 2: (100, 255, 255)}
+
+
+def compose_render(grid, agents, beam):
+    """full_map_to_colors (map_env.py:354-392): map, agents in agent order, beams on top"""
+    rgb = RENDER_CELL_RGB[grid].copy()
+    for i, a in enumerate(agents):
+        rgb[a[0], a[1]] = RENDER_AGENT_RGB[i]
+    for code, colour in RENDER_BEAM_RGB.items():
+        rgb[beam == code] = colour
+    return rgb
+
+
+def replay_render(g, impl, env=0, sync=lambda: None, get=None):
+    """render_* fixtures: firing enabled, beam trace on; every step's beam cells and composed colour map"""
+    if get is None:
+        def get(name):
+            return getattr(impl, name)
+    n, E = int(g["n"]), impl.E
+    impl.seed(np.full((E,), int(g["seed"]), np.uint64))
+    impl.reset()
+    sync()
+    assert not get("beam_map")[env].any(), "beams after reset"
+    assert np.array_equal(compose_render(get("grid")[env], get("agents")[env], get("beam_map")[env]), g["reset_rgb"])
+    for t in range(len(g["actions"])):
+        impl.step(np.broadcast_to(g["actions"][t], (E, n)))
+        sync()
+        beam = get("beam_map")[env]
+        assert np.array_equal(beam, g["beam"][t]), "beam cells step %d" % t
+        img = compose_render(get("grid")[env], get("agents")[env], beam)
+        if t < len(g["rgb"]):
+            assert np.array_equal(img, g["rgb"][t]), "render step %d" % t
+        sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8)
+        assert np.array_equal(sha, g["rgb_sha"][t]), "render sha step %d" % t
+        rng = get("rng")[env]
+        fp = int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16)
+        assert (int(rng[624]), fp) == tuple(int(x) for x in g["mt"][t]), "MT state step %d" % t
+        assert int(get("done")[env]) == int(g["done"][t])
+        if int(g["done"][t]):
+            impl.reset()
+            sync()
+            assert not get("beam_map")[env].any(), "beams after reset"

@@ -312,3 +312,32 @@ def test_negotiation_solver_trace(name):
             assert d["__all__"] == bool(g["done"][t]) and _fps() == list(g["fp"][t]), (ep, s)
             t += 1
     base.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["render_cleanup_n5_firing", "render_harvest_n6_firing"])
+def test_render_trace(name):
+    """what run_render.py:41 collects: env.full_map_to_colors() after every step — map, agents and the step's beams"""
+    import hashlib
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    g = np.load("%s/%s.npz" % (gc.GOLDEN_DIR, name))
+    n, seed = int(g["n"]), int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    env = (CleanupEnv if str(g["kind"]) == "cleanup" else HarvestEnv)(num_agents=n, disable_firing=False, horizon=int(g["horizon"]))
+    env.reset()
+    first = env.full_map_to_colors()
+    assert str(first.dtype) == str(g["rgb_dtype"]) and np.array_equal(first, g["reset_rgb"])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(env.render(mode="rgb_array").astype(np.uint8).tobytes()).digest(), np.uint8),
+                          g["render_rgb_sha"])
+    for t in range(len(g["actions"])):
+        _, _, d, _ = env.step({"a%d" % i: int(g["actions"][t][i]) for i in range(n)})
+        img = env.full_map_to_colors().astype(np.uint8)
+        if t < len(g["rgb"]):
+            assert np.array_equal(img, g["rgb"][t]), t
+        assert np.array_equal(np.frombuffer(hashlib.sha256(img.tobytes()).digest(), np.uint8), g["rgb_sha"][t]), t
+        assert d["__all__"] == bool(g["done"][t])
+        if d["__all__"]:
+            env.reset()
+    env.close()

@@ -303,3 +303,48 @@ def test_external_theta_one_contract_per_env(kind, n, contract):
     assert np.abs(env.download("final_f64_metrics")[:, 0]).max() > 0  # transfers did happen
     env.close()
     orc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gc.fixtures("render_"))
+def test_golden_render(name):
+    """CE_FLAG_BEAM_TRACE: the step's beam cells (MapEnv.beam_pos) and the composed full_map_to_colors frame"""
+    g = gc.load(name)
+    env = _engine(str(g["kind"]), 3, int(g["n"]), horizon=int(g["horizon"]), firing=True, beam_trace=True)
+    gc.replay_render(g, env, env=2)
+    env.check_faults()
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,firing,horizon", [("cleanup", 8, True, 35), ("cleanup", 3, False, 1000), ("harvest", 7, True, 30)])
+def test_beam_trace_random_vs_oracle(kind, n, firing, horizon):
+    """beam-heavy random rollouts with auto-reset (a done step's beams are cleared by the in-launch reset, as reset()
+    clears beam_pos); the trace changes nothing else, and switching it off leaves the map untouched"""
+    from oracle.pyoracle import Oracle
+    E, T = 192, 80
+    kw = dict(firing=firing, horizon=horizon, auto_reset=True)
+    env, orc = _engine(kind, E, n, beam_trace=True, **kw), Oracle(kind, E, n, beam_trace=True, **kw)
+    seeds = np.arange(E, dtype=np.uint64) * 104729 + 5
+    for impl in (env, orc):
+        impl.seed(seeds)
+        impl.reset()
+    fields = FIELDS_GRID + ["beam_map"] + (["waste_perm"] if kind == "cleanup" else [])
+    rs = np.random.RandomState(5)
+    na = env.num_actions
+    p = np.full(na, 0.5 / 7)
+    p[7:] = 0.5 / (na - 7)
+    seen = 0
+    for t in range(T):
+        a = rs.choice(na, size=(E, n), p=p).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        _compare(env, orc, fields, "step %d" % t)
+        seen += int(orc.beam_map.any())
+    assert seen > T // 2
+    last = env.download("beam_map")
+    env.set_flags(beam_trace=False)
+    env.step(a)
+    assert np.array_equal(env.download("beam_map"), last)  # not written (and not cleared) while the trace is off
+    env.check_faults()
+    env.close()

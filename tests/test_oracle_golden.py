@@ -17,3 +17,10 @@ def test_oracle_grid_golden(name):
 def test_oracle_selfdrive_golden(name):
     g = gc.load(name)
     gc.replay_selfdrive(g, Oracle("selfdrive", 2, int(g["n"]), contract="selfdrive_distprop"), env=1)
+
+
+@pytest.mark.parametrize("name", gc.fixtures("render_"))
+def test_oracle_render_golden(name):
+    """beam cells (MapEnv.beam_pos) and the composed full_map_to_colors image, every step"""
+    g = gc.load(name)
+    gc.replay_render(g, Oracle(str(g["kind"]), 2, int(g["n"]), horizon=int(g["horizon"]), firing=True, beam_trace=True), env=1)
