@@ -25,6 +25,9 @@ while time.time() < t_end:
     E = int(rs.choice([65, 128, 300]))
     kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, collective=collective, inequity=inequity,
               alpha=float(rs.rand() * 5), beta=float(rs.rand()))
+    trace = (not feat) and rs.rand() < 0.5
+    if trace:
+        kw["beam_trace"] = True
     env, orc = BatchedEnv(kind, E, n, **kw), Oracle(kind, E, n, **kw)
     seeds = rs.randint(0, 2 ** 31 - 1, size=E).astype(np.uint64)
     for o in (env, orc):
@@ -32,7 +35,7 @@ while time.time() < t_end:
         o.reset()
     na = env.num_actions + (1 if feat else 0)  # the feature envs' code paths accept one more (effect-free) action
     p = rs.dirichlet(np.ones(na) * rs.choice([0.3, 1.0, 5.0]))
-    fields = FIELDS + (["waste_perm"] if kind == "cleanup" else [])
+    fields = FIELDS + (["waste_perm"] if kind == "cleanup" else []) + (["beam_map"] if trace else [])
     if feat:
         fields = [f for f in FIELDS if f not in ("spawn_perm", "obs")]
     T = int(rs.choice([40, 120]))
