@@ -1677,6 +1677,30 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   // ---------------- MapEnv.step ----------------
   t += 1;
   if (p.flags & CE_FLAG_BEAM_TRACE) clear_beam_map(E, p);  // self.beam_pos = [] (map_env.py:231)
+#if defined(CE_PROBE_VALU) || defined(CE_PROBE_SALU) || defined(CE_PROBE_SMEM) || defined(CE_PROBE_LDS)  // issue / latency probes (tools/issue_probe.sh)
+  {
+#ifdef CE_PROBE_SMEM  // 16 serialised scalar-load round trips from the parameter block
+    u32 pm_ = 0;
+    asm volatile(".rept 16\n s_load_dword %0, %1, 0xb4\n s_waitcnt lgkmcnt(0)\n .endr" : "=s"(pm_) : "s"(pp) : "memory");
+    if (pm_ == 0xdeadbeefu) t += 1;
+#endif
+#ifdef CE_PROBE_LDS  // 16 serialised LDS read round trips
+    u32 pl_ = lane * 4;
+    asm volatile(".rept 16\n ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xfc, %0\n .endr" : "+v"(pl_) : : "memory");
+    if (pl_ == 0xdeadbeefu) t += 1;
+#endif
+#ifdef CE_PROBE_VALU
+    u32 pv = lane;
+    asm volatile(".rept 128\n v_mov_b32 %0, %0\n .endr" : "+v"(pv));
+    if (pv == 0xdeadbeefu) t += 1;
+#endif
+#ifdef CE_PROBE_SALU
+    u32 ps = E.n;
+    asm volatile(".rept 128\n s_mov_b32 %0, %0\n .endr" : "+s"(ps));
+    if (ps == 0xdeadbeefu) t += 1;
+#endif
+  }
+#endif
   CE_STAMP(1);
 #ifndef CE_ABLATE_MOVES
   update_moves(E, ACT);
