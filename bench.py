@@ -115,6 +115,29 @@ def cpu_baseline(kind, n, contract, target_s):
                       "1 thread, %.1f s)" % (256 * threads, steps, kind, n, dt, 256, steps1, dt1)}
 
 
+def stream_ceiling():
+    """measured streaming ceilings of this box: device-to-device copy (read + write bytes) and fill (write
+    only) of a 1 GiB buffer through torch's own kernels, GB/s"""
+    import torch
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    out = {}
+    for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("fill", lambda: dst.fill_(3), nbytes)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = moved * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -226,8 +249,10 @@ def main():
                         traffic = int(round(tj["hbm_bytes_per_env_step"] * (E // S)))
                 except Exception:
                     traffic = None
+            ceil = stream_ceiling()
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "measured_copy_GBs": ceil["copy"], "measured_fill_GBs": ceil["fill"],
                     "kernel": "k_grid_step<%s>" % kind, "kernel_ms": kernel_ms, "launches": launches,
                     "algorithmic_bytes_per_launch": algo_bytes_launch, "concurrent_streams": S}
         out = {
