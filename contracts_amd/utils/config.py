@@ -42,21 +42,42 @@ def load_config_file(path, seeds=1):
         return expand_config_list(json.load(f), seeds)
 
 
+def _env_config(job):
+    env_config = {"num_agents": job.get("num_agents"), "env_params": job.get("env_params", {})}
+    env_config.update(job.get("env_args", {}))
+    return env_config
+
+
 def build_env(job, rng="global", device=0):
-    """ray_config_utils.py:28-72,126-214: (top-level env, base env, contract) for one job dict.
-    `separate: true` returns the bare base env (the no-contract baseline); otherwise the base env is
-    wrapped in SeparateContractSubgameStage (the first training stage of every contracting config)."""
+    """ray_config_utils.py:28-72,126-214: (top-level env, base env, contract) for one job dict, the first training
+    stage of the job: `joint` -> JointEnv over the base env, `separate` -> the bare base env (the no-contract baseline),
+    `combined` -> SeparateContractCombinedStage, otherwise SeparateContractSubgameStage."""
     contract_params = dict(job.get("contract_params", {}))
     contract_params["num_agents"] = job.get("num_agents")
     contract = getattr(contract_list, job.get("contract"))(**contract_params) if job.get("contract") else None
-    env_config = {"num_agents": job.get("num_agents"), "env_params": job.get("env_params", {})}
-    env_config.update(job.get("env_args", {}))
+    env_config = _env_config(job)
     base_env = env_creator(get_base_env_tag(job), dict(env_config, rng=rng, device=device))
     convolutional = bool(job.get("env_args") and job["env_args"].get("image_obs"))
-    if job.get("joint") or job.get("combined"):
-        raise NotImplementedError("joint / combined stages are outside the accelerated hot path (SURVEY.md §8f)")
+    if job.get("joint"):
+        return env_creator("JointEnv", dict(env_config, base_env=base_env)), base_env, contract
     if job.get("separate") or contract is None:
         return base_env, base_env, contract
-    top = env_creator("ContractWrapperSubgame", dict(env_config, base_env=base_env, contract=contract,
-                                                     convolutional=convolutional))
+    tag = "ContractWrapperCombined" if job.get("combined") else "ContractWrapperSubgame"
+    top = env_creator(tag, dict(env_config, base_env=base_env, contract=contract, convolutional=convolutional))
     return top, base_env, contract
+
+
+def build_second_stage(job, base_env, contract, checkpoint_paths, trainer_config=None, trainer_factory=None):
+    """ray_config_utils.py:217-278 (get_neg_config / get_solver_config): the contract-negotiation stage of a job over
+    an already built base env — `solver: true` -> NegotiationSolver with the class defaults (50 sampled contracts,
+    'majority' rule; the job's `solver_samples` is run_solver.py's number of evaluation episodes, not a constructor
+    argument), otherwise SeparateContractNegotiateStage.  `trainer_config` is the
+    frozen first-stage trainer config the reference copies into env_config; `trainer_factory` builds the frozen
+    policies when RLlib's PPOTrainer is not what should be used."""
+    convolutional = bool(job.get("env_args") and job["env_args"].get("image_obs"))
+    env_config = dict(_env_config(job), base_env=base_env, contract=contract, convolutional=convolutional,
+                      horizon=job.get("horizon"), trainer_config=trainer_config, trainer_env="ContractWrapperSubgame",
+                      trainer_path=checkpoint_paths[0], shared=job.get("shared_policy"), trainer_factory=trainer_factory)
+    if job.get("solver"):
+        return env_creator("NegotiationSolver", env_config)
+    return env_creator("ContractWrapperNegotiate", env_config)

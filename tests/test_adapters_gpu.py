@@ -153,6 +153,26 @@ def test_reference_config_file_drives_the_engine():
            {"environment": "selfdrive", "contract": "SelfdriveContractDistprop", "env_args": {}}]
     jobs = expand_config_list(cfg)
     assert len(jobs) == 3
+    # the other first-stage wirings of ray_config_utils.py:156-208 and the second stage of `solver: true` (test.json)
+    import sys
+    sys.path.insert(0, gc.GOLDEN_DIR)
+    from ref_harness import StubPPOTrainer
+    from contracts_amd.environments import two_stage_train as tst
+    from contracts_amd.utils.config import build_second_stage
+    top, base, contract = build_env(dict(jobs[0], joint=True, env_args={"image_obs": True, "concatenated_obs": True}))
+    assert isinstance(top, tst.JointEnv) and top.reset()["a0"]["image"].shape == (15, 15, 6)
+    base.close()
+    top, base, contract = build_env(dict(jobs[0], combined=True))
+    assert isinstance(top, tst.SeparateContractCombinedStage) and set(top.reset()) == {"a0", "a1"}
+    base.close()
+    top, base, contract = build_env(jobs[0])
+    solver = build_second_stage(dict(jobs[0], solver_samples=5), base, contract, ["ckpt"], {"n_act": 8, "seed": 3}, StubPPOTrainer)
+    assert isinstance(solver, tst.NegotiationSolver) and solver.num_samples == 50 and solver.decision_rule == "majority"
+    o = solver.reset()
+    assert 0.0 <= float(solver.contract_param[0]) <= float(contract.contract_space.high[0]) and o["a1"]["contract"][0] == solver.contract_param[0]
+    neg = build_second_stage(dict(jobs[0], solver=False), base, contract, ["ckpt"], {"n_act": 8, "seed": 3}, StubPPOTrainer)
+    assert isinstance(neg, tst.SeparateContractNegotiateStage) and neg.reset()["a0"]["contract"][-1] == 2
+    base.close()
     for job in jobs:
         np.random.seed(job["seed"])
         random.seed(job["seed"])
