@@ -361,3 +361,54 @@ def test_render_trace(name):
         if d["__all__"]:
             env.reset()
     env.close()
+
+
+@pytest.mark.gpu
+def test_batched_contract_evaluation_matches_sequential_episodes():
+    """run_solver's loop (one NegotiationSolver-style episode per sampled contract, run_solver.py:18-73) against the
+    batched sweep: K contracts as K replicas of one handle — identical episode rewards, double for double"""
+    from contracts_amd.contract import contract_list
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractEnv
+    from contracts_amd.run_solver import evaluate_contracts
+    n, horizon, K = 4, 60, 6
+    thetas = np.array([0.0, 0.03, 0.08, 0.12, 0.17, float(np.float32(0.2))])
+    seeds = np.arange(K, dtype=np.uint64) * 7907 + 99
+
+    def act(k, t, a):
+        return int((k * 131 + t * 31 + a * 7 + (t * t) % 5) % 8)
+
+    class FixedContract(SeparateContractEnv):  # the episode part of NegotiationSolver with a given parameter
+        def __init__(self, base, contract, n, theta):
+            super().__init__(base, contract, n, True)
+            self._external_theta(True)
+            self._theta_value = np.array([theta])
+
+        def reset(self):
+            obs = self.base_env.reset()
+            self._set_theta(self._theta_value)
+            self.params = {"a%d" % i: self._theta_value for i in range(self.num_agents)}
+            return self._with_contract(obs, list(self.params))
+
+    want = []
+    for k in range(K):
+        np.random.seed(int(seeds[k]))
+        random.seed(int(seeds[k]))
+        base = CleanupEnv(num_agents=n, horizon=horizon)
+        env = FixedContract(base, contract_list.CleanupContract(n), n, thetas[k])
+        obs = env.reset()
+        ep, d, t = 0, {"__all__": False}, 0
+        while not d["__all__"] and t < horizon:
+            obs, r, d, info = env.step({"a%d" % a: act(k, t, a) for a in range(n)})
+            for key in obs:
+                ep += r[key]
+            t += 1
+        want.append(ep)
+        base.close()
+    got = evaluate_contracts("cleanup", n, "CleanupContract", thetas, seeds,
+                             lambda obs, th, t: np.array([[act(k, t, a) for a in range(n)] for k in range(K)]), horizon=horizon)
+    assert got["steps"] == horizon
+    assert np.array_equal(got["ep_rewards"], np.array(want, np.float64)), (got["ep_rewards"], want)
+    assert got["mean reward"] == float(np.mean(want)) and got["std contract"] == float(np.std(thetas))
+    ar = got["agent_rewards"]  # transfers are zero-sum over the agents: the parameter shows per agent, not in the total
+    assert np.array_equal(ar[0], np.rint(ar[0])) and np.abs(ar[1:] - np.rint(ar[1:])).max() > 1e-3
