@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Named known-answer scenarios: hand-placed agents, one reference step each.
-Build-container only.  Output: tests/golden/ka_cleanup.npz (same record layout as the fuzz fixtures,
-plus `names`)."""
+Build-container only.  Output: tests/golden/ka_cleanup.npz and ka_harvest.npz (same record layout as the fuzz
+fixtures, plus `names`)."""
 import hashlib
 import os
 import sys
@@ -79,8 +79,83 @@ def scenarios(env):
     return S
 
 
+def harvest_scenarios(env):
+    """KA14 (eaten_close_apples around the <4 threshold), harvest FIRE (action 7), apple under a staying agent"""
+    H, W = env.base_map.shape
+    apple_cells = [(r, c) for r in range(H) for c in range(W) if env.base_map[r, c] == b"A"]
+    far = [(14, 1, UP), (14, 3, UP), (14, 5, UP), (14, 9, UP)]
+    S = []
+
+    def grid_with(apples):
+        g = np.zeros((H, W), np.uint8)
+        g[env.base_map == b"@"] = 1
+        for (r, c) in apples:
+            g[r, c] = 2
+        return g
+
+    def add(name, agents, acts, apples, seeds=(1,)):
+        ag = list(agents) + far[len(agents):]
+        ac = list(acts) + [STAY] * (4 - len(acts))
+        for sd in seeds:
+            S.append((name + ("/s%d" % sd if len(seeds) > 1 else ""), np.array(ag), np.array(ac), grid_with(apples), sd))
+
+    # a target apple cell with a free cell on its left and at least 5 apple cells within distance^2 <= 5
+    def near(t):
+        return [q for q in apple_cells if q != t and (q[0] - t[0]) ** 2 + (q[1] - t[1]) ** 2 <= 5]
+    t = next(q for q in apple_cells if q[0] < 12 and env.base_map[q[0], q[1] - 1] == b" " and len(near(q)) >= 5)
+    for k in (0, 2, 3, 4, 5):
+        add("KA14 eat an apple with %d other apples within d^2<=5" % k, [(t[0], t[1] - 1, UP)], [R], [t] + near(t)[:k])
+    add("KA14b eat an apple with 1 other apple within d^2<=5", [(t[0], t[1] - 1, UP)], [R], [t] + near(t)[:1])
+    add("KA10h harvest FIRE (action 7): -1 firer, -50 first agent hit, passes over apples",
+        [(t[0], t[1] - 1, RIGHT), (t[0], t[1] + 3, UP), (t[0], t[1] + 4, UP)], [7, STAY, STAY], [t] + near(t)[:3])
+    add("KA10i harvest FIRE side ray", [(t[0], t[1] - 1, RIGHT), (t[0] + 1, t[1] + 1, UP)], [7, STAY], [t])
+    add("KA11c no respawn under a staying agent, dense neighbourhood", [(t[0], t[1], UP)], [STAY], near(t), seeds=tuple(range(1, 25)))
+    add("KA11d respawn of the same cell without the agent", [], [], near(t), seeds=tuple(range(1, 25)))
+    return S
+
+
+def record_harvest(Rf):
+    np.random.seed(3)
+    env = Rf.HarvestEnv(num_agents=4, disable_firing=False)
+    env.reset()
+    keys = ["a%d" % i for i in range(4)]
+    rec = {k: [] for k in ("in_grid", "in_agents", "seed", "actions", "out_grid", "out_agents", "base_rew",
+                           "eaten", "second", "feature_obs", "obs_sha", "mt_pos", "obs", "names")}
+    for name, agents, acts, grid, seed in harvest_scenarios(env):
+        inject(env, "harvest", grid, agents)
+        rec["names"].append(name)
+        rec["in_grid"].append(grid)
+        rec["in_agents"].append(agents.astype(np.uint8))
+        rec["seed"].append(seed)
+        rec["actions"].append(acts.astype(np.uint8))
+        env.timesteps = 5
+        np.random.seed(seed)
+        o, r, d, info = env.step({k: int(acts[i]) for i, k in enumerate(keys)})
+        rec["out_grid"].append(grid_codes(env))
+        rec["out_agents"].append(np.array([[a.pos[0], a.pos[1], ORIENT2INT[a.orientation]] for a in env.agents.values()], np.uint8))
+        rec["base_rew"].append(np.array([r[k] for k in keys], np.int32))
+        rec["eaten"].append(np.array([info[k]["eaten_apples"] for k in keys], np.uint8))
+        rec["second"].append(np.array([info[k]["eaten_close_apples"] for k in keys], np.uint8))
+        rec["feature_obs"].append(np.stack([info[k]["feature_obs"] for k in keys]))
+        ob = np.stack([obs_u8(o[k]["image"]) for k in keys])
+        rec["obs_sha"].append(np.frombuffer(hashlib.sha256(ob.tobytes()).digest(), np.uint8))
+        if len(rec["obs"]) < 10:
+            rec["obs"].append(ob)
+        rec["mt_pos"].append(np.random.get_state()[2])
+        if "/s" not in name or name.endswith("/s1"):
+            print("%-75s rew %s close %s" % (name[:75], rec["base_rew"][-1].tolist(), rec["second"][-1].tolist()))
+    out = {"kind": "harvest", "n": 4, "firing": 1}
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "ka_harvest.npz"), **out)
+    g = out
+    t_in, t_out = g["in_grid"], g["out_grid"]
+    print("spawns per scenario (KA11c / KA11d):", [(int(((t_out[i] == 2) & (t_in[i] != 2)).sum())) for i, nm in enumerate(g["names"]) if nm.startswith("KA11")])
+
+
 def main():
     Rf = load_reference()
+    record_harvest(Rf)
     np.random.seed(3)
     env = Rf.CleanupEnv(num_agents=4, disable_firing=False)
     env.reset()

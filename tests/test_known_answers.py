@@ -1,4 +1,4 @@
-"""Named known-answer scenarios (SURVEY.md §8c KA1-KA13) — one reference step from hand-placed agents,
+"""Named known-answer scenarios (SURVEY.md §8c KA1-KA14) — one reference step from hand-placed agents,
 recorded from the reference (tests/golden/make_ka.py).  The fixture doubles as documentation of the
 reference's conflict-resolution semantics; a few of its facts are asserted literally below."""
 import numpy as np
@@ -44,10 +44,24 @@ def test_fixture_documents_reference_semantics():
     assert g["second"][i].tolist() == [1, 0, 0, 0]                     # one H cleaned, then the beam stops
 
 
-def test_oracle_known_answers():
+def test_harvest_fixture_documents_reference_semantics():
+    g = gc.load("ka_harvest")
+    names = [str(x) for x in g["names"]]
+    close = {int(n.split(" with ")[1].split()[0]): int(g["second"][i][0]) for i, n in enumerate(names) if n.startswith("KA14")}
+    assert close == {0: 1, 1: 1, 2: 1, 3: 0, 4: 0, 5: 0}                # eaten_close: fewer than 4 apples (itself included) within d^2 <= 5
+    (i,) = _idx(names, "KA10h")
+    assert g["base_rew"][i].tolist() == [-1, -50, 0, 0]                # FIRE passes over apples, the first agent absorbs it
+    under = [i for i in _idx(names, "KA11c")]
+    t = tuple(g["in_agents"][under[0]][0][:2])
+    assert all(g["out_grid"][i][t] != 2 for i in under)                # never respawns under an agent
+
+
+@pytest.mark.parametrize("kind", ["cleanup", "harvest"])
+def test_oracle_known_answers(kind):
     from oracle.pyoracle import Oracle
-    g, names = _ka()
-    orc = Oracle("cleanup", len(names), 4, firing=True)
+    g = gc.load("ka_" + kind)
+    names = [str(x) for x in g["names"]]
+    orc = Oracle(kind, len(names), 4, firing=True)
 
     def put(field, arr):
         getattr(orc, field)[...] = arr
@@ -57,9 +71,11 @@ def test_oracle_known_answers():
 
 
 @pytest.mark.gpu
-def test_engine_known_answers():
+@pytest.mark.parametrize("kind", ["cleanup", "harvest"])
+def test_engine_known_answers(kind):
     from contracts_amd.engine import BatchedEnv
-    g, names = _ka()
-    env = BatchedEnv("cleanup", len(names), 4, firing=True)
+    g = gc.load("ka_" + kind)
+    names = [str(x) for x in g["names"]]
+    env = BatchedEnv(kind, len(names), 4, firing=True)
     run_fuzz(g, env, env.download, env.upload)
     env.close()
