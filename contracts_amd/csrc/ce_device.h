@@ -40,7 +40,7 @@ template <> struct Geo<CE_KIND_CLEANUP> {
 template <> struct Geo<CE_KIND_HARVEST> {
   static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
   static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
-  static constexpr int UWORDS = 2 * 155, SBYTES = 16;
+  static constexpr int UWORDS = 192, SBYTES = 16;  // the feature pass's key list (48 four-cell chunks >= 155 apple cells); keeps the wave's LDS slice under 5 KB = 8 waves/SIMD
   static constexpr int IMAGE_STRIDE = (PCELLS + 15) / 16 * 16;  // bytes of the padded image ce_download("grid") returns
 };
 

@@ -1462,7 +1462,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   // single v_sad_u8 against the agent's packed (row, col).  The present apples / wastes are first written as a
   // key list (absent cell = kNoKey, whose key stays above every real one) into the now idle random-word scratch; then the wave
   // splits into n groups of 2^sh lanes, group a scanning the whole list for agent a, 4 cells per LDS read.
-  constexpr u32 NCHUNK = KIND == CE_KIND_CLEANUP ? 32u : 64u;  // 4-cell chunks per list
+  constexpr u32 NCHUNK = KIND == CE_KIND_CLEANUP ? 32u : 48u;  // 4-cell chunks per list (a multiple of the largest group, 16 lanes)
   constexpr u32 kNoKey = 0x7f000000u;  // list entry of an absent cell: its key (sad << 16) + entry stays above every real key, no wrap
   constexpr u32 NENT = NCHUNK * 4u;
   static_assert(NENT >= (u32)G::NAPPLE && (KIND != CE_KIND_CLEANUP || NENT >= (u32)G::NWASTE), "key list too short");
@@ -1558,6 +1558,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 // ----------------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------------
+#ifndef CE_HARVEST_WAVES
+#define CE_HARVEST_WAVES 8
+#endif
 #ifndef CE_CLEANUP_WAVES
 #define CE_CLEANUP_WAVES 7
 #endif
@@ -1650,7 +1653,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : 7) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
                  u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
