@@ -2003,7 +2003,7 @@ template <int GK> struct alignas(16) FeatLds {
   union {           // the np.random stream is only needed for a moment at a reset (orientations, theta): it borrows
     u32 mt_np[kMtN];  // the space of the per-step working set
     struct {
-      u32 U[320];                     // tempered words of the respawn doubles of one spawn pass
+      u32 U[256];                     // tempered words of up to 128 respawn doubles (one bulk pass; harvest may take two)
       uint8_t pmap[Geo<GK>::PCELLS];  // padded map: walls + apples / wastes currently present
     } w;
   };
@@ -2244,9 +2244,11 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
     thr_uniform = te & ~kWasteOnBit;
   }
   // every eligible cell consumes exactly one random.random(): temper the 2 * nelig words in stream order
-  rng_bulk(E.py, E.L->w.U, nullptr, 2 * nelig, 2 * nelig, false, lane);
+  constexpr u32 kBulkDoubles = sizeof(E.L->w.U) / 8;  // doubles per bulk pass (the scratch is kept small: 8 waves/SIMD)
   bool spawn[AR];
   if (GK == CE_KIND_CLEANUP) {
+    static_assert(GK != CE_KIND_CLEANUP || (u32)G::NAPPLE <= kBulkDoubles, "one bulk pass covers every apple cell");
+    rng_bulk(E.py, E.L->w.U, nullptr, 2 * nelig, 2 * nelig, false, lane);
 #pragma unroll
     for (int r = 0; r < AR; ++r) spawn[r] = elig[r] && dbl_below(E.L->w.U[2 * (elig[r] ? ri[r] : 0)], E.L->w.U[2 * (elig[r] ? ri[r] : 0) + 1], thr_uniform);
   } else {
@@ -2256,9 +2258,21 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
     u32 a_w[AR], b_w[AR];
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-      a_w[r] = E.L->w.U[2 * (elig[r] ? ri[r] : 0)];
-      b_w[r] = E.L->w.U[2 * (elig[r] ? ri[r] : 0) + 1];
+      a_w[r] = b_w[r] = 0;
       spawn[r] = false;
+    }
+    for (u32 base = 0; base < nelig; base += kBulkDoubles) {  // the stream is sequential: passes of <= 128 doubles
+      const u32 cnt = nelig - base < kBulkDoubles ? nelig - base : kBulkDoubles;
+      rng_bulk(E.py, E.L->w.U, nullptr, 2 * cnt, 2 * cnt, false, lane);
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        const u32 q = ri[r] - base;
+        if (elig[r] && q < cnt) {
+          a_w[r] = E.L->w.U[2 * q];
+          b_w[r] = E.L->w.U[2 * q + 1];
+        }
+      }
+      wave_sync();  // the next pass overwrites the scratch
     }
     for (;;) {
       bool changed = false;
