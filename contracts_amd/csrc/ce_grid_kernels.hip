@@ -786,55 +786,61 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane;
+  // Every load and LDS store below is unconditional: a lane past the end of a list repeats the last element (clamped
+  // index, same value to the same address).  A divergent `if` around a single load costs a compare, an exec save /
+  // restore pair and a branch — scalar-unit work, which is what this kernel has least of.
   const uint4* rsrc = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
-  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64];
-  uint4 r2 = make_uint4(0, 0, 0, 0);
-  if (lane + 128 < kMtN / 4) r2 = rsrc[lane + 128];
+  constexpr u32 kLastQuad = (u32)kMtN / 4 - 1;
+  const u32 q2 = min(lane + 128u, kLastQuad);
+  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
   const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
   // map: the constant base image (L2-resident, shared by every env) + this env's 8 presence dwords (one scalar load)
   const u32* gsrc = (const u32*)T.base_pmap;
   constexpr int GROUNDS = (G::PCELLS / 4 + 63) / 64;
+  constexpr u32 kLastMapWord = (u32)G::PCELLS / 4 - 1;
   u32 gw[GROUNDS];
 #pragma unroll
-  for (int r = 0; r < GROUNDS; ++r) gw[r] = lane + 64 * r < (u32)G::PCELLS / 4 ? gsrc[lane + 64 * r] : 0u;
+  for (int r = 0; r < GROUNDS; ++r) gw[r] = gsrc[min(lane + 64u * r, kLastMapWord)];
   u32 gbits[8];
   {
     const auto bsrc = (CE_GPTR(const u32))(p.grid + (size_t)E.e * kGridStateBytes);
 #pragma unroll
     for (int k = 0; k < 8; ++k) gbits[k] = bsrc[k];
   }
-  u32 aw = 0;
-  if (E.is_agent) aw = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, lane);
-  E.SP = lane < 20 ? GAT(p.spawn_perm + (size_t)E.e * 20, lane) : 0;
+  const u32 aw = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, min(lane, E.n - 1u));
+  const u32 sp = GAT(p.spawn_perm + (size_t)E.e * 20, min(lane, 19u));
+  E.SP = lane < 20 ? sp : 0;
   E.WP0 = E.WP1 = 0;
   if (KIND == CE_KIND_CLEANUP) {
     const auto wp = p.waste_perm + (size_t)E.e * 119;
     E.WP0 = GAT(wp, lane);
-    E.WP1 = lane + 64 < 119 ? GAT(wp, lane + 64) : 0;
+    const u32 w1 = GAT(wp, min(lane + 64u, 118u));
+    E.WP1 = lane + 64 < 119 ? w1 : 0;
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const u32 idx = lane + 64 * r;
-    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+    const u32 v = T.apple[min(idx, (u32)G::NAPPLE - 1u)];
+    E.AP[r] = idx < (u32)G::NAPPLE ? v : 0;
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const u32 idx = lane + 64 * r;
-    E.WS[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+    const u32 v = T.waste[G::NWASTE ? min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0)) : 0u];
+    E.WS[r] = idx < (u32)G::NWASTE ? v : 0;
   }
   const u32 rgbv = c_rgb[lane & 15];
   // ---- LDS image ----
   u32* pm32 = (u32*)E.L->pmap;
 #pragma unroll
-  for (int r = 0; r < GROUNDS; ++r)
-    if (lane + 64 * r < (u32)G::PCELLS / 4) pm32[lane + 64 * r] = gw[r];
+  for (int r = 0; r < GROUNDS; ++r) pm32[min(lane + 64u * r, kLastMapWord)] = gw[r];
   wave_sync();
   paint_presence(E, gbits);
-  if (lane < 16) E.L->rgb[lane] = rgbv;
+  E.L->rgb[lane & 15] = rgbv;
   uint4* mt4 = (uint4*)E.L->mt;
   mt4[lane] = r0;
   mt4[lane + 64] = r1;
-  if (lane + 128 < kMtN / 4) mt4[lane + 128] = r2;
+  mt4[q2] = r2;
   E.rng.mt = E.L->mt;
   E.rng.pos = rfl(rpos);
   E.rng.cbase = 0;
