@@ -600,6 +600,11 @@ template <int KIND> struct alignas(16) WaveLds {
 // cell" query of the beam / spawn code into the LDS read that is needed anyway.
 constexpr uint8_t kAgentBit = 0x80;
 constexpr u32 kCodeMask = 0x7fu;
+// Predicated store into the padded map without touching exec: lanes that are off aim at byte 0 — the corner of the
+// view border, CE_CELL_EMPTY in both maps and never anything else — and write 0 there.  Two v_cndmask instead of a
+// compare + exec save / restore + branch; the scalar unit is the busier one in these kernels.
+DEVINL u32 pm_sel(bool on, u32 idx) { return on ? idx : 0u; }
+DEVINL void pm_put(uint8_t* pm, bool on, u32 idx, u32 val) { pm[on ? idx : 0u] = (uint8_t)(on ? val : 0u); }
 constexpr u32 kCellPadMask = 0x7ffu;
 DEVINL u32 cell_pad(u32 packed) { return packed & kCellPadMask; }
 DEVINL u32 cell_rc(u32 packed) { return packed >> 16; }  // col | row << 8: one byte per coordinate
@@ -641,7 +646,7 @@ template <int KIND> DEVINL u32 col_of(u32 pad) { return pad - __umul24(div_pw<KI
 // is some agent standing on padded cell `cell` (per-lane query); returns highest agent id + 1 or 0
 template <int KIND> DEVINL void mark_agents(Env<KIND>& E) {
   wave_sync();
-  if (E.is_agent) E.L->pmap[E.P] = (uint8_t)(E.L->pmap[E.P] | kAgentBit);
+  pm_put(E.L->pmap, E.is_agent, E.P, E.L->pmap[pm_sel(E.is_agent, E.P)] | kAgentBit);
   wave_sync();
 }
 template <int KIND> DEVINL u32 agent_on(const Env<KIND>& E, u32 cell) {
@@ -714,13 +719,13 @@ template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const u64 m = (u64)bits[2 * r] | (u64)bits[2 * r + 1] << 32;
-    if (E.lane + 64 * r < (u32)G::NAPPLE) pm[cell_pad(E.AP[r])] = lane_bit(m, E.lane) ? CE_CELL_APPLE : CE_CELL_EMPTY;
+    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), lane_bit(m, E.lane) ? CE_CELL_APPLE : CE_CELL_EMPTY);
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const u64 m = (u64)bits[4 + 2 * r] | (u64)bits[5 + 2 * r] << 32;
-      if (E.lane + 64 * r < (u32)G::NWASTE) pm[cell_pad(E.WS[r])] = lane_bit(m, E.lane) ? CE_CELL_WASTE : CE_CELL_RIVER;
+      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), lane_bit(m, E.lane) ? CE_CELL_WASTE : CE_CELL_RIVER);
     }
   }
 }
@@ -1033,7 +1038,7 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, const GridParams& p, u32 
     const bool upd = processed && code == CE_CELL_WASTE;
     cleaned = popc64(ballot(upd));
     wave_sync();
-    if (upd) E.L->pmap[cell] = (uint8_t)(CE_CELL_RIVER | (raw & kAgentBit));
+    pm_put(E.L->pmap, upd, cell, CE_CELL_RIVER | (raw & kAgentBit));
     wave_sync();
   } else {
     const u64 hm0 = ballot(processed && agent_here);
@@ -1244,8 +1249,11 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   wave_sync();
 #pragma unroll
   for (int r = 0; r < AR; ++r)
-    if (spawnA[r]) pm[cell_pad(E.AP[r])] = CE_CELL_APPLE;
-  if (waste_found && lane == 0) pm[waste_cell] = (uint8_t)(CE_CELL_WASTE | (pm[waste_cell] & kAgentBit));
+    pm_put(pm, spawnA[r], cell_pad(E.AP[r]), CE_CELL_APPLE);
+  {
+    const bool wput = waste_found && lane == 0;
+    pm_put(pm, wput, waste_cell, CE_CELL_WASTE | (pm[pm_sel(wput, waste_cell)] & kAgentBit));
+  }
   wave_sync();
 }
 
@@ -1261,7 +1269,7 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     // agents painted in agent order, the later agent wins on a shared cell (map_env.py:257-261)
     for (u32 a = 0; a < E.n; ++a) {
       const u32 pa = rdl(E.P, a);
-      if (lane == 0) pm[pa] = (uint8_t)(6 + a);
+      pm_put(pm, lane == 0, pa, 6 + a);
       wave_sync();
     }
   } else {
@@ -1778,7 +1786,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     }
     if (onA && first) E.RW += 1;
     wave_sync();
-    if (onA) pm[E.P] = CE_CELL_EMPTY;
+    pm_put(pm, onA, E.P, CE_CELL_EMPTY);
     mark_agents(E);
   }
   {  // update_custom_moves: always shuffles the n ids, then fires in that order
