@@ -603,6 +603,9 @@ constexpr u32 kCodeMask = 0x7fu;
 // Predicated store into the padded map without touching exec: lanes that are off aim at byte 0 — the corner of the
 // view border, CE_CELL_EMPTY in both maps and never anything else — and write 0 there.  Two v_cndmask instead of a
 // compare + exec save / restore + branch; the scalar unit is the busier one in these kernels.
+// `a && load(...)` compiles to an exec save / branch / restore around the load; where the address is valid for every
+// lane (list entries past the end point at byte 0) both sides are simply evaluated
+DEVINL bool both(bool a, bool b) { return (bool)((u32)a & (u32)b); }
 DEVINL u32 pm_sel(bool on, u32 idx) { return on ? idx : 0u; }
 DEVINL void pm_put(uint8_t* pm, bool on, u32 idx, u32 val) { pm[on ? idx : 0u] = (uint8_t)(on ? val : 0u); }
 constexpr u32 kCellPadMask = 0x7ffu;
@@ -737,14 +740,14 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p, bo
   u32 w = 0;  // lane k < 8 assembles state dword k
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
-    const u64 m = ballot(E.lane + 64 * r < (u32)G::NAPPLE && (pm[cell_pad(E.AP[r])] & kCodeMask) == CE_CELL_APPLE);
+    const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == CE_CELL_APPLE));
     if (E.lane == 2 * r) w = (u32)m;
     if (E.lane == 2 * r + 1) w = (u32)(m >> 32);
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const u64 m = ballot(E.lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE);
+      const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE));
       if (E.lane == 4 + 2 * r) w = (u32)m;
       if (E.lane == 5 + 2 * r) w = (u32)(m >> 32);
     }
@@ -1081,8 +1084,16 @@ template <int RANDW> DEVINL StreamWindow window_open(Rng& r, u32 lane) {
   w.alen = left < (u32)RANDW ? left : (u32)RANDW;
   return w;
 }
-DEVINL u32 window_read_old(const StreamWindow& w, bool need, u32 s) { return (need && s < w.alen) ? w.mt[w.pos + s] : 0u; }
-DEVINL u32 window_read_new(const StreamWindow& w, bool need, u32 s, u32 old) { return (need && s >= w.alen) ? w.mt[s - w.alen] : old; }
+DEVINL u32 window_read_old(const StreamWindow& w, bool need, u32 s) {
+  const bool ok = both(need, s < w.alen);  // branch-free: lanes without a word read mt[0]
+  const u32 v = w.mt[ok ? w.pos + s : 0u];
+  return ok ? v : 0u;
+}
+DEVINL u32 window_read_new(const StreamWindow& w, bool need, u32 s, u32 old) {
+  const bool ok = both(need, s >= w.alen);
+  const u32 v = w.mt[ok ? s - w.alen : 0u];
+  return ok ? v : old;
+}
 template <int RANDW> DEVINL void window_close(Rng& r, const StreamWindow& w) {
   r.pos = w.alen < (u32)RANDW ? (u32)RANDW - w.alen : w.pos + (u32)RANDW;
   r.ccount = 0;
@@ -1114,7 +1125,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
-      nH += popc64(ballot(v && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE));
+      nH += popc64(ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE)));
     }
     waste_on = (T.apple_thresh[nH] & kWasteOnBit) != 0;
   }
@@ -1122,7 +1133,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   for (int r = 0; r < AR; ++r) {
     const bool v = lane + 64 * r < (u32)G::NAPPLE;
     const u32 cell = cell_pad(E.AP[r]);
-    elig[r] = v && pm[cell] == CE_CELL_EMPTY;
+    elig[r] = both(v, pm[cell] == CE_CELL_EMPTY);
     if (KIND == CE_KIND_CLEANUP) {
       thrA[r] = T.apple_thresh[nH] & ~kWasteOnBit;
     } else {
@@ -1233,7 +1244,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
             const bool v = lane + 64 * r < (u32)G::NWASTE;
             const u32 widx = r == 0 ? E.WP0 : E.WP1;
             const u32 cell = cell_pad(T.waste[v ? widx : 0]);
-            const bool cand = v && (pm[cell] & kCodeMask) != CE_CELL_WASTE;
+            const bool cand = both(v, (pm[cell] & kCodeMask) != CE_CELL_WASTE);
             const u64 cb = ballot(cand);
             const u64 sel = ballot(cand && seen + popc64(cb & lt) == tstar);
             if (sel) {
@@ -1489,7 +1500,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     bool f = false;
     u32 rc = 0;
     if (r < 3) {
-      f = lane + 64 * r < (u32)G::NAPPLE && pm[cell_pad(E.AP[r < 3 ? r : 0])] == CE_CELL_APPLE;
+      f = both(lane + 64 * r < (u32)G::NAPPLE, pm[cell_pad(E.AP[r < 3 ? r : 0])] == CE_CELL_APPLE);
       rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
     napples += popc64(ballot(f));
@@ -1498,7 +1509,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (u32 r = 0; r < 2; ++r) {
-      const bool f = lane + 64 * r < (u32)G::NWASTE && (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE;
+      const bool f = both(lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE);
       nwaste += popc64(ballot(f));
       keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
     }
@@ -1536,7 +1547,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (KIND == CE_KIND_HARVEST) {
     for (u32 a = 0; a < n; ++a) {
       const u32 pa = rdl(E.P, a);
-      const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+      const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
       const u32 cnt = popc64(ballot(v));
       if (lane == a) close_now = cnt;
     }
@@ -1763,13 +1774,13 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 
   // eaten_apples: final position held an apple when the step was entered (nothing has touched
   // the map yet, so the pre-consume map IS the reference's current_apple_points)
-  const bool onA = E.is_agent && pm[E.is_agent ? E.P : 0] == CE_CELL_APPLE;
+  const bool onA = both(E.is_agent, pm[E.is_agent ? E.P : 0] == CE_CELL_APPLE);
   u32 eaten = onA ? 1u : 0u, eaten_close = 0, cleaned = 0;
   if (KIND == CE_KIND_HARVEST) {
     for (u64 om = ballot(onA); om; om &= om - 1) {  // count_apples_in_radius(5, pos) < 4
       const u32 a = ctz64(om);
       const u32 pa = rdl(E.P, a);
-      const bool v = lane < 21 && pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE;
+      const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
       const u32 cnt = popc64(ballot(v));
       if (lane == a && cnt < 4) eaten_close = 1;
     }
