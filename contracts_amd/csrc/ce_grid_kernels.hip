@@ -2071,7 +2071,13 @@ DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
 template <int GK> DEVINL void feat_base_map(FEnv<GK>& E) {
   const u32* bsrc = (const u32*)c_tab[GK].base_pmap;
   u32* pm32 = (u32*)E.L->w.pmap;
-  for (u32 k = E.lane; k < (u32)Geo<GK>::PCELLS / 4; k += 64) pm32[k] = bsrc[k];
+  constexpr int ROUNDS = (Geo<GK>::PCELLS / 4 + 63) / 64;
+  constexpr u32 kLast = (u32)Geo<GK>::PCELLS / 4 - 1;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {  // unconditional: idle lanes of the last round repeat the last word
+    const u32 k = min(E.lane + 64u * r, kLast);
+    pm32[k] = bsrc[k];
+  }
 }
 // The np.random draws of a reset — n orientations (one masked word each), then the wrapper's theta — taken in one go
 // on the stream loaded into the borrowed LDS block and written straight back: the two generators are independent,
@@ -2112,20 +2118,27 @@ template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool w
   {  // 624 words as 156 x 16 B
     const auto src4 = (CE_GPTR(const uint4))(rsrc + CE_RNG_WORDS_GRID);
     uint4* dst4 = (uint4*)E.L->mt_py;
-    for (u32 k = lane; k < (u32)kMtN / 4; k += 64) dst4[k] = src4[k];
+    // unconditional: the third round's idle lanes repeat the last quad (same value, same address)
+    const u32 q2 = min(lane + 128u, (u32)kMtN / 4 - 1);
+    const uint4 r0 = src4[lane], r1 = src4[lane + 64], r2 = src4[q2];
+    dst4[lane] = r0;
+    dst4[lane + 64] = r1;
+    dst4[q2] = r2;
   }
   rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
   feat_base_map(E);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const u32 idx = lane + 64 * r;
-    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+    const u32 av = T.apple[min(idx, (u32)G::NAPPLE - 1u)];
+    E.AP[r] = idx < (u32)G::NAPPLE ? av : 0;
     E.AS[r] = kAbsent;
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const u32 idx = lane + 64 * r;
-    E.WC[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+    const u32 wv = T.waste[G::NWASTE ? min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0)) : 0u];
+    E.WC[r] = idx < (u32)G::NWASTE ? wv : 0;
     E.WS[r] = kAbsent;
   }
   E.next_a = E.next_w = 0;
@@ -2134,18 +2147,22 @@ template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool w
   if (with_state) {
     const auto st = (CE_GPTR(const uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      if (lane + 64 * r < (u32)G::NAPPLE) E.AS[r] = st[lane + 64 * r];
+    for (int r = 0; r < 3; ++r) {
+      const u32 v = st[min(lane + 64u * r, (u32)CE_FEAT_APPLE_SLOTS - 1u)];
+      if (lane + 64 * r < (u32)G::NAPPLE) E.AS[r] = v;
+    }
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-      if (lane + 64 * r < (u32)G::NWASTE) E.WS[r] = st[CE_FEAT_APPLE_SLOTS + lane + 64 * r];
+    for (int r = 0; r < 2; ++r) {
+      const u32 v = st[CE_FEAT_APPLE_SLOTS + min(lane + 64u * r, (u32)CE_FEAT_WASTE_SLOTS - 1u)];
+      if (lane + 64 * r < (u32)G::NWASTE) E.WS[r] = v;
+    }
     const auto cnt = (CE_GPTR(const u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
     E.next_a = rfl(cnt[0]);
     E.next_w = rfl(cnt[1]);
-    if (E.is_agent) {
-      const u32 w = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, lane);
-      E.P = pad_of<GK>(w & 0xff, (w >> 8) & 0xff);
-      E.O = (w >> 16) & 3;
+    {
+      const u32 w = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, min(lane, E.n - 1u));
+      E.P = E.is_agent ? pad_of<GK>(w & 0xff, (w >> 8) & 0xff) : 0xffffu;
+      E.O = E.is_agent ? (w >> 16) & 3 : 0u;
     }
   }
   wave_sync();
@@ -2156,10 +2173,10 @@ template <int GK> DEVINL void feat_paint(FEnv<GK>& E) {
   uint8_t* pm = E.L->w.pmap;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
-    if (E.lane + 64 * r < (u32)G::NAPPLE) pm[cell_pad(E.AP[r])] = E.AS[r] != kAbsent ? CE_CELL_APPLE : CE_CELL_EMPTY;
+    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), E.AS[r] != kAbsent ? CE_CELL_APPLE : CE_CELL_EMPTY);
 #pragma unroll
   for (int r = 0; r < 2; ++r)
-    if (E.lane + 64 * r < (u32)G::NWASTE) pm[cell_pad(E.WC[r])] = E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER;
+    pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WC[r]), E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER);
   wave_sync();
 }
 template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
@@ -2324,7 +2341,7 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
       wave_sync();
 #pragma unroll
       for (int r = 0; r < AR; ++r)
-        if (elig[r]) pm[cell_pad(E.AP[r])] = spawn[r] ? (uint8_t)0x42 : (uint8_t)CE_CELL_EMPTY;  // 0x42 = spawned in this pass
+        pm_put(pm, elig[r], cell_pad(E.AP[r]), spawn[r] ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
       wave_sync();
     }
   }
@@ -2548,7 +2565,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   }
 }
 
-template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
                                                                    const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
   typedef Geo<GK> G;
   const GridParams& p = *pp;
@@ -2605,7 +2622,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
         }
       }
       wave_sync();
-      if (lane == 0) pm[pa] = CE_CELL_EMPTY;
+      pm_put(pm, lane == 0, pa, CE_CELL_EMPTY);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if (lane + 64 * r < (u32)G::NAPPLE && cell_pad(E.AP[r]) == pa) E.AS[r] = kAbsent;
@@ -2631,7 +2648,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_step(const GridPa
       const u32 c = popc64(ballot(hitw));
       if (lane == a) cleaned = c;
       wave_sync();
-      if (hitw) pm[cell] = CE_CELL_RIVER;
+      pm_put(pm, hitw, cell, CE_CELL_RIVER);
       for (u64 hw = ballot(hitw); hw; hw &= hw - 1) {
         const u32 cw = rdl(cell, ctz64(hw));
 #pragma unroll
