@@ -41,7 +41,11 @@ __constant__ u32 c_rgb[16];                                       // colour LUT,
 // ----------------------------------------------------------------------------------------
 // wave primitives
 // ----------------------------------------------------------------------------------------
-DEVINL u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+DEVINL u32 lane_id() {
+  const u32 l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  __builtin_assume(l < 64u);  // lets the compiler drop the `lane + 64 r < N` guards that are always true
+  return l;
+}
 DEVINL u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 DEVINL u32 rdl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 // clang exposes no builtin for v_writelane_b32, but the LLVM intrinsic can be declared directly; the
@@ -698,7 +702,11 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   if (rfl(E.rng.twists) != 0) {  // the key words only change at a twist; otherwise just the position moves
     uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
     const uint4* src = (const uint4*)E.L->mt;
-    for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+    const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
+    const uint4 r0 = src[E.lane], r1 = src[E.lane + 64], r2 = src[q2];
+    dst[E.lane] = r0;
+    dst[E.lane + 64] = r1;
+    dst[q2] = r2;
   }
   if (E.lane == 0) p.rng[(size_t)E.e * kRngStride + kMtN] = E.rng.pos;
 }
