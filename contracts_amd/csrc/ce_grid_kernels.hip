@@ -1315,7 +1315,9 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   const u32 voff = __umul24(lane, 12u);
   const u32* rgb = E.L->rgb;
   const auto dst_env = (CE_GPTR(char))(p.obs + (size_t)E.e * p.obs_env_stride);
-  for (u32 a = 0; a < E.n; ++a) {
+  typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+  // the 4 pixels of this lane in agent a's view, packed as 12 bytes
+  auto view_unit = [&](u32 a) -> u32x3 {
     const u32 vw = rdl(VW, a);
     const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24;
     const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)(vw & 0xffffu);
@@ -1325,20 +1327,29 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     const u32 c2 = rgb[pm[off2]];
     u32 c3 = rgb[pm[off3]];
     c3 = padded ? 0u : c3;
-    uint3 d;
+    u32x3 d;
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
     d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
     d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
+    return d;
+  };
+  auto put_unit = [&](u32 a, const u32x3& dv) {
     const u32 doff = voff + __umul24(a, (u32)kObsAgentStride);  // 32-bit offset from the wave-uniform env base
 #ifdef CE_ABLATE_OBSSTORE  // traffic experiment: the pixels are computed but not written
-    asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
+    asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
 #else
     // streaming (nontemporal) store: the observation is write-once output and the bulk of the step's bytes; keeping it
     // out of L2 / Infinity Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536)
-    typedef u32 u32x3 __attribute__((ext_vector_type(3)));
-    const u32x3 dv = {d.x, d.y, d.z};
     if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_env + doff));
 #endif
+  };
+  // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
+  // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
+  for (u32 a = 0; a < E.n; a += 2) {
+    const u32 a1 = min(a + 1u, E.n - 1u);
+    const u32x3 d0 = view_unit(a), d1 = view_unit(a1);
+    put_unit(a, d0);
+    put_unit(a1, d1);
   }
 }
 
