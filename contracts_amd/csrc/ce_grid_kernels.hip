@@ -1286,10 +1286,21 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   wave_sync();
   if (paint_agents) {
     // agents painted in agent order, the later agent wins on a shared cell (map_env.py:257-261)
-    for (u32 a = 0; a < E.n; ++a) {
-      const u32 pa = rdl(E.P, a);
-      pm_put(pm, lane == 0, pa, 6 + a);
+    if (E.n <= 8) {
+      // one (a, b) pair per lane: agent a is covered when a later agent b stands on its cell; every uncovered agent
+      // paints itself in one store
+      const u32 a = lane >> 3, b = lane & 7u;
+      const u32 pa = bperm(E.P, a), pb = bperm(E.P, b);
+      const u64 cov = ballot(a < b && b < E.n && pa == pb);
+      const bool top = ((u32)(cov >> ((lane & 7u) << 3)) & 0xffu) == 0;  // lane a < 8 reads its own row of pairs
+      pm_put(pm, E.is_agent && top, E.P, 6 + lane);
       wave_sync();
+    } else {
+      for (u32 a = 0; a < E.n; ++a) {
+        const u32 pa = rdl(E.P, a);
+        pm_put(pm, lane == 0, pa, 6 + a);
+        wave_sync();
+      }
     }
   } else {
     if (E.is_agent) pm[E.P] = (uint8_t)(pm[E.P] & kCodeMask);  // reset(): agents are not on the colour map
