@@ -1575,11 +1575,27 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   }
   u32 close_now = 0;
   if (KIND == CE_KIND_HARVEST) {
-    for (u32 a = 0; a < n; ++a) {
-      const u32 pa = rdl(E.P, a);
-      const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
-      const u32 cnt = popc64(ballot(v));
-      if (lane == a) close_now = cnt;
+    if (n <= 8) {
+      // all agents at once: lane = agent * 8 + j looks at offsets j, 8 + j, 16 + j of the 21-cell neighbourhood — three
+      // independent map reads in flight instead of n dependent read / ballot rounds
+      const u32 ag = lane >> 3, j = lane & 7u;
+      const i32 pa = (i32)bperm(E.P, ag < n ? ag : 0u);
+      const i32 o0 = (i32)T.close_off[j], o1 = (i32)T.close_off[8 + j], o2 = (i32)T.close_off[min(16u + j, 20u)];
+      const bool live = ag < n;
+      const u64 b0 = ballot(both(live, pm[live ? pa + o0 : 0] == CE_CELL_APPLE));
+      const u64 b1 = ballot(both(live, pm[live ? pa + o1 : 0] == CE_CELL_APPLE));
+      const u64 b2 = ballot(both(live && j < 5, pm[live ? pa + o2 : 0] == CE_CELL_APPLE));
+      const u32 sh8 = (lane & 7u) << 3;  // lane a < 8: its own byte of the three pair masks
+      close_now = __builtin_popcount((u32)(b0 >> sh8) & 0xffu) + __builtin_popcount((u32)(b1 >> sh8) & 0xffu) +
+                  __builtin_popcount((u32)(b2 >> sh8) & 0xffu);
+      if (!E.is_agent) close_now = 0;
+    } else {
+      for (u32 a = 0; a < n; ++a) {
+        const u32 pa = rdl(E.P, a);
+        const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
+        const u32 cnt = popc64(ballot(v));
+        if (lane == a) close_now = cnt;
+      }
     }
   }
   auto f = feat_env + __umul24(E.is_agent ? lane : 0u, nf);
