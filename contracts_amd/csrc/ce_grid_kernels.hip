@@ -1568,11 +1568,15 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
   if (ka >= kNoKey) ka = 0;  // [0, 0] sentinel when there is none
   if (kw >= kNoKey) kw = 0;
-  if (gl == 0 && ga < n) {  // the group's first lane writes agent ga's closest-apple / closest-waste features
+  if (!al && gl == 0 && ga < n) {  // odd row pitch: the group's first lane writes agent ga's closest-apple / -waste features
     auto f = feat_env + __umul24(ga, nf);
     store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
     if (KIND == CE_KIND_CLEANUP) store_feat2(f, 8, (kw >> 8) & 0xffu, kw & 0xffu, al);
   }
+  // dword-aligned rows (every harvest row, cleanup with an even n): agent lane a fetches its group's minima and
+  // writes its whole row as a few wide stores in ONE predicated block (it was ~10 dword stores in 3 blocks)
+  const u32 lead = E.is_agent ? lane << sh : 0u;
+  const u32 ka_a = bperm(ka, lead), kw_a = KIND == CE_KIND_CLEANUP ? bperm(kw, lead) : 0u;
   u32 close_now = 0;
   if (KIND == CE_KIND_HARVEST) {
     if (n <= 8) {
@@ -1599,17 +1603,51 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     }
   }
   auto f = feat_env + __umul24(E.is_agent ? lane : 0u, nf);
-  if (KIND == CE_KIND_CLEANUP) {
-    if (al) {  // n even: the cleaned vector as n/2 dwords
-      for (u32 b = 0; b < n; b += 2) {
-        const u32 w = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
-        if (E.is_agent) *(CE_GPTR(u32))(f + 12 + b) = w;
+  if (al) {
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const auto f32 = (CE_GPTR(u32))f;
+    const u32x4 head = {myrow | mycol << 16, E.O | row_of<KIND>(cpp) << 16, col_of<KIND>(cpp) | cpo << 16,
+                        ((ka_a >> 8) & 0xffu) | (ka_a & 0xffu) << 16};
+    if (KIND == CE_KIND_CLEANUP) {
+      const u32x2 mid = {((kw_a >> 8) & 0xffu) | (kw_a & 0xffu) << 16, napples | nwaste << 16};
+      u32 cw[4] = {0, 0, 0, 0};  // the cleaned vector, two agents per dword (wave-uniform)
+      if (n == 8) {
+#pragma unroll
+        for (u32 b = 0; b < 8; b += 2) cw[b >> 1] = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
       }
+      if (E.is_agent) {
+        *(CE_GPTR(u32x4))(f32) = head;
+        *(CE_GPTR(u32x2))(f32 + 4) = mid;
+        if (n == 8) {
+          const u32x4 tail = {cw[0], cw[1], cw[2], cw[3]};
+          *(CE_GPTR(u32x4))(f32 + 6) = tail;
+        }
+      }
+      if (n != 8)
+        for (u32 b = 0; b < n; b += 2) {
+          const u32 w = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
+          if (E.is_agent) f32[6 + (b >> 1)] = w;
+        }
     } else {
-      for (u32 b = 0; b < n; ++b) {
-        const u32 cb = rdl(cleaned, b);
-        if (E.is_agent) f[12 + b] = (int16_t)cb;
+      if (E.is_agent) {
+        *(CE_GPTR(u32x4))(f32) = head;
+        f32[4] = close_now | napples << 16;
+        if (n == 8) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          *(CE_GPTR(u32x4))(f32 + 5) = z;
+          *(CE_GPTR(u32x4))(f32 + 9) = z;
+        } else {
+          for (u32 b = 0; b < n; ++b) f32[5 + b] = 0u;
+        }
       }
+    }
+    return close_now;
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+    for (u32 b = 0; b < n; ++b) {
+      const u32 cb = rdl(cleaned, b);
+      if (E.is_agent) f[12 + b] = (int16_t)cb;
     }
   }
   if (E.is_agent) {
