@@ -1245,22 +1245,25 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #endif
       CE_SUBSTAMP(13);
       if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
-        u32 seen = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          if (!waste_found) {
-            const bool v = lane + 64 * r < (u32)G::NWASTE;
-            const u32 widx = r == 0 ? E.WP0 : E.WP1;
-            const u32 cell = cell_pad(T.waste[v ? widx : 0]);
-            const bool cand = both(v, (pm[cell] & kCodeMask) != CE_CELL_WASTE);
-            const u64 cb = ballot(cand);
-            const u64 sel = ballot(cand && seen + popc64(cb & lt) == tstar);
-            if (sel) {
-              waste_found = true;
-              waste_cell = rdl(cell, ctz64(sel));
-            }
-            seen += popc64(cb);
-          }
+        // both halves of the list at once; the static cell of list entry w sits in lane w (mod 64) of E.WS — a lane
+        // permute instead of a dependent table load from memory
+        static_assert(KIND != CE_KIND_CLEANUP || (G::NWASTE > 64 && G::NWASTE <= 128), "two lane rounds");
+        const bool v1 = lane + 64 < (u32)G::NWASTE;
+        const u32 w0 = E.WP0, w1 = v1 ? E.WP1 : 0u;
+        const u32 t00 = bperm(E.WS[0], w0), t01 = bperm(E.WS[1], w0 - 64u);
+        const u32 t10 = bperm(E.WS[0], w1), t11 = bperm(E.WS[1], w1 - 64u);
+        const u32 c0 = cell_pad(w0 < 64u ? t00 : t01), c1 = cell_pad(w1 < 64u ? t10 : t11);
+        const bool cand0 = (pm[c0] & kCodeMask) != CE_CELL_WASTE;
+        const bool cand1 = both(v1, (pm[c1] & kCodeMask) != CE_CELL_WASTE);
+        const u64 cb0 = ballot(cand0), cb1 = ballot(cand1);
+        const u64 sel0 = ballot(cand0 && popc64(cb0 & lt) == tstar);
+        const u64 sel1 = ballot(cand1 && popc64(cb0) + popc64(cb1 & lt) == tstar);
+        if (sel0) {
+          waste_found = true;
+          waste_cell = rdl(c0, ctz64(sel0));
+        } else if (sel1) {
+          waste_found = true;
+          waste_cell = rdl(c1, ctz64(sel1));
         }
       }
     }
