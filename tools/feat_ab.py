@@ -1,3 +1,5 @@
+"""Throughput of the two feature-vector envs (n = 2, 16 384 envs, two streams) for A/B runs of engine builds:
+    CONTRACTS_AMD_LIB=path/to/lib.so python tools/feat_ab.py"""
 import sys, time, os
 sys.path.insert(0, ".")
 import torch
