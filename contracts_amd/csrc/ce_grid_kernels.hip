@@ -392,11 +392,70 @@ template <bool TWO, int MODE = 0> DEVINL void shuffle_core(Rng& r, u32& L0, u32&
 // The same walk for a list of at most 64 items held in one register, written as ONE flat loop (one exit, the
 // cache refill as a rare `continue`): the nested form above costs ~17 scalar instructions per draw in compiler
 // generated flag shuffling, this one ~10.  MODE as in shuffle_core.
+// Lists of at most 8 elements (the agent-order shuffles of every step): the serial walk below costs ~540 cycles per
+// draw on a full SIMD — a dozen dependent scalar instructions each — and these two shuffles were a fifth of a wave's
+// life.  Here the acceptance masks of all seven possible indices (three bit masks, seven compares) are taken up
+// front, independent of each other; what stays serial per draw is and / find-first / shift on 64-bit scalars.
+// Returns the index still to be drawn (0 = done) when the cached words run out, for the serial walk to finish.
+template <int MODE> DEVINL u32 shuffle_le8(Rng& r, u32& l0, u32 len, u32 lane) {
+  u32 off = r.pos - r.cbase;
+  if (off >= r.ccount || r.ccount - off < 24u) {  // too few cached words to make running out unlikely: recache at pos
+    rng_refill(r, lane);
+    off = 0;
+  }
+  const u32 w = r.cache;
+  const u32 v7 = w & 7u, v3 = w & 3u, v1 = w & 1u;
+  const u64 B7 = ballot(v7 <= 7u), B6 = ballot(v7 <= 6u), B5 = ballot(v7 <= 5u), B4 = ballot(v7 <= 4u);
+  const u64 B3 = ballot(v3 <= 3u), B2 = ballot(v3 <= 2u), B1 = ballot(v1 <= 1u);
+  u64 avail = r.cvalid & (~0ull << off);
+  u32 i = len - 1;
+  u32 next = r.cbase + off;  // stream position after the last consumed word
+#define CE_LE8_STEP(I, B, V)                                    \
+  if (i == (I)) {                                               \
+    const u64 hit = (B) & avail;                                \
+    if (hit == 0) {                                             \
+      r.pos = next;                                             \
+      return (I);                                               \
+    }                                                           \
+    const u32 k = ctz64(hit);                                   \
+    avail &= (~1ull) << k;                                      \
+    next = r.cbase + k + 1;                                     \
+    if (MODE == 1) {                                            \
+      l0 = wrl(rdl((V), k), (I), l0);                           \
+    } else if (MODE == 0) {                                     \
+      const u32 j = rdl((V), k);                                \
+      const u32 vi = rdl(l0, (I)), vj = rdl(l0, j);             \
+      l0 = wrl(vj, (I), l0);                                    \
+      l0 = wrl(vi, j, l0);                                      \
+    }                                                           \
+    i = (I) - 1;                                                \
+  }
+  CE_LE8_STEP(7, B7, v7)
+  CE_LE8_STEP(6, B6, v7)
+  CE_LE8_STEP(5, B5, v7)
+  CE_LE8_STEP(4, B4, v7)
+  CE_LE8_STEP(3, B3, v3)
+  CE_LE8_STEP(2, B2, v3)
+  CE_LE8_STEP(1, B1, v1)
+#undef CE_LE8_STEP
+  r.pos = next;
+  return 0;
+}
+
 template <int MODE> DEVINL void shuffle_small(Rng& r, u32& L0, u32 len, u32 lane) {
   if (len < 2) return;
   rng_assert_uniform(r);
   u32 i = rfl(len) - 1;
   u32 l0 = L0;
+#ifndef CE_SERIAL_SMALL_SHUFFLE
+  if (i <= 7u) {
+    i = shuffle_le8<MODE>(r, l0, i + 1, lane);
+    if (i == 0) {
+      L0 = l0;
+      return;
+    }
+  }
+#endif
   u32 off = r.pos - r.cbase;
   if (off >= r.ccount) {
     rng_refill(r, lane);
@@ -1796,7 +1855,11 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   CE_HEAD_PTR(timestep, 5);
   CE_HEAD_PTR(theta, 6);
 #undef CE_HEAD_PTR
+#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
+  ph.debug = p.debug;  // diagnostic builds stamp through E.dbg
+#else
   ph.debug = nullptr;
+#endif
   ph.E = sb[0];
   ph.n = sb[1];
   const auto acts = (CE_GPTR(const uint8_t))((u64)ka[2] | ((u64)ka[3] << 32));
