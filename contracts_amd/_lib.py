@@ -52,6 +52,11 @@ class CeBuffers(C.Structure):
     ]
 
 
+class CeTraj(C.Structure):
+    _fields_ = [("num_planes", C.c_uint32), ("first_plane", C.c_uint32), ("obs", _P), ("obs_f64", _P), ("base_reward", _P),
+                ("reward", _P), ("done", _P), ("done_agents", _P), ("info", _P), ("features", _P)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ce_abi_version": (C.c_int, []),
@@ -65,6 +70,7 @@ EXPORTS = {
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "ce_rollout_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeTraj), C.c_uint32, C.c_void_p]),
     "ce_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_synth_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ce_synth_action_host": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),

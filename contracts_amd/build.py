@@ -42,6 +42,10 @@ def build(force=False, verbose=False):
     if stamps:  # diagnostic build: s_memtime stamps per phase, separate file, never benchmarked
         flags.append("-DCE_PHASE_STAMPS")
         lib, suffix, force = LIB.replace(".so", "_stamps.so"), "_stamps", True
+    variant = os.environ.get("CE_VARIANT")  # experiment builds: extra flags, separate file (CONTRACTS_AMD_LIB selects it)
+    if variant:
+        flags += os.environ.get("CE_VARIANT_FLAGS", "").split()
+        lib, suffix, force = LIB.replace(".so", "_%s.so" % variant), "_" + variant, True
     if not force and not needs_build():
         return LIB
     objs = []

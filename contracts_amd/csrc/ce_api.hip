@@ -544,6 +544,66 @@ extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, 
   return CE_OK;
 }
 
+extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_steps, uint32_t steps_per_launch,
+                                const ce_traj* traj, uint32_t num_slices, void* const* streams) {
+  if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
+  if (traj && traj->num_planes == 0) return fail(h, CE_EINVAL, "ce_traj.num_planes must be at least 1");
+  if (traj && traj->first_plane >= traj->num_planes) return fail(h, CE_EINVAL, "ce_traj.first_plane out of range");
+  (void)hipSetDevice(h->cfg.device);
+  const ce_buffers& b = h->buf;
+  const uint64_t E = h->cfg.num_envs, n = h->cfg.num_agents;
+  RolloutArgs ra;
+  std::memset(&ra, 0, sizeof(ra));
+  // an array the caller did not supply is the handle's own buffer, overwritten by every step (plane stride 0)
+#define CE_TRAJ(field, elems)                                   \
+  do {                                                          \
+    if (traj && traj->field) {                                  \
+      ra.field = traj->field;                                   \
+      ra.field##_plane = (elems);                               \
+    } else {                                                    \
+      ra.field = b.field;                                       \
+      ra.field##_plane = 0;                                     \
+    }                                                           \
+  } while (0)
+  CE_TRAJ(obs, E * b.obs_env_stride);
+  CE_TRAJ(obs_f64, E * n * (2 * n + 7));
+  CE_TRAJ(reward, E * n);
+  CE_TRAJ(done, E);
+  CE_TRAJ(done_agents, E * n);
+  CE_TRAJ(info, E * n * 2);
+  CE_TRAJ(features, E * n * b.num_features);
+#undef CE_TRAJ
+  if (traj && traj->base_reward) {
+    ra.base_reward = traj->base_reward;
+    ra.agent_plane = E * n;
+  } else {
+    ra.base_reward = b.base_reward;
+    ra.agent_plane = 0;
+  }
+  ra.action_plane = E * n;  // elements (bytes for the u8 kinds, floats for selfdrive)
+  ra.num_planes = traj ? traj->num_planes : 1;
+  ra.env_first = 0;
+  ra.env_end = (uint32_t)E;
+  const uint32_t per = steps_per_launch ? steps_per_launch : num_steps;
+  uint32_t plane = traj ? traj->first_plane : 0;
+  for (uint32_t s0 = 0; s0 < num_steps; s0 += per) {
+    const uint32_t cnt = num_steps - s0 < per ? num_steps - s0 : per;
+    ra.actions = (const char*)actions + (size_t)s0 * E * n * (u8_actions(h->cfg) ? 1 : 4);
+    ra.num_steps = cnt;
+    ra.plane0 = plane;
+    for (uint32_t sl = 0; sl < num_slices; ++sl) {
+      ra.env_first = (uint32_t)(E * sl / num_slices);
+      ra.env_end = (uint32_t)(E * (sl + 1) / num_slices);
+      void* stream = streams ? streams[sl] : nullptr;
+      if (is_grid(h->cfg)) launch_grid_rollout((int)h->cfg.kind, h->d_gparams, ra, stream);
+      else return fail(h, CE_EINVAL, "ce_rollout_fused: not built for this env family yet");
+      if (h->timing_armed) h->timed_launches++;
+    }
+    plane = (uint32_t)(((uint64_t)plane + cnt) % ra.num_planes);
+  }
+  return check_launch(h, "fused rollout kernel");
+}
+
 extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
   if (!h) return CE_EINVAL;
   return ce_step_range(h, actions, active, 0, h->cfg.num_envs, stream);

@@ -102,6 +102,24 @@ struct GridParams {
   double contract_low, contract_high, null_prob, alpha, beta;
 };
 
+// By-value kernel argument of the fused rollout kernels (ce_rollout_fused).  Step s of the launch reads action plane s
+// and writes plane (plane0 + s) mod num_planes of each output array; *_plane = distance between consecutive planes in
+// ELEMENTS of that array (0 = the array is the handle's own per-step buffer and every step overwrites it).
+struct RolloutArgs {
+  CE_GPTR(const void) actions;  // [num_steps][E][n] uint8 ids (grid / feature kinds) or float32 accelerations (selfdrive)
+  CE_GPTR(uint8_t) obs;
+  CE_GPTR(double) obs_f64;      // selfdrive
+  CE_GPTR(int32_t) base_reward;
+  CE_GPTR(double) reward;
+  CE_GPTR(uint8_t) done;
+  CE_GPTR(uint8_t) done_agents;  // selfdrive
+  CE_GPTR(uint8_t) info;
+  CE_GPTR(int16_t) features;
+  uint64_t action_plane, obs_plane, obs_f64_plane, agent_plane, reward_plane, done_plane, done_agents_plane, info_plane, features_plane;
+  uint32_t num_steps, num_planes, plane0;
+  uint32_t env_first, env_end;
+};
+
 struct SdParams {
   CE_GPTR(double) sd_state;
   CE_GPTR(uint32_t) rng;
@@ -139,6 +157,7 @@ void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream);
 void launch_sd_construct(const SdParams& p, void* stream);
 void launch_sd_reset(const SdParams& p, void* stream);
 void launch_sd_step(const SdParams& p, void* stream);

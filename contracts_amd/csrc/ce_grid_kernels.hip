@@ -743,6 +743,25 @@ template <int KIND> DEVINL void load_static(Env<KIND>& E) {
   if (E.lane < 16) E.L->rgb[E.lane] = c_rgb[E.lane];
 }
 
+// The same two tables with unconditional clamped loads (a fused rollout re-fetches them at the top of every step: five
+// L1-resident loads are cheaper than five registers held across the whole step body)
+template <int KIND> DEVINL void reload_static(Env<KIND>& E) {
+  typedef Geo<KIND> G;
+  const GridTables& T = c_tab[KIND];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const u32 idx = E.lane + 64 * r;
+    const u32 v = T.apple[min(idx, (u32)G::NAPPLE - 1u)];
+    E.AP[r] = idx < (u32)G::NAPPLE ? v : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const u32 idx = E.lane + 64 * r;
+    const u32 v = T.waste[G::NWASTE ? min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0)) : 0u];
+    E.WS[r] = idx < (u32)G::NWASTE ? v : 0;
+  }
+}
+
 template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
   const uint4* src = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
   uint4* dst = (uint4*)E.L->mt;
@@ -1341,11 +1360,19 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 // ----------------------------------------------------------------------------------------
 // observation crop: the env's n*225 pixels as one byte stream, 4 pixels (12 B) per lane
 // ----------------------------------------------------------------------------------------
-template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, bool paint_agents) {
+// `obs` = base of the [E][obs_env_stride] plane this step's observation goes to.  RESTORE (fused rollouts): the map
+// bytes under the painted agents are put back afterwards (cell code only, agent bit cleared), so the LDS map stays the
+// env's map for the next step of the same launch.
+template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, CE_GPTR(uint8_t) obs, bool paint_agents) {
   typedef Geo<KIND> G;
   const u32 lane = E.lane;
   uint8_t* pm = E.L->pmap;
   wave_sync();
+  u32 under = 0;
+  if (RESTORE && paint_agents) {
+    under = pm[pm_sel(E.is_agent, E.P)] & kCodeMask;
+    wave_sync();
+  }
   if (paint_agents) {
     // agents painted in agent order, the later agent wins on a shared cell (map_env.py:257-261)
     if (E.n <= 8) {
@@ -1387,7 +1414,7 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
   const bool padded = j0 == 12;  // column 15 is the row padding
   const u32 voff = __umul24(lane, 12u);
   const u32* rgb = E.L->rgb;
-  const auto dst_env = (CE_GPTR(char))(p.obs + (size_t)E.e * p.obs_env_stride);
+  const auto dst_env = (CE_GPTR(char))(obs + (size_t)E.e * p.obs_env_stride);
   typedef u32 u32x3 __attribute__((ext_vector_type(3)));
   // the 4 pixels of this lane in agent a's view, packed as 12 bytes
   auto view_unit = [&](u32 a) -> u32x3 {
@@ -1423,6 +1450,11 @@ template <int KIND> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, boo
     const u32x3 d0 = view_unit(a), d1 = view_unit(a1);
     put_unit(a, d0);
     put_unit(a1, d1);
+  }
+  if (RESTORE && paint_agents) {
+    wave_sync();
+    pm_put(pm, E.is_agent, E.P, under);
+    wave_sync();
   }
 }
 
@@ -1560,13 +1592,13 @@ template <class P> DEVINL void store_feat2(P f, u32 idx, u32 lo, u32 hi, bool al
   }
 }
 
-template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, u32 cleaned) {
+template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned) {
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
   uint8_t* pm = E.L->pmap;
   const u32 nf = p.num_features;
-  const auto feat_env = p.features + (size_t)E.e * n * nf;  // wave-uniform base, 32-bit lane offsets below
+  const auto feat_env = features + (size_t)E.e * n * nf;  // wave-uniform base, 32-bit lane offsets below
   const bool al = (nf & 1u) == 0;  // feature rows dword aligned
   const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos bug: a0 -> a1, everyone else -> a0
   const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
@@ -1814,8 +1846,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   store_rng(E, p);
   clear_step_outputs(E, p);
   if (!E.is_agent) E.P = 0xffffu;
-  compute_features(E, p, 0u);
-  write_obs(E, p, false);  // reset() does not paint the agents on the colour map
+  compute_features(E, p, p.features, 0u);
+  write_obs(E, p, p.obs, false);  // reset() does not paint the agents on the colour map
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
     p.theta[E.e] = theta;
@@ -1824,68 +1856,46 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
-                 u32 env_first, u32 env_end) {
-  const GridParams& p = *pp;
-  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
-  Env<KIND> E;
-#ifndef CE_NO_PRELOAD
-  // Entry latency: left to itself the compiler fetches each kernel argument and each parameter-block field with its own
-  // scalar load right before the first use, behind the branches of the range check — five to six serialised ≈ 270-cycle
-  // round trips before the first state load is even issued.  Two batched fetches instead: the 32-byte kernarg segment,
-  // then the head of the block (state pointers) and its scalar fields together; the first phase reads from these copies.
-  typedef u32 u32x8 __attribute__((ext_vector_type(8)));
-  typedef u32 u32x16 __attribute__((ext_vector_type(16)));
-  static_assert(offsetof(GridParams, theta) == 0x30 && offsetof(GridParams, E) == 0xb0 && offsetof(GridParams, num_features) == 0xc8,
-                "preload offsets follow the GridParams layout");
-  u32x8 ka;
-  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ka) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
-  u32x16 hb;
-  u32x8 sb;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0xb0\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(hb), "=&s"(sb)
-               : "s"((u64)ka[0] | ((u64)ka[1] << 32)));
-  GridParams ph;
-#define CE_HEAD_PTR(field, k) ph.field = (decltype(ph.field))((u64)hb[2 * (k)] | ((u64)hb[2 * (k) + 1] << 32))
-  CE_HEAD_PTR(grid, 0);
-  CE_HEAD_PTR(agents, 1);
-  CE_HEAD_PTR(spawn_perm, 2);
-  CE_HEAD_PTR(waste_perm, 3);
-  CE_HEAD_PTR(rng, 4);
-  CE_HEAD_PTR(timestep, 5);
-  CE_HEAD_PTR(theta, 6);
-#undef CE_HEAD_PTR
-#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
-  ph.debug = p.debug;  // diagnostic builds stamp through E.dbg
-#else
-  ph.debug = nullptr;
-#endif
-  ph.E = sb[0];
-  ph.n = sb[1];
-  const auto acts = (CE_GPTR(const uint8_t))((u64)ka[2] | ((u64)ka[3] << 32));
-  if (!env_begin(E, ph, lds, ka[6], ka[7])) return;
-#else
-  const GridParams& ph = p;
-  const auto acts = (CE_GPTR(const uint8_t))call_actions;
-  if (!env_begin(E, p, lds, env_first, env_end)) return;
-#endif
-    const GridTables& T = c_tab[KIND];
+// ----------------------------------------------------------------------------------------
+// Where a step's per-step outputs go.  StepOutDirect: the handle's own [E] buffers (one launch per step).
+// StepOutPlane: plane `pl` of the trajectory arrays of a fused rollout (ce_rollout_fused; an array the caller did not
+// supply is the handle's buffer with plane stride 0, resolved on the host).
+// ----------------------------------------------------------------------------------------
+struct StepOutDirect {
+  const GridParams& p;
+  DEVINL CE_GPTR(uint8_t) obs() const { return p.obs; }
+  DEVINL CE_GPTR(int32_t) base_reward() const { return p.base_reward; }
+  DEVINL CE_GPTR(double) reward() const { return p.reward; }
+  DEVINL CE_GPTR(uint8_t) done() const { return p.done; }
+  DEVINL CE_GPTR(uint8_t) info() const { return p.info; }
+  DEVINL CE_GPTR(int16_t) features() const { return p.features; }
+};
+struct StepOutPlane {
+  const RolloutArgs& ra;
+  u32 pl;
+  DEVINL CE_GPTR(uint8_t) obs() const { return ra.obs + (size_t)pl * ra.obs_plane; }
+  DEVINL CE_GPTR(int32_t) base_reward() const { return ra.base_reward + (size_t)pl * ra.agent_plane; }
+  DEVINL CE_GPTR(double) reward() const { return ra.reward + (size_t)pl * ra.reward_plane; }
+  DEVINL CE_GPTR(uint8_t) done() const { return ra.done + (size_t)pl * ra.done_plane; }
+  DEVINL CE_GPTR(uint8_t) info() const { return ra.info + (size_t)pl * ra.info_plane; }
+  DEVINL CE_GPTR(int16_t) features() const { return ra.features + (size_t)pl * ra.features_plane; }
+};
+
+// One env-step on the state held in E / LDS: MapEnv.step, infos, contract transfer, metrics, observation, in-launch
+// auto-reset.  FUSED = false: the step is its own launch and the state is written back to HBM at the end.
+// FUSED = true (k_grid_rollout): the state stays resident for the next step; only the per-step outputs leave.
+template <int KIND, bool FUSED, class OUT>
+DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u32 ACT, u32& t, double& theta, u32& fault,
+                           bool& did_reset) {
+  const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
-
-  // the action load is in flight together with the state loads; it is validated before anything is written
-  u32 ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
-  CE_STAMP(0);
-  CE_REALSTAMP(14);
-  load_env_state(E, ph);
-  u32 t = (u32)ph.timestep[E.e];
-  double theta = ph.theta[E.e];
   const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
-  if (ballot(E.is_agent && ACT > max_action) != 0) {  // KeyError in the reference (Agent.py:174,213)
-    if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
+  if (ballot(E.is_agent && ACT > max_action) != 0) {  // KeyError in the reference (Agent.py:174,213): the step is not taken
+    if (FUSED) fault |= CE_FAULT_BAD_ACTION;
+    else if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
     return;
   }
-  u32 fault = 0;
   uint8_t* pm = E.L->pmap;
 
   // ---------------- MapEnv.step ----------------
@@ -1895,7 +1905,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   {
 #ifdef CE_PROBE_SMEM  // 16 serialised scalar-load round trips from the parameter block
     u32 pm_ = 0;
-    asm volatile(".rept 16\n s_load_dword %0, %1, 0xb4\n s_waitcnt lgkmcnt(0)\n .endr" : "=s"(pm_) : "s"(pp) : "memory");
+    asm volatile(".rept 16\n s_load_dword %0, %1, 0xb4\n s_waitcnt lgkmcnt(0)\n .endr" : "=s"(pm_) : "s"(&p) : "memory");
     if (pm_ == 0xdeadbeefu) t += 1;
 #endif
 #ifdef CE_PROBE_LDS  // 16 serialised LDS read round trips
@@ -2006,7 +2016,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   CE_STAMP(5);
   // ---------------- feature obs, infos, metrics ----------------
 #ifndef CE_ABLATE_FEATURES
-  const u32 feat8 = compute_features(E, p, cleaned);
+  const u32 feat8 = compute_features(E, p, out.features(), cleaned);
 #else
   const u32 feat8 = 0;
 #endif
@@ -2016,8 +2026,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   // observation instead and keeps the late path.
   const bool obs_early = t != p.horizon;
   if (obs_early) {
-    store_grid(E, p);
-    write_obs(E, p, true);
+    if (!FUSED) store_grid(E, p);  // a fused rollout keeps the map in LDS and packs it once, after its last step
+    write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   double transfers_total = 0.0;
@@ -2091,13 +2101,12 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     }
   }
   if (E.is_agent) {
-    GAT(p.base_reward + ea, lane) = base_rew;
-    GAT(p.reward + ea, lane) = rew;
+    GAT(out.base_reward() + ea, lane) = base_rew;
+    GAT(out.reward() + ea, lane) = rew;
     const u32 info2 = eaten | (KIND == CE_KIND_CLEANUP ? cleaned : eaten_close) << 8;  // info[a][0..1] as one short
-    *(CE_GPTR(uint16_t))(p.info + 2 * ea + 2 * lane) = (uint16_t)info2;
+    *(CE_GPTR(uint16_t))(out.info() + 2 * ea + 2 * lane) = (uint16_t)info2;
   }
 
-  bool did_reset = false;
   if (done) {
     // equality / sustainability (cleanup_new.py:422-445) and their transferred versions
     const long long sr = E.is_agent ? m_sr : 0;
@@ -2141,13 +2150,20 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
     for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
     if (p.flags & CE_FLAG_AUTO_RESET) {
       __threadfence_block();
+      if (FUSED) E.SP = GAT(p.spawn_perm + (size_t)E.e * 20, min(lane, 19u));  // the spawn list is only ever needed here
       reset_env(E, p, theta, t, fault);
+      if (FUSED) store_perms(E, p, true, false);
       did_reset = true;
     }
   }
 
   CE_STAMP(7);
   // ---------------- state out ----------------
+  if (FUSED) {  // the env state stays in registers / LDS for the next step of this launch
+    if (lane == 0) out.done()[E.e] = done ? 1 : 0;
+    if (!obs_early) write_obs<KIND, true>(E, p, out.obs(), !did_reset);
+    return;
+  }
   if (!obs_early) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, did_reset, E.waste_perm_dirty);
@@ -2156,14 +2172,155 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
 #endif
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
-    p.done[E.e] = done ? 1 : 0;
+    out.done()[E.e] = done ? 1 : 0;
     if (did_reset) p.theta[E.e] = theta;
     if (fault) p.error_flags[E.e] |= fault;
   }
   CE_STAMP(8);
-  if (!obs_early) write_obs(E, p, !did_reset);
+  if (!obs_early) write_obs(E, p, out.obs(), !did_reset);
   CE_STAMP(9);
   CE_REALSTAMP(15);
+}
+
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+                 u32 env_first, u32 env_end) {
+  const GridParams& p = *pp;
+  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
+  Env<KIND> E;
+#ifndef CE_NO_PRELOAD
+  // Entry latency: left to itself the compiler fetches each kernel argument and each parameter-block field with its own
+  // scalar load right before the first use, behind the branches of the range check — five to six serialised ≈ 270-cycle
+  // round trips before the first state load is even issued.  Two batched fetches instead: the 32-byte kernarg segment,
+  // then the head of the block (state pointers) and its scalar fields together; the first phase reads from these copies.
+  typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+  typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+  static_assert(offsetof(GridParams, theta) == 0x30 && offsetof(GridParams, E) == 0xb0 && offsetof(GridParams, num_features) == 0xc8,
+                "preload offsets follow the GridParams layout");
+  u32x8 ka;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ka) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+  u32x16 hb;
+  u32x8 sb;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0xb0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(hb), "=&s"(sb)
+               : "s"((u64)ka[0] | ((u64)ka[1] << 32)));
+  GridParams ph;
+#define CE_HEAD_PTR(field, k) ph.field = (decltype(ph.field))((u64)hb[2 * (k)] | ((u64)hb[2 * (k) + 1] << 32))
+  CE_HEAD_PTR(grid, 0);
+  CE_HEAD_PTR(agents, 1);
+  CE_HEAD_PTR(spawn_perm, 2);
+  CE_HEAD_PTR(waste_perm, 3);
+  CE_HEAD_PTR(rng, 4);
+  CE_HEAD_PTR(timestep, 5);
+  CE_HEAD_PTR(theta, 6);
+#undef CE_HEAD_PTR
+#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
+  ph.debug = p.debug;  // diagnostic builds stamp through E.dbg
+#else
+  ph.debug = nullptr;
+#endif
+  ph.E = sb[0];
+  ph.n = sb[1];
+  const auto acts = (CE_GPTR(const uint8_t))((u64)ka[2] | ((u64)ka[3] << 32));
+  if (!env_begin(E, ph, lds, ka[6], ka[7])) return;
+#else
+  const GridParams& ph = p;
+  const auto acts = (CE_GPTR(const uint8_t))call_actions;
+  if (!env_begin(E, p, lds, env_first, env_end)) return;
+#endif
+  const u32 lane = E.lane, n = E.n;
+  const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
+
+  // the action load is in flight together with the state loads; it is validated before anything is written
+  u32 ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
+  CE_STAMP(0);
+  CE_REALSTAMP(14);
+  load_env_state(E, ph);
+  u32 t = (u32)ph.timestep[E.e];
+  double theta = ph.theta[E.e];
+  u32 fault = 0;
+  bool did_reset = false;
+  grid_step_core<KIND, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
+}
+
+// Fused multi-step rollout (ce_rollout_fused): the env's state — map, agent table, persistent lists, MT19937 — is loaded
+// once, stays in LDS / registers for `num_steps` consecutive steps and is written back once; every step still reads its
+// own action plane and writes its own observation / reward / info / feature / done outputs (plane (plane0 + s) mod
+// num_planes of the trajectory arrays).  Results are those of num_steps single-step launches, bit for bit.
+// Consumers in the reference that roll whole episodes per call: run_solver.py:35-65, two_stage_train.py:290-333.
+// Loop-invariant scalar loads (parameter-block fields, trajectory pointers) and everything derived from the env index
+// would be hoisted out of the step loop and then live in registers across the whole step body — far more than there
+// are.  Each iteration therefore takes them through a value the compiler cannot see through: a real v_mov inside a
+// volatile asm (an empty asm with a "+v" operand would leave the SGPR -> VGPR copy hoistable, i.e. a VGPR held across
+// the loop per value), re-asserted wave-uniform with v_readfirstlane.  Two instructions per value and step.
+DEVINL u32 opaque_u32(u32 x) {
+  u32 v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return rfl(v);
+}
+// ... and for the two read-only argument blocks the pointer is typed into the constant address space, so that the field
+// reads stay scalar loads (an integer-built pointer is a flat one to the compiler).
+template <class T> DEVINL const T& opaque_block(const T* q) {
+  typedef const __attribute__((address_space(4))) T* cptr;
+  return *(const T*)(cptr)(((u64)opaque_u32((u32)((u64)q >> 32)) << 32) | opaque_u32((u32)(u64)q));
+}
+
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+  // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
+  static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
+  const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  __shared__ WaveLds<KIND> lds[kWavesPerBlock];
+  Env<KIND> E;
+  if (!env_begin(E, *pp, lds, rap->env_first, rap->env_end)) return;
+  u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))rap->actions + (size_t)E.e * E.n, E.lane) : 4u;
+  load_env_state(E, *pp);
+  u32 t = rfl((u32)pp->timestep[E.e]);
+  double theta = shfl_f64(pp->theta[E.e], 0);  // wave-uniform: kept in SGPRs across the loop
+  u32 fault = 0, pl = rap->plane0;
+  bool any_reset = false;
+  const u32 num_steps = rap->num_steps;
+  for (u32 s = 0; s < num_steps; ++s) {
+    const GridParams& p = opaque_block(pp);
+    const RolloutArgs& ra = opaque_block(rap);
+    // the same for everything derived from the lane id / env index (address offsets, masks, group ids): recomputed per
+    // step like in a single-step launch instead of living in registers across the loop
+    asm volatile("" : "+v"(E.lane));
+    E.n = opaque_u32(E.n);
+    E.e = opaque_u32(E.e);
+    E.is_agent = E.lane < E.n;
+    const u32 lane = E.lane;
+    const size_t ea = (size_t)E.e * E.n;
+    reload_static(E);
+    E.SP = 0;  // lives in HBM between resets (grid_step_core fetches it for an in-launch reset)
+    // the next step's actions are in flight while this step runs (the last iteration re-reads its own plane)
+    const u32 sn = s + 1 < num_steps ? s + 1 : s;
+    const u32 ACTN = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))ra.actions + (size_t)sn * ra.action_plane + ea, lane) : 4u;
+    bool did_reset = false;
+    grid_step_core<KIND, true>(E, p, StepOutPlane{ra, pl}, ACT, t, theta, fault, did_reset);
+    ACT = ACTN;
+    pl = pl + 1 == ra.num_planes ? 0u : pl + 1;
+    // what is carried into the next step as a wave-uniform value must also be one for the compiler (a loop-carried
+    // value that merges with anything it takes for divergent becomes a VGPR held across the whole body)
+    rng_assert_uniform(E.rng);
+    E.rng.twists = rfl(E.rng.twists);
+    E.waste_perm_dirty = rfl((u32)E.waste_perm_dirty) != 0;
+    t = rfl(t);
+    fault = rfl(fault);
+    any_reset = rfl((u32)(any_reset || did_reset)) != 0;
+    if (did_reset) theta = shfl_f64(theta, 0);  // comes out of VALU double arithmetic
+    E.RW = 0;
+  }
+  const GridParams& p = opaque_block(pp);
+  asm volatile("" : "+v"(E.lane));
+  reload_static(E);
+  store_grid(E, p);
+  store_agents(E, p);
+  store_perms(E, p, false, E.waste_perm_dirty);
+  store_rng(E, p);
+  if (E.lane == 0) {
+    p.timestep[E.e] = (i32)t;
+    if (any_reset) p.theta[E.e] = theta;
+    if (fault) p.error_flags[E.e] |= fault;
+  }
 }
 
 // ========================================================================================
@@ -3169,6 +3326,13 @@ static unsigned extra_lds() {
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+
+void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+  const u32 count = ra.env_end - ra.env_first;
+  dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_rollout<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+  else hipLaunchKernelGGL(k_grid_rollout<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+}
 
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
   if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);

@@ -67,6 +67,45 @@ class _DevArray:
         self._owner = owner
 
 
+class Trajectory:
+    """Per-step outputs of a fused rollout as [P, E, ...] device tensors; step s of a call lands in plane
+    (first_plane + s) % P.  `fields` selects which outputs are kept as trajectories (the others go to the engine's
+    per-step buffers, overwritten every step)."""
+
+    def __init__(self, env, num_planes, fields=None):
+        import torch
+        b, E, n, P = env.b, env.E, env.n, int(num_planes)
+        dev = "cuda:%d" % env.cfg.device
+        if env.kind == "selfdrive":
+            shapes = {"obs_f64": ((E, n, 2 * n + 7), torch.float64), "done_agents": ((E, n), torch.uint8)}
+        elif env.kind in _lib.FEAT_KINDS:
+            shapes = {"features": ((E, n, b.num_features), torch.int16)}
+        else:
+            shapes = {"obs": ((E, b.obs_env_stride), torch.uint8), "features": ((E, n, b.num_features), torch.int16)}
+        shapes.update({"base_reward": ((E, n), torch.int32), "reward": ((E, n), torch.float64), "done": ((E,), torch.uint8),
+                       "info": ((E, n, 2), torch.uint8)})
+        self.env, self.P = env, P
+        self.tensors = {}
+        self.c = _lib.CeTraj()
+        self.c.num_planes, self.c.first_plane = P, 0
+        for f, (shape, dt) in shapes.items():
+            if fields is not None and f not in fields:
+                continue
+            t = torch.zeros((P,) + shape, dtype=dt, device=dev)
+            self.tensors[f] = t
+            setattr(self.c, f, t.data_ptr())
+
+    def host(self, field):
+        """host copy [P, E, ...]; obs comes back dense [P, E, n, 15, 15, 3]"""
+        a = self.tensors[field].cpu().numpy()
+        if field == "obs":
+            b, n = self.env.b, self.env.n
+            a = a.reshape(self.P, self.env.E, n, b.obs_agent_stride)[..., : 15 * b.obs_row_stride]
+            a = np.ascontiguousarray(a.reshape(self.P, self.env.E, n, 15, b.obs_row_stride)[..., :45]).reshape(
+                self.P, self.env.E, n, 15, 15, 3)
+        return a
+
+
 class BatchedEnv:
     def __init__(self, kind, num_envs, num_agents, **kw):
         self.kind, self.E, self.n = kind, int(num_envs), int(num_agents)
@@ -160,6 +199,25 @@ class BatchedEnv:
             check(self._L.ce_rollout(self._h, actions_ptr, int(num_steps), len(stream_handles), arr), self._h, "ce_rollout")
         else:
             check(self._L.ce_rollout(self._h, actions_ptr, int(num_steps), 1, None), self._h, "ce_rollout")
+
+    def rollout_fused(self, actions_ptr, num_steps, steps_per_launch=0, traj=None, stream_handles=None):
+        """num_steps consecutive steps from device action planes [T, E, n] with ONE launch per steps_per_launch steps
+        (0 = a single launch): the env state stays on chip between the steps of a launch, every step still writes all
+        of its outputs — to its plane of `traj` (a Trajectory) or, without one, to the per-step buffers.  Bit-identical
+        to num_steps step_device() calls (see ce_rollout_fused).  stream_handles: raw HIP stream handles, one contiguous
+        env slice per stream (None = one slice on the null stream)."""
+        t = None if traj is None else C.byref(traj.c)
+        ns, arr = 1, None
+        if stream_handles:
+            ns, arr = len(stream_handles), (C.c_void_p * len(stream_handles))(*stream_handles)
+        check(self._L.ce_rollout_fused(self._h, actions_ptr, int(num_steps), int(steps_per_launch), t, ns, arr), self._h,
+              "ce_rollout_fused")
+        if traj is not None:
+            traj.c.first_plane = (traj.c.first_plane + int(num_steps)) % traj.c.num_planes
+
+    def alloc_trajectory(self, num_planes, fields=None):
+        """device-resident trajectory arrays [P, E, ...] for rollout_fused (torch owns the memory: plumbing only)"""
+        return Trajectory(self, num_planes, fields)
 
     def synth_actions(self, key, t0, T, out_ptr, stream=None):
         check(self._L.ce_synth_actions(self._h, int(key), int(t0), int(T), out_ptr, stream), self._h, "ce_synth_actions")

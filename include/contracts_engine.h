@@ -114,7 +114,7 @@ typedef struct ce_buffers {
   uint32_t obs_row_stride;       /* bytes between consecutive rows of a 15x15x3 view (48: rows are
                                     pitched to 16 pixels so a 4-pixel store unit never straddles a row) */
 
-  /* ---- persistent env state (read-write via ce_get_state / ce_set_state) ---- */
+  /* ---- persistent env state (host copies via ce_download / ce_upload) ---- */
   uint8_t* grid;        /* grid kinds: 32 bytes per env (grid_env_stride) — one "present" bit per apple cell (bits 0..)
                            and per waste cell (bits 128..) in row-major cell order, bit 255 = blank map; the rest
                            of the map is static.  ce_download / ce_upload("grid") convert from / to the padded
@@ -270,6 +270,38 @@ int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint3
  * all on the null stream).  actions: DEVICE pointer to [num_steps][E][n] planes.  Every step is still its own
  * launch reading its own action plane; only the host-side loop moves out of the interpreter. */
 int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams);
+
+/* Trajectory arrays of a fused rollout (all DEVICE pointers, caller-owned; each holds `num_planes` planes with the
+ * layout of the per-step buffer of the same name in ce_buffers: obs [P][E][obs_env_stride], base_reward [P][E][n], ...).
+ * A NULL array means "not wanted as a trajectory": that output is written to the handle's own per-step buffer instead,
+ * every step, and holds the last step's values on return — exactly what num_steps ce_step calls leave there. */
+typedef struct ce_traj {
+  uint32_t num_planes;   /* planes per array; step s of a call goes to plane (first_plane + s) % num_planes   */
+  uint32_t first_plane;
+  uint8_t* obs;          /* grid kinds                                                                         */
+  double* obs_f64;       /* selfdrive                                                                          */
+  int32_t* base_reward;
+  double* reward;
+  uint8_t* done;
+  uint8_t* done_agents;  /* selfdrive                                                                          */
+  uint8_t* info;
+  int16_t* features;     /* grid / feature kinds                                                               */
+} ce_traj;
+
+/* Fused multi-step rollout for pre-supplied actions: ONE launch per `steps_per_launch` consecutive env-steps.  Each
+ * env's state (map, agent table, persistent shuffled lists, MT19937) is loaded once per launch, stays on chip for the
+ * steps of that launch and is written back once; every step still reads its own action plane (actions: DEVICE pointer
+ * to [num_steps][E][n]) and writes all of its per-step outputs (observation, rewards, infos, features, done; in-launch
+ * auto-reset included) to its plane of `traj` (NULL = the handle's per-step buffers).  State, outputs, metrics and RNG
+ * streams after the call are bit-identical to num_steps ce_step calls.  steps_per_launch = 0 means one launch for all
+ * steps.  Reference callers that roll whole episodes per call: run_solver.py:35-65, two_stage_train.py:290-333.
+ * Selfdrive: agents that are not done act (the `active = NULL` behaviour of ce_step).
+ * num_slices / streams as in ce_rollout: the env axis is cut into num_slices contiguous slices, slice i is launched on
+ * streams[i] (NULL = everything on the null stream).  Envs are independent, so results do not depend on the slicing; a
+ * launch's waves all run equally long, and with one launch in flight the chip idles through the last, partly filled
+ * round of wave slots — several slices in flight fill one slice's tail with the next launch of another. */
+int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_steps, uint32_t steps_per_launch,
+                     const ce_traj* traj, uint32_t num_slices, void* const* streams);
 
 /* Same as ce_step with HOST action / active pointers: they are copied to an engine-owned
  * staging buffer on `stream` first (the per-env adapters use this). */
