@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the rollout hot path on MI355X.
 
-Workload (BASELINE.json north star / configs[3]): CleanupEnv `cleanup_new`, 8 agents, CleanupContract,
-16384 env replicas per GPU (131072 over 8 GPUs; weak scaling, plain shard of the env axis, no
-collectives), horizon 1000 with in-engine auto-reset, uniform i.i.d. synthetic actions generated on
-device by the counter hash keyed (seed, global env index, t, agent) and resident in HBM before the
-timed region.  A "step" = one pass of the hot path over the whole env batch of this rank (MapEnv.step +
-obs crop + contract transfer for every env), issued as `--streams` (default 3) ce_step_range launches over
-contiguous env slices on separate HIP streams: slices are independent, so one slice's kernel tail overlaps
-the other's head (the same double buffering an RL sampler uses to overlap policy inference with stepping).
+Workload (BASELINE.json north star / configs[3]): CleanupEnv `cleanup_new`, 8 agents, CleanupContract, 16384 env
+replicas per GPU (131072 over 8 GPUs; weak scaling, plain shard of the env axis, no collectives), horizon 1000 with
+in-engine auto-reset, uniform i.i.d. synthetic actions from the counter hash keyed (seed, global env index, t, agent),
+resident in HBM before the timed region.  A "step" = one pass of the hot path over the whole env batch of this rank
+(MapEnv.step + obs crop + contract transfer for every env).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Protocol per measured mode: a fixed untimed pre-roll (PREROLL steps, so the steady state does not depend on --warmup),
+W untimed warm-up steps, then R >= 3 repeats of EXACTLY K steps, each bracketed by barrier + device synchronize on both
+sides and reduced with MAX over ranks; the report carries the median repeat.  Two modes are measured on the headline:
+  per_step  one launch per env-step and env slice (`--streams` slices on separate HIP streams) — what an RL sampler that
+            needs the observation before choosing the next action can use; this is `value`;
+  fused     ce_rollout_fused: T consecutive steps per launch with the env state resident on chip, every step's outputs
+            written to its plane of a trajectory ring (pre-supplied actions: contract search, random-policy rollouts).
+Prints ONE JSON line on rank 0 (DESIGN.md §5 explains every field).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,30 +31,52 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ENVS_PER_GPU = 16384
-N_AGENTS = 8
+from contracts_amd import parallel  # noqa: E402  (no GPU / torch import at module level)
+
 SEED0 = 73907  # the reference's seed multiplier (runner.py:130)
-# algorithmic bytes per env-step, cleanup n=8 (state read+written once, uint8 obs)
-ALGO_BYTES_PER_ENV_STEP = 7235
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PREROLL = 300
+# algorithmic bytes per env-step (state read + written once, uint8 obs); feature kinds: list stamps +
+# agents + accumulators once, int16 feature rows, rewards, infos (same accounting)
+WORKLOADS = {
+    "C4": dict(kind="cleanup", n=8, E=16384, contract="cleanup", algo=7235,
+               name="cleanup_new 8 agents + CleanupContract, 16384 envs/GPU, horizon 1000, auto-reset"),
+    "C2": dict(kind="cleanup", n=4, E=4096, contract="cleanup", algo=4211,
+               name="cleanup_new 4 agents + CleanupContract, 4096 envs"),
+    "C3": dict(kind="harvest", n=8, E=16384, contract="harvest_local", algo=7313,
+               name="harvest_new 8 agents + HarvestFeaturemodLocalContract, 16384 envs"),
+    "C5": dict(kind="selfdrive", n=4, E=32768, contract="selfdrive_distprop", algo=863,
+               name="selfdrive 4 agents + SelfdriveContractDistprop, 32768 envs (float64 path)"),
+    "C1": dict(kind="harvest_features", n=2, E=16384, contract="harvest_local", algo=887,
+               name="harvest (HarvestFeatures) 2 agents + HarvestFeaturemodLocalContract, batched to 16384 envs"),
+}
+DTYPE = {"cleanup": "u8", "harvest": "u8", "harvest_features": "u8", "cleanup_features": "u8", "selfdrive": "f64"}
+FUSED_KINDS = ("cleanup", "harvest")  # kinds ce_rollout_fused is built for
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--agents", type=int, default=N_AGENTS)
-    ap.add_argument("--kind", default="cleanup", choices=["cleanup", "harvest"])
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--kind", default=None, choices=["cleanup", "harvest", "selfdrive", "harvest_features", "cleanup_features"])
     ap.add_argument("--streams", type=int, default=3,
-                    help="split each rank's env batch into this many contiguous slices stepped on separate HIP streams "
-                         "(slices are independent; one slice's kernel tail overlaps the next slice's head)")
+                    help="env slices per rank, each stepped on its own HIP stream (slices are independent; one slice's "
+                         "kernel tail overlaps the next slice's head)")
+    ap.add_argument("--fused-steps", type=int, default=16, help="steps per launch of the fused mode (0 = skip it)")
+    ap.add_argument("--repeats", type=int, default=3, help="minimum number of timed K-step repeats (median reported)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="keep repeating until this much timed wall time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (C1, C2, C3, C5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle on the host cores, same envs / seeds / actions as the GPU run's first envs
+# ------------------------------------------------------------------------------------------------------------------
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -76,43 +102,44 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(kind, n, contract, target_s):
-    """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this
-    box's host cores with OpenMP over envs: a bounded sample of the same workload, at all threads (the
-    reported value) and at one thread."""
+def cpu_baseline(wl, target_s):
+    """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this box's host cores
+    with OpenMP over envs.  Like for like with the GPU run: the first `256 x threads` envs of the same batch (global
+    indices 0.., seeds SEED0 + b), the same counter-hash actions (contracts_amd.synth mirrors the device generator), the
+    same horizon / auto-reset, from t = 0; all threads (the reported value) and one thread."""
     import ctypes
+    from contracts_amd import synth
     from oracle.pyoracle import Oracle
+    kind, n, contract = wl["kind"], wl["n"], wl["contract"]
     threads = _usable_cores()
     gomp = ctypes.CDLL("libgomp.so.1")
-    rs = np.random.RandomState(1)
-    na = 8 if kind == "cleanup" else 7
+    na = {"cleanup": 8, "harvest": 7}[kind]
+    CH = 32
 
     def run(nthreads, E, seconds):
         gomp.omp_set_num_threads(nthreads)
         orc = Oracle(kind, E, n, contract=contract, horizon=1000, auto_reset=True)
         orc.seed(seed0=SEED0)
         orc.reset()
-        acts = rs.randint(na, size=(32, E, n)).astype(np.uint8)
-        for t in range(8):
-            orc.step(acts[t % 32])
-        steps, t0 = 0, time.perf_counter()
-        while True:
-            for _ in range(8):
-                orc.step(acts[steps % 32])
-                steps += 1
-            dt = time.perf_counter() - t0
-            if dt >= seconds:
-                break
+        steps, spent = 0, 0.0
+        while spent < seconds:
+            acts = synth.synth_actions_u8(SEED0 + 1, 0, E, n, steps, CH, na)  # generated outside the timed span
+            t0 = time.perf_counter()
+            for t in range(CH):
+                orc.step(acts[t])
+            spent += time.perf_counter() - t0
+            steps += CH
         orc.close()
-        return E * n * steps / dt, steps, dt
+        return E * n * steps / spent, steps, spent
 
     v_all, steps, dt = run(threads, 256 * threads, target_s)
     v_one, steps1, dt1 = run(1, 256, min(4.0, target_s))
     return {"value": v_all, "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "single_thread_value": v_one, "cpu_model": _cpu_model(),
             "python_reference_per_core": 4259,  # BASELINE.md: the reference itself, measured by the survey
-            "sample": "%d envs x %d steps, %s n=%d + contract, auto-reset, OpenMP over envs, %.1f s (+ %d envs x %d steps on "
-                      "1 thread, %.1f s)" % (256 * threads, steps, kind, n, dt, 256, steps1, dt1)}
+            "sample": "envs 0..%d of the same batch (seeds %d + b, the same counter-hash actions, horizon 1000, auto-reset), "
+                      "steps 0..%d, %s n=%d + contract, OpenMP over envs on %d threads, %.1f s of stepping (+ envs 0..255 x %d "
+                      "steps on 1 thread, %.1f s)" % (256 * threads - 1, SEED0, steps - 1, kind, n, threads, dt, steps1, dt1)}
 
 
 def stream_ceiling():
@@ -138,139 +165,219 @@ def stream_ceiling():
     return out
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(a.gpus, 1):
-        if rank == 0 and world == 1 and a.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
-            sys.exit(2)
+# ------------------------------------------------------------------------------------------------------------------
+# one workload, one mode
+# ------------------------------------------------------------------------------------------------------------------
+class Runner:
+    """one engine handle of this rank + its resident action planes; measures one mode at a time"""
+
+    def __init__(self, group, wl, E, K, W, streams, device_index):
+        import torch
+        from contracts_amd.engine import BatchedEnv
+        self.torch, self.group, self.wl, self.E, self.K, self.W = torch, group, wl, E, K, W
+        kind, n = wl["kind"], wl["n"]
+        base, _ = group.shard(E)  # rank g owns global envs [g*E, (g+1)*E); seeds / actions are keyed by the global index
+        self.env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
+                              env_index_base=base)
+        self.env.seed(seed0=SEED0)
+        self.env.reset()
+        dt = torch.float32 if kind == "selfdrive" else torch.uint8
+        self.esz = 4 if kind == "selfdrive" else 1
+        self.plane = E * n * self.esz
+        # all action planes resident in HBM before any timing: pre-roll, warm-up, then K planes reused by every repeat
+        # (each repeat continues from the state the previous one left, so no two repeats replay the same trajectory)
+        self.acts = torch.empty((PREROLL + W + K, E, n), dtype=dt, device="cuda")
+        self.env.synth_actions(SEED0 + 1, 0, PREROLL + W + K, self.acts.data_ptr())
+        self.env.synchronize()
+        S = max(1, min(streams, E))
+        self.S = S
+        self.streams = [torch.cuda.Stream() for _ in range(S)] if S > 1 else [torch.cuda.current_stream()]
+        self.handles = [st.cuda_stream for st in self.streams] if S > 1 else None
+        self.traj = None
+        self.env.rollout_device(self.acts.data_ptr(), PREROLL, self.handles)
+        torch.cuda.synchronize()
+
+    def _issue(self, mode, first_plane, count, T):
+        ptr = self.acts.data_ptr() + first_plane * self.plane
+        if mode == "fused":
+            self.env.rollout_fused(ptr, count, T, self.traj, self.handles)
+        else:
+            self.env.rollout_device(ptr, count, self.handles)  # the launch loop itself runs in C (ce_rollout)
+
+    def _fence(self):
+        self.torch.cuda.synchronize()
+        self.group.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, mode, T=0, min_repeats=3, min_seconds=1.0, max_repeats=25):
+        torch, K, W, E, n = self.torch, self.K, self.W, self.E, self.wl["n"]
+        if mode == "fused" and self.traj is None:
+            self.traj = self.env.alloc_trajectory(max(1, min(T, K)))  # every per-step output kept, ring of T planes
+        if W:
+            self._issue(mode, PREROLL, W, T)
+        elapsed, ev_ms = [], []
+        while len(elapsed) < min_repeats or (sum(elapsed) < min_seconds and len(elapsed) < max_repeats):
+            self._fence()
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in self.streams]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in self.streams]
+            for e0, st in zip(ev0, self.streams):
+                e0.record(st)
+            t0 = time.perf_counter()
+            self._issue(mode, PREROLL + W, K, T)
+            for e1, st in zip(ev1, self.streams):
+                e1.record(st)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self._fence()
+            elapsed.append(self.group.max(t1 - t0))  # MAX over ranks
+            ev_ms.append(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)))
+        self.env.check_faults()
+        med = statistics.median(elapsed)
+        units = self.group.world * E * n * K
+        launches_per_step = self.S if mode == "per_step" else self.S / float(T)
+        res = {"mode": mode, "value": units / med, "value_min": units / max(elapsed), "value_max": units / min(elapsed),
+               "repeats": len(elapsed), "ms_per_step": med / K * 1e3, "timed_seconds": sum(elapsed),
+               # HIP events on the launch streams (slowest stream per repeat, median repeat): the device-side time of
+               # the same K steps, without the host's launch / synchronize overhead
+               "event_ms_per_step": statistics.median(ev_ms) / K, "streams": self.S, "launches_per_step": launches_per_step}
+        if mode == "fused":
+            res["steps_per_launch"] = T
+            res["trajectory_planes"] = self.traj.P
+        return res
+
+    def roofline(self, res, kernel, traffic_key):
+        """algorithmic bytes of one step of this rank's batch over the wall time of a step"""
+        E, algo = self.E, self.wl["algo"]
+        ms = res["ms_per_step"]
+        achieved = algo * E / (ms * 1e-3) / 1e9
+        envs_per_launch = E / float(self.S)
+        steps_per_launch = res.get("steps_per_launch", 1)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            row = tj.get(traffic_key)
+            if row and row.get("kind") == self.wl["kind"] and row.get("agents") == self.wl["n"]:
+                traffic = int(round(row["hbm_bytes_per_env_step"] * envs_per_launch * steps_per_launch))
+        except (OSError, ValueError):
+            traffic = None
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": kernel,
+                "algorithmic_bytes_per_env_step": algo,
+                "algorithmic_bytes_per_launch": int(round(algo * envs_per_launch * steps_per_launch)),
+                "envs_per_launch": envs_per_launch, "steps_per_launch": steps_per_launch,
+                "launch_ms": ms * steps_per_launch,  # S launches run concurrently and finish one step of the batch per ms_per_step
+                "event_ms_per_step": res["event_ms_per_step"]}
+
+    def sanity(self):
+        if self.wl["kind"] in ("cleanup", "harvest"):
+            mi = self.env.download("int_metrics")
+            return {"apples_eaten_running_episode_mean": float(mi[:, 0].mean()), "dirt_cleaned_mean": float(mi[:, 2].mean()),
+                    "timestep_mean": float(self.env.download("timestep").mean())}
+        return {}
+
+    def close(self):
+        self.traj = None
+        self.env.close()
+        del self.acts
+
+
+KERNEL = {"cleanup": ("k_grid_step<cleanup>", "k_grid_rollout<cleanup>"), "harvest": ("k_grid_step<harvest>", "k_grid_rollout<harvest>"),
+          "selfdrive": ("k_sd_step", None), "harvest_features": ("k_feat_step<harvest>", None),
+          "cleanup_features": ("k_feat_step<cleanup>", None)}
+
+
+def run_rank(a):
     import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    rank, local_rank, world = parallel.rank_info()
+    if world != max(a.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, world))
     # functional-test knobs (tests/test_bench_multirank_gpu.py): several ranks on ONE GPU with a gloo rendezvous —
-    # exercises the sharding / reduction / reporting path where only a single-GPU box is available; never for numbers
+    # exercises the launch / shard / reduction / report path where only a single-GPU box is available; never for numbers
     backend = os.environ.get("CONTRACTS_BENCH_BACKEND", "nccl")
     if os.environ.get("CONTRACTS_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+    group = parallel.Group(backend, "cuda:%d" % local_rank)
 
-    from contracts_amd.engine import BatchedEnv
-    kind, n, E = a.kind, a.agents, a.envs_per_gpu
-    contract = "cleanup" if kind == "cleanup" else "harvest_local"
-    env = BatchedEnv(kind, E, n, contract=contract, horizon=1000, auto_reset=True, device=local_rank,
-                     env_index_base=rank * E)
-    env.seed(seed0=SEED0)  # env b (global index) is seeded SEED0 + b: results independent of GPU count
-    env.reset()
+    wl = dict(WORKLOADS["C4"])
+    custom = bool(a.kind or a.agents)
+    if custom:  # a hand-picked workload: its algorithmic bytes are only known when it coincides with a BASELINE config
+        kind = a.kind or wl["kind"]
+        n = a.agents or next((w["n"] for w in WORKLOADS.values() if w["kind"] == kind), wl["n"])
+        match = next((w for w in WORKLOADS.values() if (w["kind"], w["n"]) == (kind, n)), None)
+        contract = {"cleanup": "cleanup", "harvest": "harvest_local", "selfdrive": "selfdrive_distprop",
+                    "harvest_features": "harvest_local", "cleanup_features": "cleanup"}[kind]
+        wl = dict(match) if match else dict(kind=kind, n=n, E=wl["E"], contract=contract, algo=None,
+                                            name="%s %d agents + contract (custom)" % (kind, n))
+    E = a.envs_per_gpu or wl["E"]
     K, W = a.steps, a.warmup
-    # synthetic inputs: all K+W action planes resident in HBM before timing
-    acts = torch.empty((W + K, E, n), dtype=torch.uint8, device="cuda")
-    env.synth_actions(SEED0 + 1, 0, W + K, acts.data_ptr())
-    env.synchronize()
-    plane = E * n
-    base = acts.data_ptr()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    S = max(1, a.streams)
-    bounds = [E * i // S for i in range(S + 1)]
-    slices = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(S)]
-    if S == 1:
-        streams = [None]
-        handles = [None]
-    else:
-        streams = [torch.cuda.Stream() for _ in range(S)]
-        handles = [st.cuda_stream for st in streams]
-
-    def run_steps(t_begin, count):
-        # one launch per (step, slice); the loop itself runs in C (ce_rollout) to keep the host off the path
-        env.rollout_device(base + t_begin * plane, count, None if S == 1 else handles)
-
-    run_steps(0, W)
-    barrier()
-    # per-launch kernel time: HIP events on the stream(s) the kernels are launched on
-    if S == 1:
-        env.timing_begin()
-    else:
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-        for e0, st in zip(ev0, streams):
-            e0.record(st)
-    t0 = time.perf_counter()
-    run_steps(W, K)
-    if S > 1:
-        for e1, st in zip(ev1, streams):
-            e1.record(st)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if S == 1:
-        kernel_ms, launches = env.timing_end()
-    else:
-        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in zip(ev0, ev1)])) / K
-        launches = K * S
-    barrier()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    env.check_faults()
-    # sanity statistics of the simulated workload (not timed)
-    mi = env.download("int_metrics")
-    stats = {"apples_eaten_running_episode_mean": float(mi[:, 0].mean()), "dirt_cleaned_mean": float(mi[:, 2].mean())}
-
+    r = Runner(group, wl, E, K, W, a.streams, local_rank)
+    head = r.measure("per_step", min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=1000)
+    fused = None
+    if a.fused_steps and wl["kind"] in FUSED_KINDS:
+        fused = r.measure("fused", T=a.fused_steps, min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=1000)
+    stats = r.sanity()
+    out = None
     if rank == 0:
-        total_agent_steps = world * E * n * K
-        value = total_agent_steps / elapsed
-        # one launch covers E/S envs; S launches (one per stream) run concurrently
-        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * E // S if (kind == "cleanup" and n == 8) else None
-        roof = None
-        if algo_bytes_launch:
-            achieved = S * algo_bytes_launch / (kernel_ms * 1e-3) / 1e9  # S concurrent launches share the chip
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))  # PMC bytes per env-step (traffic is linear in the envs of a launch)
-                    if tj.get("agents") == n and tj.get("kind") == kind:
-                        traffic = int(round(tj["hbm_bytes_per_env_step"] * (E // S)))
-                except Exception:
-                    traffic = None
+        kstep, kfused = KERNEL[wl["kind"]]
+        roof = r.roofline(head, kstep, "per_step") if wl["algo"] else None
+        if roof is not None:
             ceil = stream_ceiling()
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "measured_copy_GBs": ceil["copy"], "measured_fill_GBs": ceil["fill"],
-                    "kernel": "k_grid_step<%s>" % kind, "kernel_ms": kernel_ms, "launches": launches,
-                    "algorithmic_bytes_per_launch": algo_bytes_launch, "concurrent_streams": S}
+            roof["measured_copy_GBs"], roof["measured_fill_GBs"] = ceil["copy"], ceil["fill"]
         out = {
-            "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "cleanup_new 8 agents + CleanupContract, %d envs/GPU, horizon 1000, auto-reset" % E
-                       if kind == "cleanup" else "harvest_new %d agents + HarvestFeaturemodLocalContract, %d envs/GPU" % (n, E),
-                       "envs_per_gpu": E, "envs_per_launch": E // S, "agents": n, "global_envs": world * E, "rng": "mt19937-numpy-compat",
-                       "parallelism": "env-shard x%d, no collectives" % world, "streams_per_gpu": S, "sanity": stats},
+            "metric": "agent-steps/sec", "value": head["value"], "unit": "agent-steps/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE[wl["kind"]], "data": "synthetic",
+            "repeats": head["repeats"], "value_min": head["value_min"], "value_max": head["value_max"],
+            "config": {"workload": wl["name"], "mode": "per_step: one launch per env-step and env slice", "envs_per_gpu": E,
+                       "envs_per_launch": E // r.S, "agents": wl["n"], "global_envs": world * E, "rng": "mt19937-numpy-compat",
+                       "parallelism": "env-shard x%d, no collectives" % world, "streams_per_gpu": r.S,
+                       "preroll_steps": PREROLL, "timed_seconds": head["timed_seconds"], "sanity": stats},
             "roofline": roof,
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kind, n, contract, a.cpu_seconds)
-        print(json.dumps(out))
-    env.close()
-    if world > 1:
-        dist.destroy_process_group()
+        if fused is not None:
+            fr = r.roofline(fused, kfused, "fused") if wl["algo"] else None
+            out["fused"] = dict(fused, roofline=fr, note="ce_rollout_fused: %d steps per launch, env state resident on chip, every "
+                                "step's obs / rewards / infos / features / done written to a %d-plane trajectory ring; results "
+                                "bit-identical to per_step (tests/test_fused_rollout_gpu.py)" % (fused["steps_per_launch"], fused["trajectory_planes"]))
+    r.close()
+
+    # the other BASELINE configs, same protocol with a shorter timed region (single-GPU workloads: rank 0's GPU only
+    # would idle the others, so every rank runs its shard of them too and the line reports the whole-job value)
+    if not a.no_configs and not custom:
+        rows = []
+        for key in ("C2", "C3", "C5", "C1"):
+            w = WORKLOADS[key]
+            rr = Runner(group, w, w["E"], min(K, 300), min(W, 20), a.streams, local_rank)
+            m = rr.measure("per_step", min_repeats=3, min_seconds=0.2, max_repeats=5)
+            row = {"config": key, "workload": w["name"], "dtype": DTYPE[w["kind"]], "envs_per_gpu": w["E"], "agents": w["n"],
+                   "value": m["value"], "unit": "agent-steps/s", "ms_per_step": m["ms_per_step"], "repeats": m["repeats"],
+                   "steps": rr.K, "roofline": rr.roofline(m, KERNEL[w["kind"]][0], "per_step_" + key)}
+            if a.fused_steps and w["kind"] in FUSED_KINDS:
+                f = rr.measure("fused", T=a.fused_steps, min_repeats=3, min_seconds=0.2, max_repeats=5)
+                row["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps_per_launch": f["steps_per_launch"],
+                                "roofline_frac": rr.roofline(f, KERNEL[w["kind"]][1], "fused_" + key)["frac"]}
+            rows.append(row)
+            rr.close()
+        if out is not None:
+            out["configs"] = rows
+    if out is not None:
+        if not a.no_cpu_baseline and world == 1 and wl["kind"] in ("cleanup", "harvest"):
+            out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    group.close()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and not parallel.launched_by_torchrun():
+        # `python bench.py --gpus N` by itself: N fresh rank processes on this node, one per GPU, started before this
+        # process has touched the GPU (no exec over a HIP context); rank 0 prints the line
+        sys.exit(parallel.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    run_rank(a)
 
 
 if __name__ == "__main__":

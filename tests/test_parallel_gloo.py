@@ -1,60 +1,67 @@
-"""CPU, world_size 2 over gloo: the multi-GPU layout of the hot path (plain shard of the env axis, seeds
-keyed by the GLOBAL env index, no data-path collective; MAX over ranks for the timing).  The CPU oracle
-stands in for the engine so the test runs without GPUs: two ranks stepping their shards must reproduce
-exactly what one rank stepping the whole batch produces."""
-import hashlib
+"""CPU, world_size 2 over gloo: the multi-GPU layout of the hot path (plain shard of the env axis, seeds and synthetic
+actions keyed by the GLOBAL env index, no data-path collective; MAX over ranks for the timing) through the code that
+bench.py runs — contracts_amd.parallel's launcher (spawn_local_ranks), rank bootstrap (Group), shard arithmetic and
+reductions.  The CPU oracle stands in for the engine here; tests/test_bench_multirank_gpu.py runs the same rank script
+with the HIP engine, and bench.py --gpus 2 itself, on the GPU box."""
+import json
 import os
-import socket
+import sys
 
-import numpy as np
-import torch.distributed as dist
-import torch.multiprocessing as mp
+import pytest
 
-from contracts_amd.parallel import env_shard, max_over_ranks, sum_over_ranks
+from contracts_amd import parallel
 
-
-def _rollout(kind, n, base, count, steps):
-    from oracle.pyoracle import Oracle
-    orc = Oracle(kind, count, n, contract="cleanup", horizon=30, auto_reset=True, env_index_base=base)
-    orc.seed(seed0=73907)  # env b gets 73907 + env_index_base + b
-    orc.reset()
-    digests = []
-    for t in range(steps):
-        # actions keyed by (global env index, t, agent) exactly like the engine's counter hash would be
-        g = np.arange(base, base + count)[:, None]
-        a = ((g * 31 + t * 17 + np.arange(n)[None, :] * 7) % 8).astype(np.uint8)
-        orc.step(a)
-    for e in range(count):
-        digests.append(hashlib.sha256(orc.grid[e].tobytes() + orc.obs[e].tobytes() + orc.reward[e].tobytes()).hexdigest())
-    return digests
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, per_rank, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    base, count = env_shard(rank, world, per_rank)
-    d = _rollout("cleanup", 4, base, count, 45)
-    elapsed = 1.0 + rank  # rank 1 is "slower"
-    mx = max_over_ranks(elapsed)
-    tot = sum_over_ranks(count)
-    dist.barrier()
-    out[rank] = (base, d, mx, tot)
-    dist.destroy_process_group()
+def _run(tmp_path, world, per_rank, engine=False):
+    sys.path.insert(0, HERE)
+    import _shard_rank
+    out = str(tmp_path / "shard")
+    argv = ["--out", out, "--per-rank", str(per_rank)] + (["--engine"] if engine else [])
+    rc = parallel.spawn_local_ranks(os.path.join(HERE, "_shard_rank.py"), argv, world, timeout=600)
+    assert rc == 0
+    got = [None] * (world * per_rank)
+    for r in range(world):
+        res = json.load(open("%s.%d" % (out, r)))
+        assert res["world"] == world and res["max"] == float(world) and res["sum"] == world * per_rank
+        assert res["base"] == r * per_rank
+        got[res["base"]:res["base"] + per_rank] = res["digests"]
+    whole = _shard_rank.rollout(engine, "cleanup", 4, 0, world * per_rank, 45)
+    assert got == whole  # N ranks stepping their shards == one rank stepping the whole batch, env for env
 
 
-def test_two_rank_shard_equals_single_rank():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    per_rank = 6
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, per_rank, out), nprocs=2, join=True)
-    whole = _rollout("cleanup", 4, 0, 2 * per_rank, 45)
-    got = [None] * (2 * per_rank)
-    for rank in (0, 1):
-        base, d, mx, tot = out[rank]
-        assert mx == 2.0 and tot == 2 * per_rank
-        got[base:base + per_rank] = d
-    assert got == whole
+def test_two_rank_shard_equals_single_rank(tmp_path):
+    _run(tmp_path, 2, 6)
+
+
+@pytest.mark.gpu
+def test_two_rank_shard_equals_single_rank_engine(tmp_path):
+    """the same, with both ranks stepping the HIP engine (they share GPU 0; gloo rendezvous)"""
+    _run(tmp_path, 2, 70, engine=True)
+
+
+def test_shard_arithmetic():
+    assert parallel.env_shard(3, 8, 16384) == (49152, 16384)
+    with pytest.raises(ValueError):
+        parallel.env_shard(8, 8, 4)
+    assert parallel.split_envs(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert parallel.slice_bounds(16384, 3) == [(0, 5461), (5461, 5461), (10922, 5462)]
+    assert sum(c for _, c in parallel.slice_bounds(1000, 7)) == 1000
+
+
+def test_bench_self_launch_starts_ranks_before_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` without torchrun: the parent only parses and spawns (no torch / HIP in it); on this
+    GPU-less box the rank processes then refuse loudly — the engine has no CPU path — and the parent reports failure"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CONTRACTS_BENCH_BACKEND="gloo")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert p.stderr.count("needs an MI355X") == 2  # both ranks were started and both refused
