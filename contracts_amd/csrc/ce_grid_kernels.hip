@@ -2029,6 +2029,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     if (!FUSED) store_grid(E, p);  // a fused rollout keeps the map in LDS and packs it once, after its last step
     write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
+  const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   double transfers_total = 0.0;
   if (p.contract != CE_CONTRACT_NONE) {
@@ -2088,6 +2089,20 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       }
     }
   }
+  double b_sr = 0.0, b_str = 0.0;
+  if (p.flags & CE_FLAG_INEQUITY_AVERSE) {
+    // float env rewards: the reference appends / sums the floats themselves (cleanup_new.py:227-234): raw_rewards = 0;
+    // raw_rewards += r[k] in agent order; metrics['raw_env_rewards'] += raw_rewards; total_reward_dict[k].append(r[k])
+    double raw = 0.0;
+    for (u32 b = 0; b < n; ++b) raw += shfl_f64(rew_env, b);
+    if (lane == 0) mf[CE_MF_RAW_ENV_REWARDS_F(n)] += raw;
+    if (E.is_agent) {
+      b_sr = GAT(mf, CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_R, lane)) + rew_env;
+      b_str = GAT(mf, CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_TR, lane)) + (double)(t - 1) * rew_env;
+      GAT(mf, CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_R, lane)) = b_sr;
+      GAT(mf, CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_TR, lane)) = b_str;
+    }
+  }
   if (p.contract != CE_CONTRACT_NONE) {
     if (transfers_total != 0.0 && lane == 0) mf[CE_MF_TRANSFERS] += transfers_total;
     const bool any_rew = ballot(E.is_agent && rew != 0.0) != 0;  // adding +-0.0 leaves the (never -0.0) sums unchanged
@@ -2121,13 +2136,11 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       total += ri;
     }
     const double ts = total == 0 ? 0.001 : (double)total;
-    const double equality = 1.0 - (double)eq / ((double)(2 * n) * ts);
+    double equality = 1.0 - (double)eq / ((double)(2 * n) * ts);
     const long long den = sr < 1 ? 1 : sr;
-    const double sust = np_sum_lanes((double)str_ / (double)den, n) / (double)n;
-    double teq = 0.0, tsust = 0.0;
-    if (p.contract != CE_CONTRACT_NONE) {
-      const double fr = E.is_agent ? f_sr : 0.0;
-      const double ftr = E.is_agent ? f_str : 0.0;
+    double sust = np_sum_lanes((double)str_ / (double)den, n) / (double)n;
+    // the same two formulas on float per-agent sums (held in lanes 0..n-1), in the reference's accumulation order
+    auto eq_sust_f64 = [&](double fr, double ftr, double& eq_out, double& sust_out) {
       double e2 = 0.0, tot = 0.0;
       for (u32 i = 0; i < n; ++i) {
         const double ri = shfl_f64(fr, i);
@@ -2135,10 +2148,13 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
         tot += ri;
       }
       if (tot == 0.0) tot = 0.001;
-      teq = 1.0 - e2 / ((double)(2 * n) * tot);
+      eq_out = 1.0 - e2 / ((double)(2 * n) * tot);
       const double dn = fr > 1.0 ? fr : 1.0;
-      tsust = np_sum_lanes(ftr / dn, n) / (double)n;
-    }
+      sust_out = np_sum_lanes(ftr / dn, n) / (double)n;
+    };
+    if (p.flags & CE_FLAG_INEQUITY_AVERSE) eq_sust_f64(E.is_agent ? b_sr : 0.0, E.is_agent ? b_str : 0.0, equality, sust);
+    double teq = 0.0, tsust = 0.0;
+    if (p.contract != CE_CONTRACT_NONE) eq_sust_f64(E.is_agent ? f_sr : 0.0, E.is_agent ? f_str : 0.0, teq, tsust);
     if (lane == 0) {
       mf[CE_MF_EQUALITY] = equality;
       mf[CE_MF_SUSTAINABILITY] = sust;

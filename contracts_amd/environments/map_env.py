@@ -305,6 +305,11 @@ class GridEnvAdapter(_Base):
             avg_times.append(t_sum / denom)
         return np.mean(avg_times)
 
+    def _raw_env_rewards(self, mi, mf):
+        """metrics['raw_env_rewards']: an int, or — under inequity aversion, where the env's rewards are floats and the
+        reference sums those (cleanup_new.py:229-234) — the float accumulator CE_MF_RAW_ENV_REWARDS_F"""
+        return float(mf[5 + 2 * self.num_agents]) if self.inequity_averse_reward else int(mi[1])
+
     def _refresh_metrics(self, final):
         eng = self._engine
         mi = eng.download("final_int_metrics" if final else "int_metrics")[0]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_ABI_VERSION 1
+#define CE_ABI_VERSION 2
 
 /* error codes */
 #define CE_OK 0
@@ -194,8 +194,17 @@ typedef struct ce_buffers {
 #define CE_MF_GLOBALS 5
 #define CE_MFA_SUM_R 0   /* per agent: sum of transferred rewards  */
 #define CE_MFA_SUM_TR 1  /* per agent: sum of t * transferred reward */
-#define CE_MF_COUNT(n) (CE_MF_GLOBALS + 2 * (n))
 #define CE_MF_AGENT(n, which, i) (CE_MF_GLOBALS + (which) * (n) + (i))
+/* Float twins of the integer reward accumulators, maintained under CE_FLAG_INEQUITY_AVERSE only: there the env's own
+ * rewards are floats, and the reference appends / sums THOSE (cleanup_new.py:227-234, harvest_new.py:200-205,
+ * compute_equality / compute_sustainability cleanup_new.py:422-445), in step order.  With the flag set, equality and
+ * sustainability are computed from these and metrics['raw_env_rewards'] is CE_MF_RAW_ENV_REWARDS_F; the integer
+ * accumulators (CE_MI_RAW_ENV_REWARDS, CE_MIA_SUM_R / SUM_TR) keep summing the integer rewards before the aversion. */
+#define CE_MF_RAW_ENV_REWARDS_F(n) (CE_MF_GLOBALS + 2 * (n))
+#define CE_MFA_BASE_SUM_R 0   /* per agent: sum_t r_i,t of the env's (float) rewards  */
+#define CE_MFA_BASE_SUM_TR 1  /* per agent: sum_t t * r_i,t                           */
+#define CE_MF_BASE_AGENT(n, which, i) (CE_MF_GLOBALS + 2 * (n) + 1 + (which) * (n) + (i))
+#define CE_MF_COUNT(n) (CE_MF_GLOBALS + 4 * (n) + 1)
 
 /* selfdrive state block: pos[n], vel[n], dist_to_front[n], done[n] (0/1), done_all,
  * n_crossed, crossed[n] (agent indices in crossing order), transfers metric */

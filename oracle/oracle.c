@@ -22,7 +22,7 @@
  * restated here from the published algorithm.
  *
  * Parity pin: tests/test_oracle_golden.py checks this file, step by step, against the
- * fixtures under tests/golden/*.npz that were produced by running the reference itself
+ * fixtures under tests/golden/ (.npz) that were produced by running the reference itself
  * (tests/golden/make_golden.py).  The reference has no tests of its own for this path.
  *
  * Data layout mirrors include/contracts_engine.h (ce_buffers) with host pointers.
@@ -916,6 +916,24 @@ static void grid_reset(orc_t* o, int ei) {
   export_state(o, ei);
 }
 
+/* compute_equality / compute_sustainability (cleanup_new.py:422-445) on float per-agent sums */
+static void eq_sust_f64(int n, const double* sum_r, const double* sum_tr, double* equality, double* sustainability) {
+  double eq = 0, total = 0; /* python ints 0 promoted on first float add */
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) eq += fabs(sum_r[i] - sum_r[j]);
+    total += sum_r[i];
+  }
+  if (total == 0) total = 0.001;
+  *equality = 1 - eq / (2 * n * total);
+  double av[MAXN];
+  for (int i = 0; i < n; i++) {
+    double denom = sum_r[i];
+    if (!(denom > 1)) denom = 1; /* max(denom, 1) */
+    av[i] = sum_tr[i] / denom;
+  }
+  *sustainability = np_sum(av, n) / n;
+}
+
 static void finalize_episode_metrics(orc_t* o, int ei) {
   int n = o->n;
   int64_t* mi = o->b.int_metrics + (size_t)ei * CE_MI_COUNT(n);
@@ -938,23 +956,12 @@ static void finalize_episode_metrics(orc_t* o, int ei) {
     }
     mf[CE_MF_SUSTAINABILITY] = np_sum(av, n) / n;
   }
-  if (o->cfg.contract != CE_CONTRACT_NONE) {
-    /* two_stage_train.py:97-99 on the transferred (float) rewards */
-    double eq = 0, total = 0; /* python ints 0 promoted on first float add */
-    for (int i = 0; i < n; i++) {
-      for (int j = 0; j < n; j++) eq += fabs(mf[CE_MF_AGENT(n, CE_MFA_SUM_R, i)] - mf[CE_MF_AGENT(n, CE_MFA_SUM_R, j)]);
-      total += mf[CE_MF_AGENT(n, CE_MFA_SUM_R, i)];
-    }
-    if (total == 0) total = 0.001;
-    mf[CE_MF_TRANSFER_EQUALITY] = 1 - eq / (2 * n * total);
-    double av[MAXN];
-    for (int i = 0; i < n; i++) {
-      double denom = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, i)];
-      if (!(denom > 1)) denom = 1; /* max(denom, 1) */
-      av[i] = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, i)] / denom;
-    }
-    mf[CE_MF_TRANSFER_SUSTAINABILITY] = np_sum(av, n) / n;
-  }
+  if (o->cfg.flags & CE_FLAG_INEQUITY_AVERSE) /* float rewards: the same two formulas on the float sums */
+    eq_sust_f64(n, mf + CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_R, 0), mf + CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_TR, 0),
+                &mf[CE_MF_EQUALITY], &mf[CE_MF_SUSTAINABILITY]);
+  if (o->cfg.contract != CE_CONTRACT_NONE) /* two_stage_train.py:97-99 on the transferred (float) rewards */
+    eq_sust_f64(n, mf + CE_MF_AGENT(n, CE_MFA_SUM_R, 0), mf + CE_MF_AGENT(n, CE_MFA_SUM_TR, 0), &mf[CE_MF_TRANSFER_EQUALITY],
+                &mf[CE_MF_TRANSFER_SUSTAINABILITY]);
   memcpy(o->b.final_int_metrics + (size_t)ei * CE_MI_COUNT(n), mi, sizeof(int64_t) * CE_MI_COUNT(n));
   memcpy(o->b.final_f64_metrics + (size_t)ei * CE_MF_COUNT(n), mf, sizeof(double) * CE_MF_COUNT(n));
 }
@@ -1044,12 +1051,22 @@ static void grid_step(orc_t* o, int ei, const uint8_t* act) {
         mi[CE_MI_TOTAL_APPLES_EATEN] += 1;
       }
   }
-  /* total_reward_dict / raw_env_rewards.  (With float rewards the reference sums floats; the
-   * integer accumulators then hold the truncated base reward — only the default int path is pinned.) */
+  /* total_reward_dict / raw_env_rewards (cleanup_new.py:227-234, harvest_new.py:200-205): integer accumulators of the
+   * integer rewards; with float rewards (inequity aversion) the reference appends / sums the floats themselves, in
+   * step order — kept in the float twins CE_MF_RAW_ENV_REWARDS_F / CE_MF_BASE_AGENT */
   for (int a = 0; a < n; a++) {
     mi[CE_MI_AGENT(n, CE_MIA_SUM_R, a)] += rew_i[a];
     mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, a)] += (int64_t)(e->timesteps - 1) * rew_i[a];
     mi[CE_MI_RAW_ENV_REWARDS] += rew_i[a];
+  }
+  if (float_rewards) {
+    double raw = 0; /* raw_rewards = 0; for k, v in r.items(): raw_rewards += v */
+    for (int a = 0; a < n; a++) raw += rew_f[a];
+    mf[CE_MF_RAW_ENV_REWARDS_F(n)] += raw;
+    for (int a = 0; a < n; a++) {
+      mf[CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_R, a)] += rew_f[a];
+      mf[CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_TR, a)] += (double)(e->timesteps - 1) * rew_f[a];
+    }
   }
   write_features(o, e, ei, cleaned);
   int16_t* feat = o->b.features + (size_t)ei * n * o->b.num_features;
@@ -1564,7 +1581,7 @@ static void sd_reset(orc_t* o, int ei) {
   e->sd_ncross = 0;
   latch_zero_metrics(o, ei);
   sample_theta(o, e);
-  int active[MAXN];
+  int active[MAXN] = {0};
   for (int a = 0; a < n; a++) active[a] = 1;
   sd_write_obs(o, e, ei, active, e->sd_pos, 0.0);
   for (int a = 0; a < n; a++) {
@@ -1767,7 +1784,7 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
 /* ------------------------------------------------------------------------- */
 #define ALLOC(field, type, count)                                   \
   do {                                                              \
-    o->b.field = (type*)calloc((size_t)(count) ? (size_t)(count) : 1, sizeof(type)); \
+    o->b.field = (type*)calloc((size_t)(count) != 0 ? (size_t)(count) : 1, sizeof(type)); \
     if (!o->b.field) return CE_ENOMEM;                              \
   } while (0)
 

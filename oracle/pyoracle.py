@@ -64,7 +64,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
                 beam_trace=False):
     cfg = CeConfig()
-    cfg.abi_version = 1
+    cfg.abi_version = 2
     cfg.kind = KIND[kind]
     cfg.num_envs = num_envs
     cfg.num_agents = num_agents

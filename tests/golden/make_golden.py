@@ -248,6 +248,14 @@ def main():
                                           action_p=[.1, .1, .15, .1, .05, .1, .1, .3], extra_env_kwargs=dict(image_obs=False))
     jobs["g9_harvest_n4_features"] = dict(kind="harvest", n=4, seed=S0 + 34, T=200, store_obs_steps=0, contract=False,
                                           extra_env_kwargs=dict(image_obs=False))
+    # whole (short-horizon) episodes under inequity aversion: the float reward accumulators behind raw_env_rewards,
+    # equality and sustainability at the done step, and their transferred twins, across a reset
+    jobs["g9b_cleanup_n3_inequity_done"] = dict(kind="cleanup", n=3, seed=S0 + 35, T=[60, 45], episodes=2, firing=True,
+                                                contract=False, store_obs_steps=5,
+                                                extra_env_kwargs=dict(inequity_averse_reward=True, alpha=5.0, beta=0.05, horizon=60))
+    jobs["g9b_harvest_n4_inequity_contract_done"] = dict(kind="harvest", n=4, seed=S0 + 36, T=[80, 30], episodes=2,
+                                                         store_obs_steps=5,
+                                                         extra_env_kwargs=dict(inequity_averse_reward=True, alpha=0.5, beta=0.25, horizon=80))
     for s in range(6):  # short multi-seed traces (RNG / reset variety)
         jobs["g7_cleanup_n8_s%d" % s] = dict(kind="cleanup", n=8, seed=1000 + 17 * s, T=120, store_obs_steps=8,
                                              action_p=[.1, .1, .15, .1, .05, .1, .1, .3] if s % 2 else None)

@@ -35,9 +35,10 @@ METRIC_INT = {"total_apples_eaten": 0, "raw_env_rewards": 1, "dirt_cleaned": 2, 
 METRIC_F64 = {"transfers": 0, "equality": 1, "sustainability": 2, "transfer_equality": 3, "transfer_sustainability": 4}
 
 
-def metrics_dict(kind, n, mi, mf, final):
-    """reference-style env.metrics dict from the engine's metric arrays"""
-    out = {"total_apples_eaten": mi[0], "raw_env_rewards": mi[1], "transfers": mf[0]}
+def metrics_dict(kind, n, mi, mf, final, float_base=False):
+    """reference-style env.metrics dict from the engine's metric arrays (float_base: inequity aversion — the env's rewards
+    are floats and the reference sums those: CE_MF_RAW_ENV_REWARDS_F)"""
+    out = {"total_apples_eaten": mi[0], "raw_env_rewards": mf[5 + 2 * n] if float_base else mi[1], "transfers": mf[0]}
     if kind == "cleanup":
         out["dirt_cleaned"] = mi[2]
         for i in range(n):
@@ -124,12 +125,10 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
         final = "equality" in keys
         mi = get("final_int_metrics" if final else "int_metrics")[env]
         mf = get("final_f64_metrics" if final else "f64_metrics")[env]
-        md = metrics_dict(kind, n, mi, mf, final)
+        md = metrics_dict(kind, n, mi, mf, final, float_base)
         for k, v in zip(keys, vals):
             if k.startswith("transfer") and int(g["contract"]) == 0:
                 continue
-            if float_base and k in ("raw_env_rewards", "equality", "sustainability"):
-                continue  # float base rewards: integer accumulators diverge by design
             np.testing.assert_allclose(md[k], v, rtol=1e-12, atol=1e-9, err_msg="metric %s ep%d" % (k, ep))
         assert spawn_cells() == list(g["spawn_perm"][ep]), "spawn list after ep%d" % ep
 

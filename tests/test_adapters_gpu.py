@@ -19,7 +19,9 @@ def _mt_fp():
 
 
 @pytest.mark.parametrize("name,steps", [("g1_cleanup_n4", 1150), ("g3c_cleanup_n4_cleaner", 250), ("g2_harvest_n8", 300),
-                                        ("g4_cleanup_n8_fire", 120), ("g6_harvest_n1_nocontract", 100)])
+                                        ("g4_cleanup_n8_fire", 120), ("g6_harvest_n1_nocontract", 100),
+                                        ("g9b_cleanup_n3_inequity_done", 105),
+                                        ("g9b_harvest_n4_inequity_contract_done", 110)])
 def test_grid_adapter_trace(name, steps):
     from contracts_amd.contract import contract_list as cl
     from contracts_amd.environments.cleanup_new import CleanupEnv
@@ -30,7 +32,12 @@ def test_grid_adapter_trace(name, steps):
     np.random.seed(seed)
     random.seed(seed)
     cls = CleanupEnv if kind == "cleanup" else HarvestEnv
-    env = cls(num_agents=n, disable_firing=not bool(int(g["firing"])))
+    extra = {}
+    if int(g["inequity"]):  # float env rewards: raw_env_rewards / equality / sustainability come from float accumulators
+        extra = dict(inequity_averse_reward=True, alpha=float(g["alpha"]), beta=float(g["beta"]))
+    if int(g["horizon"]) != 1000:
+        extra["horizon"] = int(g["horizon"])
+    env = cls(num_agents=n, disable_firing=not bool(int(g["firing"])), **extra)
     assert _mt_fp() == tuple(int(x) for x in g["ctor_mt"])  # the constructor consumed the global stream
     contract = bool(int(g["contract"]))
     if contract:

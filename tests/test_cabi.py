@@ -26,7 +26,7 @@ def test_header_functions_exported():
     for name in names:
         assert hasattr(L, name), "library does not export %s" % name
         assert name in _lib.EXPORTS, "ctypes table misses %s" % name
-    assert L.ce_abi_version() == 1
+    assert L.ce_abi_version() == 2
 
 
 def test_struct_layout_matches_ctypes():
