@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcontracts_engine.so")
 SOURCES = ["ce_api.hip", "ce_grid_kernels.hip", "ce_selfdrive_kernels.hip"]
-HEADERS = ["ce_device.h", os.path.join("..", "..", "include", "contracts_engine.h")]
+HEADERS = ["ce_device.h", "ce_grid_probe.inc", os.path.join("..", "..", "include", "contracts_engine.h")]
 # -ffp-contract=off: float64 reward/transfer arithmetic must round exactly like the reference's
 # separate multiply and add; no fast-math anywhere.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
     stamps = os.environ.get("CE_PHASE_STAMPS") == "1"
     lib, flags, suffix = LIB, list(FLAGS), ""
     if stamps:  # diagnostic build: s_memtime stamps per phase, separate file, never benchmarked
-        flags.append("-DCE_PHASE_STAMPS")
+        flags += ["-DCE_DIAGNOSTIC", "-DCE_PHASE_STAMPS"]
         lib, suffix, force = LIB.replace(".so", "_stamps.so"), "_stamps", True
     variant = os.environ.get("CE_VARIANT")  # experiment builds: extra flags, separate file (CONTRACTS_AMD_LIB selects it)
     if variant:

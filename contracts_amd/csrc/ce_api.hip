@@ -712,8 +712,13 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
     uint8_t* tmp = nullptr;
     hipError_t e2 = hipMalloc((void**)&tmp, (size_t)env_count * f.env_bytes);
     if (e2 != hipSuccess) return fail(h, CE_ENOMEM, "grid image buffer", e2);
-    launch_grid_expand((int)h->cfg.kind, h->buf.grid, tmp, env_begin, env_count, nullptr);
+    // step kernels may still be in flight on non-blocking streams the null stream does not wait for: drain the
+    // device first, as every other field does, so the presence bits are read between steps and not inside one
     e2 = hipDeviceSynchronize();
+    if (e2 == hipSuccess) {
+      launch_grid_expand((int)h->cfg.kind, h->buf.grid, tmp, env_begin, env_count, nullptr);
+      e2 = hipDeviceSynchronize();
+    }
     if (e2 == hipSuccess) e2 = hipMemcpy(dst, tmp, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (e2 != hipSuccess) return fail(h, CE_ENODEV, "grid download", e2);
@@ -735,7 +740,8 @@ extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uin
     uint8_t* tmp = nullptr;
     hipError_t e2 = hipMalloc((void**)&tmp, (size_t)env_count * f.env_bytes);
     if (e2 != hipSuccess) return fail(h, CE_ENOMEM, "grid image buffer", e2);
-    e2 = hipMemcpy(tmp, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
+    e2 = hipDeviceSynchronize();  // no step kernel may still be writing the bits this upload replaces
+    if (e2 == hipSuccess) e2 = hipMemcpy(tmp, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
     if (e2 == hipSuccess) {
       launch_grid_pack((int)h->cfg.kind, tmp, h->buf.grid, h->buf.error_flags, env_begin, env_count, nullptr);
       e2 = hipDeviceSynchronize();

@@ -27,6 +27,25 @@
 // which is what lets the access take the SGPR-base + VGPR-offset form (a 64-bit scaled index does not).
 #define GAT(base, idx) (*(decltype(base))((CE_GPTR(char))(base) + (u32)((u32)(idx) * (u32)sizeof(*(base)))))
 
+// Diagnostic builds (phase stamps, truncated kernels, ablations, issue probes: the scripts under tools/) compile with
+// -DCE_DIAGNOSTIC and take their instrumentation from ce_grid_probe.inc; the shipped build has none of it.
+#ifdef CE_DIAGNOSTIC
+#include "ce_grid_probe.inc"
+#else
+#define CE_STAMP(k) ((void)0)
+#define CE_SUBSTAMP(k) ((void)0)
+#define CE_REALSTAMP(k) ((void)0)
+#define CE_PROBE_POINT(T_, P_, LANE_, N_) ((void)0)
+#define CE_TRUNCATE_SPAWN_RETURN() ((void)0)
+namespace ce {
+namespace diag {
+constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = false, ablate_obsstore = false,
+               ablate_gridstore = false, ablate_rngstore = false, seq_shuffle = false, serial_apply = false,
+               serial_small_shuffle = false;
+}
+}  // namespace ce
+#endif
+
 namespace ce {
 
 typedef uint32_t u32;
@@ -85,69 +104,6 @@ DEVINL u32 wave_min_u32(u32 v) {
 #undef CE_DPP_MIN
   return rdl(v, 63);
 }
-
-// Diagnostic builds (-DCE_PHASE_STAMPS) record s_memtime at phase boundaries of the step kernel
-// into GridParams.debug; in the shipped build CE_STAMP expands to nothing.
-#ifdef CE_PHASE_STAMPS
-#define CE_STAMP(k)                                                                    \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
-  } while (0)
-#define CE_REALSTAMP(k)                                                                \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                    \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (lane == 0 && p.debug) p.debug[(size_t)E.e * 16 + (k)] = t_;                    \
-  } while (0)
-#define CE_SUBSTAMP(k)                                                                 \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (lane == 0 && E.dbg) E.dbg[(k)] = t_;                                           \
-  } while (0)
-#elif defined(CE_TRUNCATE)
-// Profiling builds (-DCE_TRUNCATE=k, tools/valu_profile.py): the step kernel ends at phase boundary k, so the
-// instruction counters of consecutive builds difference into per-phase counts.  Never shipped.
-// (everything the remaining phases would consume is folded into one store, so that nothing before the cut is dead)
-#define CE_TRUNC_SINK()                                                                                         \
-  do {                                                                                                          \
-    const u32 sink_ = E.P ^ E.O ^ (u32)E.RW ^ E.SP ^ E.WP0 ^ E.WP1 ^ E.rng.pos ^ E.rng.cache ^                  \
-                      ((const u32*)E.L->pmap)[E.lane] ^ ((const u32*)E.L->pmap)[E.lane + 248] ^ E.L->mt[E.lane]; \
-    E.dbg[E.lane & 15] = sink_;                                                                                 \
-  } while (0)
-#define CE_STAMP(k)               \
-  do {                            \
-    if (CE_TRUNCATE == (k)) {     \
-      CE_TRUNC_SINK();            \
-      return;                     \
-    }                             \
-  } while (0)
-#define CE_SUBSTAMP(k)            \
-  do {                            \
-    if (CE_TRUNCATE == (k)) {     \
-      CE_TRUNC_SINK();            \
-      return;                     \
-    }                             \
-  } while (0)
-#define CE_REALSTAMP(k) \
-  do {                  \
-  } while (0)
-#else
-#define CE_STAMP(k) \
-  do {              \
-  } while (0)
-#define CE_SUBSTAMP(k) \
-  do {                 \
-  } while (0)
-#define CE_REALSTAMP(k) \
-  do {                  \
-  } while (0)
-#endif
 
 // ----------------------------------------------------------------------------------------
 // MT19937 in LDS (numpy legacy RandomState stream)
@@ -447,15 +403,13 @@ template <int MODE> DEVINL void shuffle_small(Rng& r, u32& L0, u32 len, u32 lane
   rng_assert_uniform(r);
   u32 i = rfl(len) - 1;
   u32 l0 = L0;
-#ifndef CE_SERIAL_SMALL_SHUFFLE
-  if (i <= 7u) {
+  if (!diag::serial_small_shuffle && i <= 7u) {
     i = shuffle_le8<MODE>(r, l0, i + 1, lane);
     if (i == 0) {
       L0 = l0;
       return;
     }
   }
-#endif
   u32 off = r.pos - r.cbase;
   if (off >= r.ccount) {
     rng_refill(r, lane);
@@ -512,10 +466,7 @@ DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
 // each, so they take the one-draw-per-ballot walk instead (3 VALU per draw), collecting J[i] in lane i.
 // Returns with r advanced past every consumed word.
 DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
-#ifndef CE_VEC_MIN
-#define CE_VEC_MIN 8
-#endif
-  constexpr u32 kVecMin = CE_VEC_MIN;
+  constexpr u32 kVecMin = 8;
   rng_assert_uniform(r);
   u32 i0 = len - 1;
   while (i0 >= kVecMin) {
@@ -1292,11 +1243,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   u32 waste_cell = 0;
   bool waste_found = false;
   if (KIND == CE_KIND_CLEANUP) {
-#ifdef CE_ABLATE_SHUFFLE
-    if (false) {
-#else
-    if (waste_on) {
-#endif
+    if (waste_on && !diag::ablate_shuffle) {
       // The walk over the shuffled list stops at the first candidate whose double is < 0.5: t* is the first
       // candidate index with a clear tempered sign bit, independent of the permutation.
       u32 tstar = 0xffffffffu;
@@ -1305,22 +1252,19 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
         const u64 sb = ballot(needw[r] && (__builtin_popcount(ww[r] & 0x89010000u) & 1) == 0);
         if (tstar == 0xffffffffu && sb) tstar = ctz64(sb) + 64 * r;
       }
-#ifdef CE_SEQ_SHUFFLE
-      shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
-#else
-      // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
-      // spills into S)
-      E.waste_perm_dirty = true;
-      shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
-      CE_SUBSTAMP(10);
-#ifdef CE_SERIAL_APPLY
-      shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
-#else
-      static_assert(offsetof(WaveLds<KIND>, S) == offsetof(WaveLds<KIND>, U) + sizeof(E.L->U), "S must follow U");
-      static_assert(KIND != CE_KIND_CLEANUP || sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
-      shuffle_apply_par(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
-#endif
-#endif
+      if (diag::seq_shuffle) {
+        shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+      } else {
+        // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
+        // spills into S)
+        E.waste_perm_dirty = true;
+        shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
+        CE_SUBSTAMP(10);
+        static_assert(offsetof(WaveLds<KIND>, S) == offsetof(WaveLds<KIND>, U) + sizeof(E.L->U), "S must follow U");
+        static_assert(KIND != CE_KIND_CLEANUP || sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
+        if (diag::serial_apply) shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+        else shuffle_apply_par(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+      }
       CE_SUBSTAMP(13);
       if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
         // both halves of the list at once; the static cell of list entry w sits in lane w (mod 64) of E.WS — a lane
@@ -1435,13 +1379,13 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
   };
   auto put_unit = [&](u32 a, const u32x3& dv) {
     const u32 doff = voff + __umul24(a, (u32)kObsAgentStride);  // 32-bit offset from the wave-uniform env base
-#ifdef CE_ABLATE_OBSSTORE  // traffic experiment: the pixels are computed but not written
-    asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
-#else
+    if (diag::ablate_obsstore) {  // traffic experiment: the pixels are computed but not written
+      asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
+      return;
+    }
     // streaming (nontemporal) store: the observation is write-once output and the bulk of the step's bytes; keeping it
     // out of L2 / Infinity Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536)
     if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_env + doff));
-#endif
   };
   // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
   // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
@@ -1777,7 +1721,7 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
-#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
+#ifdef CE_INSTRUMENTED
   E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
 #else
   E.dbg = nullptr;
@@ -1838,9 +1782,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   double theta = 0.0;
   u32 t = 0, fault = 0;
   reset_env(E, p, theta, t, fault);
-#ifndef CE_ABLATE_GRIDSTORE
-  store_grid(E, p);
-#endif
+  if (!diag::ablate_gridstore) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, true);
   store_rng(E, p);
@@ -1901,34 +1843,9 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   // ---------------- MapEnv.step ----------------
   t += 1;
   if (p.flags & CE_FLAG_BEAM_TRACE) clear_beam_map(E, p);  // self.beam_pos = [] (map_env.py:231)
-#if defined(CE_PROBE_VALU) || defined(CE_PROBE_SALU) || defined(CE_PROBE_SMEM) || defined(CE_PROBE_LDS)  // issue / latency probes (tools/issue_probe.sh)
-  {
-#ifdef CE_PROBE_SMEM  // 16 serialised scalar-load round trips from the parameter block
-    u32 pm_ = 0;
-    asm volatile(".rept 16\n s_load_dword %0, %1, 0xb4\n s_waitcnt lgkmcnt(0)\n .endr" : "=s"(pm_) : "s"(&p) : "memory");
-    if (pm_ == 0xdeadbeefu) t += 1;
-#endif
-#ifdef CE_PROBE_LDS  // 16 serialised LDS read round trips
-    u32 pl_ = lane * 4;
-    asm volatile(".rept 16\n ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 0xfc, %0\n .endr" : "+v"(pl_) : : "memory");
-    if (pl_ == 0xdeadbeefu) t += 1;
-#endif
-#ifdef CE_PROBE_VALU
-    u32 pv = lane;
-    asm volatile(".rept 128\n v_mov_b32 %0, %0\n .endr" : "+v"(pv));
-    if (pv == 0xdeadbeefu) t += 1;
-#endif
-#ifdef CE_PROBE_SALU
-    u32 ps = E.n;
-    asm volatile(".rept 128\n s_mov_b32 %0, %0\n .endr" : "+s"(ps));
-    if (ps == 0xdeadbeefu) t += 1;
-#endif
-  }
-#endif
+  CE_PROBE_POINT(t, &p, lane, n);
   CE_STAMP(1);
-#ifndef CE_ABLATE_MOVES
-  update_moves(E, ACT);
-#endif
+  if (!diag::ablate_moves) update_moves(E, ACT);
   CE_STAMP(2);
   if (!E.is_agent) E.P = 0xffffu;
 
@@ -1988,9 +1905,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   }
   CE_STAMP(3);
   custom_map_update(E);
-#ifdef CE_TRUNCATE
-  if (CE_TRUNCATE >= 10 && CE_TRUNCATE <= 13) return;
-#endif
+  CE_TRUNCATE_SPAWN_RETURN();
   CE_STAMP(4);
 
   // ---------------- rewards ----------------
@@ -2015,11 +1930,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 
   CE_STAMP(5);
   // ---------------- feature obs, infos, metrics ----------------
-#ifndef CE_ABLATE_FEATURES
-  const u32 feat8 = compute_features(E, p, out.features(), cleaned);
-#else
-  const u32 feat8 = 0;
-#endif
+  const u32 feat8 = diag::ablate_features ? 0u : compute_features(E, p, out.features(), cleaned);
   // The observation (the bulk of the step's stores) goes out as early as the map allows, so that its stores drain
   // under the epilogue's arithmetic instead of at the wave's very end.  It paints the agents over the map bytes,
   // hence after the feature pass and after the map state is packed; a done step with auto-reset writes the reset
@@ -2183,9 +2094,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   if (!obs_early) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, did_reset, E.waste_perm_dirty);
-#ifndef CE_ABLATE_RNGSTORE
-  store_rng(E, p);
-#endif
+  if (!diag::ablate_rngstore) store_rng(E, p);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
     out.done()[E.e] = done ? 1 : 0;
@@ -2203,7 +2112,6 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
-#ifndef CE_NO_PRELOAD
   // Entry latency: left to itself the compiler fetches each kernel argument and each parameter-block field with its own
   // scalar load right before the first use, behind the branches of the range check — five to six serialised ≈ 270-cycle
   // round trips before the first state load is even issued.  Two batched fetches instead: the 32-byte kernarg segment,
@@ -2229,7 +2137,7 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   CE_HEAD_PTR(timestep, 5);
   CE_HEAD_PTR(theta, 6);
 #undef CE_HEAD_PTR
-#if defined(CE_PHASE_STAMPS) || defined(CE_TRUNCATE)
+#ifdef CE_INSTRUMENTED
   ph.debug = p.debug;  // diagnostic builds stamp through E.dbg
 #else
   ph.debug = nullptr;
@@ -2238,11 +2146,6 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   ph.n = sb[1];
   const auto acts = (CE_GPTR(const uint8_t))((u64)ka[2] | ((u64)ka[3] << 32));
   if (!env_begin(E, ph, lds, ka[6], ka[7])) return;
-#else
-  const GridParams& ph = p;
-  const auto acts = (CE_GPTR(const uint8_t))call_actions;
-  if (!env_begin(E, p, lds, env_first, env_end)) return;
-#endif
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
 

@@ -161,17 +161,28 @@ class BatchedEnv:
     def seed(self, seeds=None, seed0=0, mask=None, replay_constructor=True):
         """np.random.seed(s) (+ random.seed(s)) then construct the env (see ce_seed)."""
         s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        m = self._mask(mask)
+        if s is not None and s.size != self.E:  # ce_seed reads E entries from the raw pointer
+            raise ValueError("seeds must hold one entry per env (%d), got %d" % (self.E, s.size))
         check(self._L.ce_seed(self._h, None if s is None else s.ctypes.data, int(seed0),
                               None if m is None else m.ctypes.data, 3 if replay_constructor else 1), self._h, "ce_seed")
 
+    def _mask(self, mask):
+        """host env mask for the C-ABI (which reads exactly E bytes from the pointer)"""
+        if mask is None:
+            return None
+        m = np.ascontiguousarray(mask, np.uint8)
+        if m.size != self.E:
+            raise ValueError("mask must hold one entry per env (%d), got %d" % (self.E, m.size))
+        return m
+
     def construct(self, mask=None):
         """replay the constructor's RNG use on the CURRENT generator state (no re-seed)"""
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        m = self._mask(mask)
         check(self._L.ce_seed(self._h, None, 0, None if m is None else m.ctypes.data, 2), self._h, "ce_seed")
 
     def reset(self, mask=None, stream=None):
-        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        m = self._mask(mask)
         check(self._L.ce_reset(self._h, None if m is None else m.ctypes.data, stream), self._h, "ce_reset")
 
     def step(self, actions, active=None, stream=None):
@@ -310,9 +321,12 @@ class BatchedEnv:
         mine = [_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon]
         if meta[:3] != mine[:3]:
             raise ValueError("checkpoint is for kind/E/n %s, engine has %s" % (meta[:3], mine[:3]))
-        for f, arr in state.items():
-            if f != "_meta":
-                self.upload(f, arr)
+        if meta[3:] != mine[3:]:  # stepping on would silently not be bit-identical to the run that was saved
+            raise ValueError("checkpoint was taken with contract/flags/horizon %s, engine has %s" % (meta[3:], mine[3:]))
+        # error_flags first: the validated grid upload may raise CE_FAULT_BAD_GRID, which must survive the restore
+        for f in sorted((f for f in state if f != "_meta"), key=lambda f: f != "error_flags"):
+            self.upload(f, state[f])
+        self.check_faults()
 
     def save(self, path):
         np.savez_compressed(path, **self.state_dict())

@@ -36,6 +36,8 @@ class SelfAcceleratingCarEnv(_Base):
             c, lo, hi, null_prob = self._contract
             if c is not None:
                 self._engine.set_contract(c, lo, hi, null_prob)
+            if getattr(self, "_external_theta", False):  # a negotiate / combined / solver stage owns theta (set before pickling)
+                self._engine.set_flags(external_theta=True)
             pending = getattr(self, "_pending_state", None)
             if pending:
                 for f, arr in pending.items():
@@ -47,7 +49,8 @@ class SelfAcceleratingCarEnv(_Base):
         d = dict(self.__dict__)
         eng = d.pop("_engine", None)
         if eng is not None:
-            d["_pending_state"] = {f: eng.download(f, raw=True) for f in ("sd_state", "rng", "theta", "f64_metrics")}
+            d["_pending_state"] = {f: eng.download(f, raw=True) for f in ("sd_state", "rng", "theta", "f64_metrics", "int_metrics",
+                                                                          "done", "done_agents", "error_flags")}
         d["_engine"] = None
         return d
 

@@ -8,9 +8,23 @@ try:  # pragma: no cover - gym is absent in the build image
 except Exception:
 
     class _Space:
+        """like gym 0.21's Space, sampling draws from a PRIVATE generator (np_random, seedable with .seed()): a
+        .sample() must not advance the process-global np.random stream the env itself consumes"""
+
         def __init__(self, shape=None, dtype=None):
             self.shape = None if shape is None else tuple(shape)
             self.dtype = None if dtype is None else np.dtype(dtype)
+            self._np_random = None
+
+        @property
+        def np_random(self):
+            if self._np_random is None:
+                self.seed()
+            return self._np_random
+
+        def seed(self, seed=None):
+            self._np_random = np.random.RandomState(seed)
+            return [seed]
 
     class Box(_Space):
         """gym 0.21 semantics: default dtype float32, bounds broadcast to `shape` and cast to dtype"""
@@ -25,7 +39,7 @@ except Exception:
             super().__init__(shape, dtype)
 
         def sample(self):
-            return np.random.uniform(self.low, self.high).astype(self.dtype)
+            return self.np_random.uniform(self.low, self.high).astype(self.dtype)
 
         def contains(self, x):
             x = np.asarray(x)
@@ -37,7 +51,7 @@ except Exception:
             super().__init__((), np.int64)
 
         def sample(self):
-            return int(np.random.randint(self.n))
+            return int(self.np_random.randint(self.n))
 
         def contains(self, x):
             return 0 <= int(x) < self.n

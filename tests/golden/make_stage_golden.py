@@ -102,6 +102,7 @@ def run_solver(R, n, seed, horizon, episodes, rule, samples, steps):
     con = R.contract_list.CleanupContract(n)
     env = tst.NegotiationSolver(base, con, n, horizon, {"n_act": 8, "seed": seed + 7}, "stub-env", "stub-path", True, False,
                                 contract_samples=samples, decision_rule=rule)
+    env.contract_param_space.seed(seed + 11)  # gym spaces sample from their own np_random: seeded, or not reproducible
     keys = ["a%d" % i for i in range(n)]
     ars = np.random.RandomState(seed + 1)
     rec = {k: [] for k in ("actions", "obs_sha", "contract_obs", "rew", "done", "fp", "chosen", "reset_sha", "reset_contract")}

@@ -28,9 +28,22 @@ def reference_available():
 # are broadcast to `shape` and cast to dtype).
 # --------------------------------------------------------------------------- #
 class _Space:
+    """gym 0.21: sample() draws from the space's own np_random (seedable with .seed()), not from the global stream"""
+
     def __init__(self, shape=None, dtype=None):
         self.shape = None if shape is None else tuple(shape)
         self.dtype = None if dtype is None else np.dtype(dtype)
+        self._np_random = None
+
+    @property
+    def np_random(self):
+        if self._np_random is None:
+            self.seed()
+        return self._np_random
+
+    def seed(self, seed=None):
+        self._np_random = np.random.RandomState(seed)
+        return [seed]
 
 
 class Box(_Space):
@@ -44,7 +57,7 @@ class Box(_Space):
         super().__init__(shape, dtype)
 
     def sample(self):
-        return np.random.uniform(self.low, self.high).astype(self.dtype)
+        return self.np_random.uniform(self.low, self.high).astype(self.dtype)
 
 
 class Discrete(_Space):
@@ -53,7 +66,7 @@ class Discrete(_Space):
         super().__init__((), np.int64)
 
     def sample(self):
-        return int(np.random.randint(self.n))
+        return int(self.np_random.randint(self.n))
 
 
 class MultiDiscrete(_Space):

@@ -33,7 +33,7 @@ def test_grid_adapter_trace(name, steps):
     random.seed(seed)
     cls = CleanupEnv if kind == "cleanup" else HarvestEnv
     extra = {}
-    if int(g["inequity"]):  # float env rewards: raw_env_rewards / equality / sustainability come from float accumulators
+    if "inequity" in g and int(g["inequity"]):  # float env rewards: raw_env_rewards / equality / sustainability come from float accumulators
         extra = dict(inequity_averse_reward=True, alpha=float(g["alpha"]), beta=float(g["beta"]))
     if int(g["horizon"]) != 1000:
         extra["horizon"] = int(g["horizon"])
@@ -326,6 +326,7 @@ def test_negotiation_solver_trace(name):
     env = NegotiationSolver(base, contract_list.CleanupContract(n), n, horizon, {"n_act": 8, "seed": seed + 7}, "stub-env",
                             "stub-path", True, False, contract_samples=int(g["samples"]), decision_rule=str(g["rule"]),
                             trainer_factory=StubPPOTrainer)
+    env.contract_param_space.seed(seed + 11)  # as the fixture's generator did (a gym space samples from its own np_random)
     keys = ["a%d" % i for i in range(n)]
     t = 0
     for ep in range(len(g["chosen"])):

@@ -68,3 +68,39 @@ def test_config_expansion_matches_runner_semantics():
     assert jobs[0]["seed"] == 73907 and jobs[1]["seed"] == 2 * 73907
     assert jobs[0]["experiment_name"] == "cleanup_new-2agents"
     assert cfg[2].get("num_workers") is None  # the input list is not mutated
+
+
+def test_space_sampling_leaves_the_global_stream_alone():
+    """gym 0.21 spaces draw from a private np_random; the stand-ins must too — the adapters hand the process-global
+    np.random state to the engine, so a .sample() on it would shift the env's own trajectory"""
+    from contracts_amd import spaces
+    if spaces.Box.__module__.startswith("gym"):
+        pytest.skip("real gym present")
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy(), np.random.get_state()[2]
+    b, d = spaces.Box(0.0, 0.2, shape=(1,)), spaces.Discrete(8)
+    b.seed(3)
+    d.seed(3)
+    x = [b.sample() for _ in range(4)] + [d.sample() for _ in range(4)]
+    after = np.random.get_state()
+    assert np.array_equal(before[0], after[1]) and before[1] == after[2]
+    b.seed(3)
+    assert np.array_equal(b.sample(), x[0]) and b.sample().dtype == np.float32
+
+
+def test_synth_action_mirror_matches_the_library():
+    """contracts_amd.synth (numpy) == ce_synth_action_host / ce_synth_hash_host (the device generator's host twin)"""
+    from contracts_amd import _lib, synth
+    L = _lib.load()
+    a = synth.synth_actions_u8(73908, 16380, 6, 8, 997, 5, 8)
+    for t in range(5):
+        for e in range(6):
+            for g in range(8):
+                assert a[t, e, g] == L.ce_synth_action_host(73908, 16380 + e, 997 + t, g, 8)
+    f = synth.synth_actions_f32(9, 0, 3, 4, 0, 2)
+    for t in range(2):
+        for e in range(3):
+            for g in range(4):
+                bits = L.ce_synth_hash_host(9, e, t, g) >> 40
+                want = np.float32(np.float32(bits) * np.float32(1.0 / 16777216.0)) * np.float32(0.2) - np.float32(0.1)
+                assert f[t, e, g] == want and f.dtype == np.float32
