@@ -48,13 +48,13 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P), ("beam_map", _P),
+        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P),
     ]
 
 
 class CeTraj(C.Structure):
     _fields_ = [("num_planes", C.c_uint32), ("first_plane", C.c_uint32), ("obs", _P), ("obs_f64", _P), ("base_reward", _P),
-                ("reward", _P), ("done", _P), ("done_agents", _P), ("info", _P), ("features", _P)]
+                ("reward", _P), ("done", _P), ("done_agents", _P), ("info", _P), ("features", _P), ("sd_info", _P)]
 
 
 EXPORTS = {

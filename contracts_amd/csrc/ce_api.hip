@@ -268,6 +268,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     A(sd_state, E * CE_SD_STATE_DOUBLES(n));
     A(obs_f64, E * n * (2 * n + 7));
     A(done_agents, E * n);
+    A(sd_info, E * 2);
   }
   A(timestep, E);
   A(theta, E);
@@ -394,6 +395,7 @@ static SdParams sd_params(ce_engine* h) {
   p.done = b.done;
   p.done_agents = b.done_agents;
   p.info = b.info;
+  p.sd_info = b.sd_info;
   p.f64_metrics = b.f64_metrics;
   p.final_f64_metrics = b.final_f64_metrics;
   p.int_metrics = b.int_metrics;
@@ -572,6 +574,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
   CE_TRAJ(done_agents, E * n);
   CE_TRAJ(info, E * n * 2);
   CE_TRAJ(features, E * n * b.num_features);
+  CE_TRAJ(sd_info, E * 2);
 #undef CE_TRAJ
   if (traj && traj->base_reward) {
     ra.base_reward = traj->base_reward;
@@ -596,6 +599,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       ra.env_end = (uint32_t)(E * (sl + 1) / num_slices);
       void* stream = streams ? streams[sl] : nullptr;
       if (is_grid(h->cfg)) launch_grid_rollout((int)h->cfg.kind, h->d_gparams, ra, stream);
+      else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);
       else return fail(h, CE_EINVAL, "ce_rollout_fused: not built for this env family yet");
       if (h->timing_armed) h->timed_launches++;
     }
@@ -691,6 +695,7 @@ static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
       {"final_f64_metrics", b.final_f64_metrics, (size_t)b.num_f64_metrics * 8},
       {"error_flags", b.error_flags, 4},
       {"beam_map", b.beam_map, (size_t)b.grid_h * b.grid_w},
+      {"sd_info", b.sd_info, 16},
       {"debug", h->d_debug, 128},
   };
   for (const FieldDesc& f : fields)

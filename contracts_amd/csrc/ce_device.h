@@ -115,7 +115,9 @@ struct RolloutArgs {
   CE_GPTR(uint8_t) done_agents;  // selfdrive
   CE_GPTR(uint8_t) info;
   CE_GPTR(int16_t) features;
-  uint64_t action_plane, obs_plane, obs_f64_plane, agent_plane, reward_plane, done_plane, done_agents_plane, info_plane, features_plane;
+  CE_GPTR(double) sd_info;      // selfdrive
+  uint64_t action_plane, obs_plane, obs_f64_plane, agent_plane, reward_plane, done_plane, done_agents_plane, info_plane, features_plane,
+      sd_info_plane;
   uint32_t num_steps, num_planes, plane0;
   uint32_t env_first, env_end;
 };
@@ -130,6 +132,7 @@ struct SdParams {
   CE_GPTR(uint8_t) done;
   CE_GPTR(uint8_t) done_agents;
   CE_GPTR(uint8_t) info;
+  CE_GPTR(double) sd_info;
   CE_GPTR(double) f64_metrics;
   CE_GPTR(double) final_f64_metrics;
   CE_GPTR(int64_t) int_metrics;
@@ -161,6 +164,7 @@ void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, 
 void launch_sd_construct(const SdParams& p, void* stream);
 void launch_sd_reset(const SdParams& p, void* stream);
 void launch_sd_step(const SdParams& p, void* stream);
+void launch_sd_rollout(const SdParams& p, const RolloutArgs& ra, void* stream);
 void launch_synth_actions_u8(uint8_t* out, uint64_t key, uint64_t env_base, uint32_t E, uint32_t n, uint32_t t0,
                              uint32_t T, uint32_t num_actions, void* stream);
 void launch_synth_actions_f32(float* out, uint64_t key, uint64_t env_base, uint32_t E, uint32_t n, uint32_t t0,

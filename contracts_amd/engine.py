@@ -27,7 +27,7 @@ _FIELD_DTYPES = {
     "base_reward": np.int32, "reward": np.float64, "done": np.uint8, "done_agents": np.uint8, "info": np.uint8,
     "features": np.int16, "int_metrics": np.int64, "f64_metrics": np.float64, "final_int_metrics": np.int64,
     "final_f64_metrics": np.float64, "error_flags": np.uint32, "debug": np.uint64,
-    "beam_map": np.uint8,
+    "beam_map": np.uint8, "sd_info": np.float64,
 }
 
 
@@ -77,7 +77,8 @@ class Trajectory:
         b, E, n, P = env.b, env.E, env.n, int(num_planes)
         dev = "cuda:%d" % env.cfg.device
         if env.kind == "selfdrive":
-            shapes = {"obs_f64": ((E, n, 2 * n + 7), torch.float64), "done_agents": ((E, n), torch.uint8)}
+            shapes = {"obs_f64": ((E, n, 2 * n + 7), torch.float64), "done_agents": ((E, n), torch.uint8),
+                      "sd_info": ((E, 2), torch.float64)}
         elif env.kind in _lib.FEAT_KINDS:
             shapes = {"features": ((E, n, b.num_features), torch.int16)}
         else:
@@ -254,7 +255,7 @@ class BatchedEnv:
             "done_agents": (n,), "info": (n, 2), "features": (n, b.num_features), "int_metrics": (b.num_int_metrics,),
             "f64_metrics": (b.num_f64_metrics,), "final_int_metrics": (b.num_int_metrics,),
             "final_f64_metrics": (b.num_f64_metrics,), "error_flags": (), "debug": (16,),
-            "beam_map": (b.grid_h, b.grid_w),
+            "beam_map": (b.grid_h, b.grid_w), "sd_info": (2,),
         }[field]
 
     def download(self, field, env_begin=0, env_count=None, raw=False):
@@ -372,6 +373,7 @@ class BatchedEnv:
         else:
             out["obs_f64"] = _DevArray(b.obs_f64, (E, n, 2 * n + 7), np.float64, None, self)
             out["done_agents"] = _DevArray(b.done_agents, (E, n), np.uint8, None, self)
+            out["sd_info"] = _DevArray(b.sd_info, (E, 2), np.float64, None, self)
         out["reward"] = _DevArray(b.reward, (E, n), np.float64, None, self)
         out["done"] = _DevArray(b.done, (E,), np.uint8, None, self)
         out["info"] = _DevArray(b.info, (E, n, 2), np.uint8, None, self)

@@ -119,15 +119,24 @@ class SelfAcceleratingCarEnv(_Base):
         return d
 
     def _infos(self, keys):
+        """the reference's infos dict (:183-189, update_infos :127-149): ambulance stats and is_crashed ride on the first
+        key of the action dict, every other key carries zeros there"""
         info = self._engine.download("info")[0]
-        return {k: {"just_passed": bool(info[int(k[1:]), 0]), "is_crashed": int(info[int(k[1:]), 1]) if k == keys[0] else 0}
-                for k in keys}
+        rank, dtf = (float(x) for x in self._engine.download("sd_info")[0])
+        out = {}
+        for k in keys:
+            first = k == keys[0]
+            out[k] = {"just_passed": bool(info[int(k[1:]), 0]), "is_crashed": int(info[int(k[1:]), 1]) if first else 0,
+                      "ambulance_rank": (int(rank) if first else 0.0), "ambulance_dist_to_front": (dtf if first else 0.0)}
+        return out
 
     def step(self, acts):
         keys = list(acts.keys())
         self._step_engine(acts)
         base = self._engine.download("base_reward")[0]  # -1 / -100 (ambulance) / -10000 (crash), before any contract
         r = {k: float(base[int(k[1:])]) for k in keys}
+        if int(self._engine.download("info")[0][int(keys[0][1:]), 1]):  # crash: every car is penalised, acting or not (:211)
+            r = {k: -10000.0 for k in self._keys}
         self.metrics = {"transfers": float(self._engine.download("f64_metrics")[0][0])}
         return self._base_obs(keys), r, self._dones(), self._infos(keys)
 

@@ -158,6 +158,10 @@ typedef struct ce_buffers {
   uint8_t* beam_map;     /* grid kinds: [E][grid_h][grid_w] CE_BEAM_* of the last step's beams (a later beam of the
                             shuffled firing order overwrites an earlier one, as the reference's beam_pos list does);
                             written only under CE_FLAG_BEAM_TRACE, zeroed by a reset                        */
+  double* sd_info;       /* selfdrive: [E][2] per-step infos the reference attaches to the FIRST acting key of the step
+                            (…accelerate.py:183-189, update_infos :127-149, crash branch :203-204): {ambulance_rank,
+                            ambulance_dist_to_front}; every other key carries 0.0 there.  Together with `info`
+                            ({just_passed, is_crashed}) this is the whole infos dict of a selfdrive step               */
 } ce_buffers;
 
 #define CE_BEAM_NONE 0
@@ -295,6 +299,7 @@ typedef struct ce_traj {
   uint8_t* done_agents;  /* selfdrive                                                                          */
   uint8_t* info;
   int16_t* features;     /* grid / feature kinds                                                               */
+  double* sd_info;       /* selfdrive                                                                          */
 } ce_traj;
 
 /* Fused multi-step rollout for pre-supplied actions: ONE launch per `steps_per_launch` consecutive env-steps.  Each
@@ -328,7 +333,7 @@ int ce_synchronize(ce_handle h, void* stream);
 /* Host copies (stream-synchronous helpers for tests / adapters without torch).
  * field names: "grid","agents","spawn_perm","waste_perm","rng","timestep","theta","sd_state",
  * "obs","obs_f64","base_reward","reward","done","done_agents","info","features",
- * "int_metrics","f64_metrics","final_int_metrics","final_f64_metrics","error_flags".
+ * "int_metrics","f64_metrics","final_int_metrics","final_f64_metrics","error_flags","beam_map","sd_info".
  * env_begin/env_count select a slice of the env axis; dst/src are host pointers. */
 int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
 int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);

@@ -1591,6 +1591,7 @@ static void sd_reset(orc_t* o, int ei) {
     o->b.info[((size_t)ei * n + a) * 2 + 1] = 0;
     o->b.done_agents[(size_t)ei * n + a] = 0;
   }
+  o->b.sd_info[(size_t)ei * 2] = o->b.sd_info[(size_t)ei * 2 + 1] = 0;
   o->b.done[ei] = 0;
   export_state(o, ei);
 }
@@ -1625,6 +1626,11 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
       new_pos[k] = e->sd_vel[k] + e->sd_pos[k];
     }
   int just_passed[MAXN] = {0};
+  /* infos of the first acting key (:183-189): the ambulance's rank in the merge order so far (n while it has not
+   * crossed) and its recorded distance to the car in front (high - low while nothing was recorded) */
+  double amb_rank = n, amb_dtf = e->sd_dtf[0] > -1 ? e->sd_dtf[0] : high - o->cfg.low_bound;
+  for (int i = 0; i < e->sd_ncross; i++)
+    if (e->sd_cross[i] == 0) amb_rank = i + 1;
   /* update_rel_rank :110-125 — sort key is the id's 2nd character => agent index order */
   for (int k = 0; k < n; k++)
     if (active[k] && e->sd_pos[k] < 0.0 && new_pos[k] > 0.0) e->sd_cross[e->sd_ncross++] = k;
@@ -1644,6 +1650,11 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
           }
         }
       e->sd_dtf[n - 1] = dtf; /* :144 writes index n-1 (loop variable leak) */
+      if (k == 0) {             /* :146-149 ambulance stats, on the first acting key (a0 itself: it is acting) */
+        for (int i = 0; i < e->sd_ncross; i++)
+          if (e->sd_cross[i] == 0) amb_rank = i + 1;
+        amb_dtf = dtf;
+      }
     }
   int crashed = 0;
   if (o->cfg.flags & CE_FLAG_COLLISION_ON) { /* check_if_crashed :81-90 */
@@ -1656,6 +1667,7 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
   }
   double rews[MAXN];
   if (crashed) { /* :196-215 */
+    amb_rank = n; /* :203 ambulance rank is set to the lowest value when crashed */
     e->sd_done_all = 1;
     for (int k = 0; k < n; k++)
       if (active[k]) e->sd_done[k] = 1;
@@ -1756,6 +1768,8 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
     o->b.done_agents[(size_t)ei * n + k] = (uint8_t)e->sd_done[k];
   }
   (void)base;
+  o->b.sd_info[(size_t)ei * 2] = amb_rank;
+  o->b.sd_info[(size_t)ei * 2 + 1] = amb_dtf;
   o->b.done[ei] = (uint8_t)e->sd_done_all;
   if (e->sd_done_all) {
     memcpy(o->b.final_int_metrics + (size_t)ei * CE_MI_COUNT(n), o->b.int_metrics + (size_t)ei * CE_MI_COUNT(n),
@@ -1763,13 +1777,18 @@ static void sd_step(orc_t* o, int ei, const float* act32, const uint8_t* active_
     memcpy(o->b.final_f64_metrics + (size_t)ei * CE_MF_COUNT(n), mf, sizeof(double) * CE_MF_COUNT(n));
     if (o->cfg.flags & CE_FLAG_AUTO_RESET) {
       /* keep terminal reward/info/done, publish the reset observation */
-      double rr[MAXN];
+      double rr[MAXN], si[2] = {o->b.sd_info[(size_t)ei * 2], o->b.sd_info[(size_t)ei * 2 + 1]};
+      int32_t br[MAXN];
       uint8_t inf[MAXN * 2], da[MAXN];
+      memcpy(br, o->b.base_reward + (size_t)ei * n, sizeof(int32_t) * n);
       memcpy(rr, o->b.reward + (size_t)ei * n, sizeof(double) * n);
       memcpy(inf, o->b.info + (size_t)ei * n * 2, 2 * n);
       memcpy(da, o->b.done_agents + (size_t)ei * n, n);
       sd_reset(o, ei);
+      memcpy(o->b.base_reward + (size_t)ei * n, br, sizeof(int32_t) * n);
       memcpy(o->b.reward + (size_t)ei * n, rr, sizeof(double) * n);
+      o->b.sd_info[(size_t)ei * 2] = si[0];
+      o->b.sd_info[(size_t)ei * 2 + 1] = si[1];
       memcpy(o->b.info + (size_t)ei * n * 2, inf, 2 * n);
       memcpy(o->b.done_agents + (size_t)ei * n, da, n);
       o->b.done[ei] = 1;
@@ -1844,6 +1863,7 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     ALLOC(sd_state, double, E * CE_SD_STATE_DOUBLES(n));
     ALLOC(obs_f64, double, E * n * (2 * n + 7));
     ALLOC(done_agents, uint8_t, E * n);
+    ALLOC(sd_info, double, E * 2);
   }
   ALLOC(timestep, int32_t, E);
   ALLOC(theta, double, E);
@@ -1865,7 +1885,7 @@ int orc_destroy(orc_t* o) {
   void* ptrs[] = {o->b.grid, o->b.agents, o->b.spawn_perm, o->b.waste_perm, o->b.rng, o->b.timestep, o->b.theta,
                   o->b.sd_state, o->b.obs, o->b.obs_f64, o->b.base_reward, o->b.reward, o->b.done, o->b.done_agents,
                   o->b.info, o->b.features, o->b.int_metrics, o->b.f64_metrics, o->b.final_int_metrics,
-                  o->b.final_f64_metrics, o->b.error_flags, o->b.beam_map};
+                  o->b.final_f64_metrics, o->b.error_flags, o->b.beam_map, o->b.sd_info};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(ptrs[i]);
   free(o->envs);
   free(o);

@@ -46,7 +46,7 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P), ("beam_map", _P),
+        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P),
     ]
 
 
@@ -159,6 +159,7 @@ def buffer_views(b, kind):
         v["sd_state"] = _view(b.sd_state, np.float64, (E, 5 * n + 3))
         v["obs_f64"] = _view(b.obs_f64, np.float64, (E, n, 2 * n + 7))
         v["done_agents"] = _view(b.done_agents, np.uint8, (E, n))
+        v["sd_info"] = _view(b.sd_info, np.float64, (E, 2))
     v["timestep"] = _view(b.timestep, np.int32, (E,))
     v["theta"] = _view(b.theta, np.float64, (E,))
     v["base_reward"] = _view(b.base_reward, np.int32, (E, n))

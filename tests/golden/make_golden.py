@@ -157,21 +157,22 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
     return out
 
 
-def run_selfdrive_trace(R, n, seed, max_steps=400, episodes=2, act_scale=0.15):
+def run_selfdrive_trace(R, n, seed, max_steps=400, episodes=2, act_scale=0.15, collision_on=False):
     """Selfdrive + SelfdriveContractDistprop.  RLlib stops sending actions for agents whose
     done flag is set; the action dict therefore holds the not-yet-done agents only.  Actions are
     float32 values handed over as float64 (SURVEY §7 hard part 6: reproduces the float64
     arithmetic of the numpy-1.x era the reference was written for)."""
     np.random.seed(seed)
     random.seed(seed)
-    env = R.SelfAcceleratingCarEnv(num_agents=n)
+    env = R.SelfAcceleratingCarEnv(num_agents=n, collision_on=collision_on)
     con = R.contract_list.SelfdriveContractDistprop(n)
     top = R.SeparateContractSubgameStage(env, con, n, False)
     ars = np.random.RandomState(seed + 1)
     keys = ["a%d" % i for i in range(n)]
     L = 2 * n + 5
     rec = {k: [] for k in ("actions", "active", "obs", "rew", "base_rew", "done", "pos", "vel", "just_passed", "theta",
-                           "ep_start", "reset_obs", "transfers_metric", "crossed")}
+                           "ep_start", "reset_obs", "transfers_metric", "crossed", "dist_to_front", "amb_rank", "amb_dtf",
+                           "is_crashed")}
     step_idx = 0
     for ep in range(episodes):
         o = top.reset()
@@ -200,6 +201,13 @@ def run_selfdrive_trace(R, n, seed, max_steps=400, episodes=2, act_scale=0.15):
             rec["pos"].append(np.array([env.agent_positions[k] for k in keys]))
             rec["vel"].append(np.array([env.agent_vels[k] for k in keys]))
             rec["just_passed"].append(jp)
+            # update_infos' bookkeeping (:127-149) and the infos the first acting key carries (:183-189, :203-204)
+            first = next(k for i, k in enumerate(keys) if active[i])
+            assert all(info[k]["ambulance_rank"] == 0.0 and info[k]["is_crashed"] == 0 for k in acts if k != first)
+            rec["dist_to_front"].append(np.array([env.dist_to_front[k] for k in keys], np.float64))
+            rec["amb_rank"].append(float(info[first]["ambulance_rank"]))
+            rec["amb_dtf"].append(float(info[first]["ambulance_dist_to_front"]))
+            rec["is_crashed"].append(int(info[first]["is_crashed"]))
             rec["transfers_metric"].append(float(env.metrics["transfers"]))
             cr = [int(c[1:]) for c in env.crossed_agents] + [-1] * (n - len(env.crossed_agents))
             rec["crossed"].append(np.array(cr, np.int8))
@@ -208,7 +216,7 @@ def run_selfdrive_trace(R, n, seed, max_steps=400, episodes=2, act_scale=0.15):
                 done[k] = bool(d[k])
             if d["__all__"]:
                 break
-    out = {"kind": "selfdrive", "n": n, "seed": seed}
+    out = {"kind": "selfdrive", "n": n, "seed": seed, "collision_on": int(collision_on)}
     for k, v in rec.items():
         out[k] = np.array(v)
     return out
@@ -270,7 +278,10 @@ def main():
         print("%-28s steps=%5d  %7.1f KB" % (name, len(out["actions"]), os.path.getsize(path) / 1024))
     for name, kw in {"g5_selfdrive_n4": dict(n=4, seed=S0 + 20, episodes=3),
                      "g5_selfdrive_n2": dict(n=2, seed=S0 + 21, episodes=3),
-                     "g5_selfdrive_n6": dict(n=6, seed=S0 + 22, episodes=2)}.items():
+                     "g5_selfdrive_n6": dict(n=6, seed=S0 + 22, episodes=2),
+                     # collision_on=True: disobeying the merge order ends the episode (check_if_crashed :81-90, :195-215)
+                     "g5_selfdrive_n4_collision": dict(n=4, seed=S0 + 23, episodes=6, collision_on=True),
+                     "g5_selfdrive_n3_collision": dict(n=3, seed=S0 + 24, episodes=6, collision_on=True, act_scale=0.05)}.items():
         if only and name not in only:
             continue
         out = run_selfdrive_trace(R, **kw)

@@ -164,6 +164,13 @@ def replay_selfdrive(g, impl, env=0, sync=lambda: None, get=None, atol=1e-9):
             nc = int(st[4 * n + 1])
             crossed = [int(x) for x in st[4 * n + 2:4 * n + 2 + nc]]
             assert crossed == [int(x) for x in g["crossed"][t] if x >= 0], "crossed " + tag
+            if "dist_to_front" in g:  # update_infos' bookkeeping and the infos of the first acting key
+                np.testing.assert_allclose(st[2 * n:3 * n], g["dist_to_front"][t], rtol=0, atol=atol, err_msg="dist_to_front " + tag)
+                si = get("sd_info")[env]
+                assert si[0] == g["amb_rank"][t], "ambulance_rank %s: %s != %s" % (tag, si[0], g["amb_rank"][t])
+                np.testing.assert_allclose(si[1], g["amb_dtf"][t], rtol=0, atol=atol, err_msg="ambulance_dist_to_front " + tag)
+                first = int(np.nonzero(g["active"][t])[0][0])
+                assert int(get("info")[env][first, 1]) == int(g["is_crashed"][t]), "is_crashed " + tag
 
 
 def feat_kwargs(g):

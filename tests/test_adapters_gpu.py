@@ -81,15 +81,16 @@ def test_grid_adapter_trace(name, steps):
     env.close()
 
 
-def test_selfdrive_adapter_trace():
+@pytest.mark.parametrize("name", ["g5_selfdrive_n4", "g5_selfdrive_n4_collision", "g5_selfdrive_n3_collision"])
+def test_selfdrive_adapter_trace(name):
     from contracts_amd.contract import contract_list as cl
     from contracts_amd.environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
     from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
-    g = gc.load("g5_selfdrive_n4")
-    n, seed = 4, int(g["seed"])
+    g = gc.load(name)
+    n, seed = int(g["n"]), int(g["seed"])
     np.random.seed(seed)
     random.seed(seed)
-    env = SelfAcceleratingCarEnv(num_agents=n)
+    env = SelfAcceleratingCarEnv(num_agents=n, collision_on=bool(int(g["collision_on"])))
     top = SeparateContractSubgameStage(env, cl.SelfdriveContractDistprop(n), n, False)
     keys = ["a%d" % i for i in range(n)]
     ep_start = list(g["ep_start"]) + [len(g["actions"])]
@@ -108,6 +109,11 @@ def test_selfdrive_adapter_trace():
                     assert abs(r[k] - g["rew"][t][i]) < 1e-6
                     assert info[k]["just_passed"] == bool(g["just_passed"][t][i])
                 assert d[k] == bool(g["done"][t][i])
+            # the infos the reference attaches to the first acting key (every other key: zeros)
+            first = next(iter(acts))
+            assert info[first]["ambulance_rank"] == g["amb_rank"][t] and info[first]["is_crashed"] == g["is_crashed"][t]
+            assert abs(info[first]["ambulance_dist_to_front"] - g["amb_dtf"][t]) < 1e-9
+            assert all(info[k]["ambulance_rank"] == 0.0 and info[k]["is_crashed"] == 0 for k in acts if k != first)
             assert d["__all__"] == bool(g["done"][t][n])
             assert abs(env.metrics["transfers"] - g["transfers_metric"][t]) < 1e-6
         with pytest.raises(AttributeError):  # the reference raises when stepped after __all__ (…accelerate.py:160)

@@ -167,3 +167,26 @@ def test_fused_full_episode_vs_oracle_sample():
     fused.check_faults()
     fused.close()
     ref.close()
+
+
+@pytest.mark.parametrize("n,collision_on,T,per", [(4, False, 150, 0), (4, True, 90, 16), (3, False, 120, 7), (6, False, 80, 0)])
+def test_fused_selfdrive_equals_per_step(n, collision_on, T, per):
+    """selfdrive: cars resident in registers across the steps of a launch; several episodes (in-launch auto-resets,
+    both MT19937 streams advanced by them) inside the window"""
+    E = 517
+    fused, ref = _pair("selfdrive", E, n, contract="selfdrive_distprop", auto_reset=True, collision_on=collision_on)
+    acts = _actions(fused, T)
+    traj = fused.alloc_trajectory(T)
+    fused.rollout_fused(acts.data_ptr(), T, per, traj)
+    fused.synchronize()
+    host = {f: traj.tensors[f].cpu().numpy() for f in traj.tensors}
+    plane = E * n * 4
+    for t in range(T):
+        ref.step_device(acts.data_ptr() + t * plane)
+        for f in ("obs_f64", "base_reward", "reward", "done", "done_agents", "info", "sd_info"):
+            want = ref.download(f, raw=True)
+            assert host[f][t].reshape(want.shape).tobytes() == want.tobytes(), "%s plane %d" % (f, t)
+    _same(fused, ref, ["sd_state", "rng", "theta", "f64_metrics", "final_f64_metrics", "error_flags"], "selfdrive state")
+    fused.check_faults()
+    fused.close()
+    ref.close()

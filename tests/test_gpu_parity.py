@@ -41,7 +41,7 @@ def test_golden_grid(name):
 @pytest.mark.parametrize("name", gc.fixtures("g5_selfdrive"))
 def test_golden_selfdrive(name):
     g = gc.load(name)
-    env = _engine("selfdrive", 3, int(g["n"]), contract="selfdrive_distprop")
+    env = _engine("selfdrive", 3, int(g["n"]), contract="selfdrive_distprop", collision_on=bool(int(g["collision_on"])))
     gc.replay_selfdrive(g, env, env=2)
     env.close()
 
@@ -97,10 +97,11 @@ def test_random_rollout_vs_oracle(kind, n, contract, firing, horizon, E, T):
     env.close()
 
 
-def test_selfdrive_random_vs_oracle():
+@pytest.mark.parametrize("n,collision_on", [(4, False), (4, True), (3, False), (6, True), (1, False), (2, False), (8, False), (10, True)])
+def test_selfdrive_random_vs_oracle(n, collision_on):
     from oracle.pyoracle import Oracle
-    E, n = 1024, 4
-    kw = dict(contract="selfdrive_distprop", auto_reset=True)
+    E = 1030 if n == 4 else 203  # not a multiple of the envs per wave: the last wave is partly out of range
+    kw = dict(contract="selfdrive_distprop", auto_reset=True, collision_on=collision_on)
     env, orc = _engine("selfdrive", E, n, **kw), Oracle("selfdrive", E, n, **kw)
     seeds = np.arange(E, dtype=np.uint64) + 5
     for o in (env, orc):
@@ -111,11 +112,13 @@ def test_selfdrive_random_vs_oracle():
         a = rs.uniform(-0.15, 0.15, size=(E, n)).astype(np.float32)
         env.step(a)
         orc.step(a)
-        for f in ("obs_f64", "reward", "sd_state", "theta"):
+        for f in ("obs_f64", "reward", "sd_state", "theta", "sd_info", "f64_metrics"):
             np.testing.assert_allclose(env.download(f), getattr(orc, f), rtol=0, atol=1e-9, equal_nan=True,
                                        err_msg="%s step %d" % (f, t))
-        for f in ("done", "done_agents", "info"):
+        for f in ("done", "done_agents", "info", "base_reward"):
             assert np.array_equal(env.download(f), getattr(orc, f)), "%s step %d" % (f, t)
+    keep = np.r_[0:625, 628:1253]  # both MT19937 streams (np.random: theta draws, `random`: start positions) after the resets
+    assert np.array_equal(env.download("rng")[:, keep], orc.rng[:, keep])
     env.close()
 
 
@@ -204,7 +207,7 @@ FULL_SIZE = {  # BASELINE.json configs at their full single-GPU size
 FULL_FIELDS = {
     "cleanup": ("obs", "reward", "grid", "agents", "rng", "waste_perm", "features", "int_metrics", "f64_metrics", "theta"),
     "harvest": ("obs", "reward", "grid", "agents", "rng", "features", "int_metrics", "f64_metrics", "theta"),
-    "selfdrive": ("obs_f64", "reward", "sd_state", "rng", "theta", "done", "done_agents", "info", "f64_metrics"),
+    "selfdrive": ("obs_f64", "reward", "base_reward", "sd_state", "sd_info", "rng", "theta", "done", "done_agents", "info", "f64_metrics"),
     "harvest_features": ("reward", "apple_stamp", "next_stamp", "agents", "rng", "features", "int_metrics", "f64_metrics", "theta"),
 }
 
@@ -227,7 +230,7 @@ def test_full_size_partition_invariance_and_oracle_sample(cfg):
     if kind != "selfdrive":
         kw["horizon"] = c["horizon"]  # several in-launch auto-resets inside the window
     fields = FULL_FIELDS[kind]
-    fused_ok = kind in ("cleanup", "harvest")
+    fused_ok = kind in ("cleanup", "harvest", "selfdrive")
 
     def digest(envs):
         h = hashlib.sha256()

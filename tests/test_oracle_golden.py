@@ -16,7 +16,8 @@ def test_oracle_grid_golden(name):
 @pytest.mark.parametrize("name", gc.fixtures("g5_selfdrive"))
 def test_oracle_selfdrive_golden(name):
     g = gc.load(name)
-    gc.replay_selfdrive(g, Oracle("selfdrive", 2, int(g["n"]), contract="selfdrive_distprop"), env=1)
+    gc.replay_selfdrive(g, Oracle("selfdrive", 2, int(g["n"]), contract="selfdrive_distprop",
+                               collision_on=bool(int(g["collision_on"]))), env=1)
 
 
 @pytest.mark.parametrize("name", gc.fixtures("render_"))
