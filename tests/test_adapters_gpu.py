@@ -2,6 +2,7 @@
 (`np.random.seed(s); env = CleanupEnv(num_agents=n); wrapper = SeparateContractSubgameStage(...);
 reset(); step({agent: action})`), against the traces the reference produced (tests/golden)."""
 import hashlib
+import os
 import pickle
 import random
 
@@ -426,3 +427,19 @@ def test_batched_contract_evaluation_matches_sequential_episodes():
     assert got["mean reward"] == float(np.mean(want)) and got["std contract"] == float(np.std(thetas))
     ar = got["agent_rewards"]  # transfers are zero-sum over the agents: the parameter shows per agent, not in the total
     assert np.array_equal(ar[0], np.rint(ar[0])) and np.abs(ar[1:] - np.rint(ar[1:])).max() > 1e-3
+
+
+def test_run_rendering_writes_episode_videos(tmp_path):
+    """run_render.py's loop over the drop-in env: frames from device state, one file per rendered episode"""
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.run_render import run_rendering
+    np.random.seed(3)
+    env = CleanupEnv(num_agents=3, horizon=12, disable_firing=False)
+    rs = np.random.RandomState(1)
+    paths = run_rendering(env, lambda ob: int(rs.randint(9)), str(tmp_path / "renders"), num_renders=2)
+    assert len(paths) == 2 and all(os.path.getsize(p) > 1000 for p in paths)
+    if paths[0].endswith(".gif"):
+        from PIL import Image
+        im = Image.open(paths[0])
+        assert im.n_frames == 12 and im.size == (18 * 20, 25 * 20)
+    env.close()

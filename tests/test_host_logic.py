@@ -104,3 +104,22 @@ def test_synth_action_mirror_matches_the_library():
                 bits = L.ce_synth_hash_host(9, e, t, g) >> 40
                 want = np.float32(np.float32(bits) * np.float32(1.0 / 16777216.0)) * np.float32(0.2) - np.float32(0.1)
                 assert f[t, e, g] == want and f.dtype == np.float32
+
+
+def test_video_export_nearest_upscale(tmp_path):
+    """make_video_from_rgb_imgs (env_utils.py:28-58): frames are upscaled with the nearest-neighbour rule and written
+    (GIF through PIL here: cv2 is absent); decoding the file gives the upscaled frames back"""
+    from contracts_amd.environments.env_utils import _resize_nearest, make_video_from_rgb_imgs
+    rs = np.random.RandomState(0)
+    pal = np.array([[0, 0, 0], [180, 180, 180], [0, 255, 0], [99, 156, 194], [113, 75, 24], [0, 0, 255]], np.uint8)
+    frames = [pal[rs.randint(len(pal), size=(25, 18))] for _ in range(4)]
+    up = _resize_nearest(frames[0], (18 * 20, 25 * 20))
+    assert up.shape == (500, 360, 3) and np.array_equal(up[::20, ::20], frames[0]) and np.array_equal(up[19::20, 19::20], frames[0])
+    path = make_video_from_rgb_imgs(frames, str(tmp_path / "vid"), video_name="t", resize=(360, 500))
+    if path.endswith(".gif"):
+        from PIL import Image
+        im = Image.open(path)
+        assert im.n_frames == 4 and im.size == (360, 500)
+        for i in range(4):
+            im.seek(i)
+            assert np.array_equal(np.asarray(im.convert("RGB"))[::20, ::20], frames[i])

@@ -1,18 +1,27 @@
 #!/bin/bash
-# Runs ON the GPU box (via gpurun): kernel trace + separate PMC passes of the default bench workload.
-# Output: gpurun_out/prof/{kt,pmc1,pmc2,fetch,write}/...  (summarise with tools/summarise_profiles.py)
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof
+# Runs ON the GPU box (via gpurun): the round's profile set of the headline workload.
+#   tools/collect_profiles.sh [TAG]        (TAG default r02)
+# 1. rocprofv3 --kernel-trace --stats over the default bench command (every config of the line) -> kernel_stats
+# 2. PMC passes (separate runs, --pmc only) over tools/pmc_driver.py for the per-step kernel and the fused kernel:
+#    instruction mix / waits / LDS conflicts, then FETCH_SIZE and WRITE_SIZE each in its own pass
+# Output under gpurun_out/prof_$TAG; summarise on the build box with tools/summarise_profiles.py.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
+OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B --steps 400 --warmup 50 > $OUT/kt.json 2> $OUT/kt.log
-tail -1 $OUT/kt.json | cut -c1-300
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -- $B --steps 60 --warmup 10 > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc2 -- $B --steps 60 --warmup 10 > $OUT/pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --steps 60 --warmup 10 > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B --steps 60 --warmup 10 > $OUT/write.log 2>&1
-# keep only the small CSVs (the 64 MiB merge limit)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
+tail -1 $OUT/kt_bench_line.json | cut -c1-200
+cd $R
+G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY"
+G2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
+G3="GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVES"
+ES=$((64*16384))
+tools/pmc_run.sh ${TAG}_step k_grid_step $ES "$G1" "$G2" "$G3" "FETCH_SIZE" "WRITE_SIZE" -- --mode step --steps 64 > $OUT/pmc_step.txt 2>&1
+tools/pmc_run.sh ${TAG}_fused k_grid_rollout $ES "$G1" "$G2" "$G3" "FETCH_SIZE" "WRITE_SIZE" -- --mode fused --steps 64 --T 16 > $OUT/pmc_fused.txt 2>&1
+ES5=$((64*32768))
+tools/pmc_run.sh ${TAG}_sd_step k_sd_step $ES5 "$G1" "FETCH_SIZE" "WRITE_SIZE" -- --kind selfdrive --agents 4 --envs 32768 --mode step --steps 64 > $OUT/pmc_sd_step.txt 2>&1
+tools/pmc_run.sh ${TAG}_sd_fused k_sd_rollout $ES5 "$G1" "FETCH_SIZE" "WRITE_SIZE" -- --kind selfdrive --agents 4 --envs 32768 --mode fused --steps 64 --T 16 > $OUT/pmc_sd_fused.txt 2>&1
+for k in step fused sd_step sd_fused; do cp $R/gpurun_out/pmc/${TAG}_$k/summary.json $OUT/pmc_$k.json; done
 find $OUT -name '*_agent_info.csv' -delete
-find $OUT -name '*kernel_trace.csv' -size +20M -delete
+find $OUT -name '*kernel_trace.csv' -delete
 du -sh $OUT

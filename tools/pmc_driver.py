@@ -3,7 +3,7 @@
 
     python3 tools/pmc_driver.py --mode step|fused [--kind cleanup] [--agents 8] [--envs 16384] [--steps 64] [--T 64]
                                 [--preroll 300] [--streams 3]
-The pre-roll always runs as per-step launches (so the profiled kernel of a fused run only sees the measured steps).
+The pre-roll runs with the other mode's kernel (so the profiled kernel only sees the measured, steady-state steps).
 """
 import argparse
 import os
@@ -38,8 +38,11 @@ def main():
     plane = a.envs * a.agents * (4 if a.kind == "selfdrive" else 1)
     streams = [torch.cuda.Stream() for _ in range(a.streams)]
     handles = [s.cuda_stream for s in streams] if a.streams > 1 else None
-    if a.preroll:
-        env.rollout_device(acts.data_ptr(), a.preroll, handles)
+    if a.preroll:  # with the OTHER mode's kernel where there is one, so that the profiled kernel only sees the measured steps
+        if a.mode == "step" and a.kind in ("cleanup", "harvest", "selfdrive"):
+            env.rollout_fused(acts.data_ptr(), a.preroll, 50, None, handles)
+        else:
+            env.rollout_device(acts.data_ptr(), a.preroll, handles)
     torch.cuda.synchronize()
     base = acts.data_ptr() + a.preroll * plane
     if a.mode == "fused":

@@ -18,13 +18,20 @@ cd $R
 python3 - "$OUT" "$KSUB" "$ENVSTEPS" "$NAME" <<'PY'
 import csv, glob, json, sys
 out, ksub, envsteps, name = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
-acc, disp = {}, {}
+acc, disp, passes = {}, {}, {}
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+    seen = set()
     for row in csv.DictReader(open(f)):
         if ksub in row["Kernel_Name"]:
             c = row["Counter_Name"]
             acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
             disp[c] = disp.get(c, 0) + 1
+            seen.add(c)
+    for c in seen:
+        passes[c] = passes.get(c, 0) + 1
+for c in acc:  # a counter collected in several passes: the mean of the passes
+    acc[c] /= passes[c]
+    disp[c] //= passes[c]
 res = {c: acc[c] / envsteps for c in sorted(acc)}
 for c in sorted(acc):
     print("%-28s dispatches %6d   per env-step %12.2f" % (c, disp[c], res[c]))

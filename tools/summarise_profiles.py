@@ -1,8 +1,9 @@
-"""Turns gpurun_out/prof (tools/collect_profiles.sh) into the committed summaries under profiles/:
-  r01_kernel_stats.csv   rocprofv3 --kernel-trace --stats kernel summary
-  r01_pmc_summary.json   per-dispatch / per-wave counter means of the step kernel + HBM traffic
-  traffic.json           HBM bytes per launch (read by bench.py into roofline.traffic)
-Usage: python tools/summarise_profiles.py [gpurun_out/prof] [round-tag]"""
+"""Turns gpurun_out/prof_<tag> (tools/collect_profiles.sh) into the committed summaries under profiles/:
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats kernel summary of the default bench command
+  <tag>_pmc_summary.json   per env-step counter values of the per-step and the fused kernels + HBM traffic
+  <tag>_bench_line.json    the bench line of the profiled run (slower than an unprofiled one)
+  traffic.json             PMC HBM bytes per env-step, read by bench.py into roofline.traffic
+Usage: python tools/summarise_profiles.py [gpurun_out/prof_r02] [r02]"""
 import csv
 import glob
 import json
@@ -10,79 +11,43 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
-KERNEL = "k_grid_step"
-ALGO = 7235
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+ALGO = {"step": 7235, "fused": 7235, "sd_step": 863, "sd_fused": 863}
+KIND = {"step": ("cleanup", 8), "fused": ("cleanup", 8), "sd_step": ("selfdrive", 4), "sd_fused": ("selfdrive", 4)}
 
+stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
+shutil.copy(max(stats, key=os.path.getmtime), "profiles/%s_kernel_stats.csv" % tag)
+line = [ln for ln in open(os.path.join(src, "kt_bench_line.json")).read().splitlines() if ln.startswith("{")][-1]
+json.dump(json.loads(line), open("profiles/%s_bench_line.json" % tag, "w"), indent=1)
 
-def find(sub, pat):
-    got = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
-    if not got:
-        raise SystemExit("missing %s/%s" % (sub, pat))
-    return max(got, key=os.path.getmtime)  # gpurun merges into gpurun_out/: older runs' files may still be there
-
-
-def counter_means(sub):
-    acc, meta = {}, {}
-    with open(find(sub, "*counter_collection.csv")) as f:
-        for row in csv.DictReader(f):
-            if KERNEL not in row["Kernel_Name"]:
-                continue
-            c = row["Counter_Name"]
-            s, k = acc.get(c, (0.0, 0))
-            acc[c] = (s + float(row["Counter_Value"]), k + 1)
-            if not meta:
-                meta = {k2: row[k2] for k2 in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count")
-                        if k2 in row}
-    return {c: s / k for c, (s, k) in acc.items()}, meta
-
-
-per, meta = {}, {}
-for sub in ("pmc1", "pmc2", "fetch", "write"):
-    m, mm = counter_means(sub)
-    per.update(m)
-    meta = meta or mm
-waves = per["SQ_WAVES"]  # mean over the dispatches of the step kernel (slices differ by one env)
-envs = int(round(waves))
-fetch_b = per["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reports half of wide coalesced reads
-write_b = per["WRITE_SIZE"] * 1024
-traffic = int(fetch_b + write_b)
-
-stats_path = find("kt", "*kernel_stats.csv")
-shutil.copy(stats_path, "profiles/%s_kernel_stats.csv" % tag)
-kt = {}
-with open(stats_path) as f:
-    for row in csv.DictReader(f):
-        if KERNEL in row["Name"]:
-            kt = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "percentage": float(row["Percentage"]),
-                  "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
-line = open(os.path.join(src, "kt.json")).read().strip().splitlines()[-1]
-try:
-    bench = json.loads(line)
-    kt["bench_kernel_ms_hip_events"] = bench["roofline"]["kernel_ms"]
-    kt["bench_value_under_profiler"] = bench["value"]
-except Exception:
-    pass
-
-out = {
-    "round": int(tag[1:]),
-    "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 50 --no-cpu-baseline ; "
-               "PMC: separate `rocprofv3 --pmc <set>` passes of `python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline` "
-               "(bench default: the rank's 16384 envs as 3 contiguous slices on 3 HIP streams)",
-    "kernel": "ce::k_grid_step<0> (cleanup_new n=8 + CleanupContract, ~%d envs per launch, one 64-lane workgroup per env, 3 launches in flight)" % envs,
-    "per_dispatch_mean": per,
-    "dispatch_meta": meta,
-    "per_wave": {c: round(v / waves, 1) for c, v in per.items() if c.startswith("SQ_")},
-    "hbm_traffic": {"FETCH_SIZE_KB": per["FETCH_SIZE"], "WRITE_SIZE_KB": per["WRITE_SIZE"],
-                    "note": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled; "
-                            "WRITE_SIZE taken as is; per launch of %d envs" % envs,
-                    "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": ALGO * envs},
-    "kernel_trace": kt,
-}
+out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 20 "
+       "--no-cpu-baseline --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
+       "a 300-step pre-roll run with the other mode's kernel), summed over the dispatches of the kernel and divided by envs x steps",
+       "kernels": {}}
+traffic = {}
+for key in ("step", "fused", "sd_step", "sd_fused"):
+    path = os.path.join(src, "pmc_%s.json" % key)
+    if not os.path.exists(path):
+        continue
+    s = json.load(open(path))
+    per = s["per_env_step"]
+    row = {"kernel": s["kernel"], "env_steps": s["env_steps"], "per_env_step": per, "dispatches": s["dispatches"]}
+    if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+        # rocprofv3 reports KB; gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 B -> doubled
+        # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is
+        fetch_b, write_b = per["FETCH_SIZE"] * 1024 * 2, per["WRITE_SIZE"] * 1024
+        row["hbm"] = {"fetch_bytes_per_env_step": fetch_b, "write_bytes_per_env_step": write_b,
+                      "hbm_bytes_per_env_step": fetch_b + write_b, "algorithmic_bytes_per_env_step": ALGO[key],
+                      "ratio_to_algorithmic": (fetch_b + write_b) / ALGO[key]}
+        tk = {"step": "per_step", "fused": "fused", "sd_step": "per_step_C5", "sd_fused": "fused_C5"}[key]
+        traffic[tk] = {"kind": KIND[key][0], "agents": KIND[key][1], "hbm_bytes_per_env_step": fetch_b + write_b,
+                       "source": "profiles/%s_pmc_summary.json (%s; FETCH_SIZE doubled per the gfx950 correction)" % (tag, s["kernel"])}
+    if "SQ_LDS_BANK_CONFLICT" in per and per.get("SQ_ACTIVE_INST_LDS"):
+        row["lds_conflict_share_of_lds_active"] = per["SQ_LDS_BANK_CONFLICT"] / per["SQ_ACTIVE_INST_LDS"]
+    if "SQ_WAVE_CYCLES" in per:
+        row["wait_inst_any_share"] = per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]
+    out["kernels"][key] = row
 json.dump(out, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
-json.dump({"kind": "cleanup", "agents": 8, "hbm_bytes_per_env_step": traffic / envs, "measured_envs_per_launch": envs,
-           "hbm_bytes_per_launch": traffic,
-           "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the "
-                     "gfx950 correction)" % tag}, open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps({"traffic": traffic, "algo": ALGO * envs, "kt": kt, "per_wave": out["per_wave"]}, indent=1))
+json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps({k: v.get("hbm", {}).get("hbm_bytes_per_env_step") for k, v in out["kernels"].items()}))
