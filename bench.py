@@ -51,7 +51,7 @@ WORKLOADS = {
                name="harvest (HarvestFeatures) 2 agents + HarvestFeaturemodLocalContract, batched to 16384 envs"),
 }
 DTYPE = {"cleanup": "u8", "harvest": "u8", "harvest_features": "u8", "cleanup_features": "u8", "selfdrive": "f64"}
-FUSED_KINDS = ("cleanup", "harvest", "selfdrive")  # kinds ce_rollout_fused is built for
+FUSED_KINDS = ("cleanup", "harvest", "selfdrive", "harvest_features", "cleanup_features")
 
 
 def parse():
@@ -282,8 +282,8 @@ class Runner:
 
 
 KERNEL = {"cleanup": ("k_grid_step<cleanup>", "k_grid_rollout<cleanup>"), "harvest": ("k_grid_step<harvest>", "k_grid_rollout<harvest>"),
-          "selfdrive": ("k_sd_step", "k_sd_rollout"), "harvest_features": ("k_feat_step<harvest>", None),
-          "cleanup_features": ("k_feat_step<cleanup>", None)}
+          "selfdrive": ("k_sd_step", "k_sd_rollout"), "harvest_features": ("k_feat_step<harvest>", "k_feat_rollout<harvest>"),
+          "cleanup_features": ("k_feat_step<cleanup>", "k_feat_rollout<cleanup>")}
 
 
 def run_rank(a):

@@ -2616,10 +2616,10 @@ template <int GK> DEVINL u32 feat_close_count(FEnv<GK>& E, u32 cell) {
 }
 
 // feature vector (also the observation); closest apple / waste = min over (manhattan, list stamp)
-template <int GK> DEVINL u32 feat_features(FEnv<GK>& E, const GridParams& p, u32 cleaned) {
+template <int GK> DEVINL u32 feat_features(FEnv<GK>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned) {
   typedef Geo<GK> G;
   const u32 lane = E.lane, n = E.n, nf = p.num_features;
-  const auto f = p.features + ((size_t)E.e * n + (E.is_agent ? lane : 0)) * nf;
+  const auto f = features + ((size_t)E.e * n + (E.is_agent ? lane : 0)) * nf;
   const u32 cp = n > 1 ? 1u : 0u;  // compute_closest_pos: a0 -> a1, everyone else -> a0 (inf - inf = nan argmin)
   const u32 p_a0 = rdl(E.P, 0), o_a0 = rdl(E.O, 0), p_cp = rdl(E.P, cp), o_cp = rdl(E.O, cp);
   const u32 cpp = lane == 0 ? p_cp : p_a0, cpo = lane == 0 ? o_cp : o_a0;
@@ -2761,7 +2761,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   feat_load(E, p, false);
   feat_reset_env(E, p, orient);
   feat_zero_outputs(E, p);
-  feat_features(E, p, 0u);
+  feat_features(E, p, p.features, 0u);
   feat_store(E, p);
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
@@ -2771,26 +2771,24 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   }
 }
 
-template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
-                                                                   const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+// One step of a feature-vector env on the state held in E / LDS (see grid_step_core for FUSED / OUT)
+template <int GK, bool FUSED, class OUT>
+DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32 ACT, u32& t, double& theta, u32& fault,
+                           bool& did_reset) {
   typedef Geo<GK> G;
-  const GridParams& p = *pp;
-  __shared__ FeatLds<GK> lds;
-  FEnv<GK> E;
-  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;
   constexpr bool harvest = GK == CE_KIND_HARVEST;
-  const u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + ea, lane) : 4u;
-  if (ballot(E.is_agent && ACT > (harvest ? 7u : 8u)) != 0) {
-    if (lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
+  if (ballot(E.is_agent && ACT > (harvest ? 7u : 8u)) != 0) {  // the step is not taken
+    fault |= CE_FAULT_BAD_ACTION;
     return;
   }
-  feat_load(E, p, true);
+  if (FUSED) {  // the presence map is rebuilt from the list stamps held in registers (a single-step launch does the same after its load)
+    feat_base_map(E);
+    wave_sync();
+  }
   feat_paint(E);
   uint8_t* pm = E.L->w.pmap;
-  u32 t = (u32)p.timestep[E.e];
-  double theta = p.theta[E.e];
 
   // ---- move_squares: an insertion-ordered dict — stayers first, then movers in key order; a mover is refused by
   // a wall or by any square claimed so far (harvest_features.py:176-196 / cleanup_features.py:165-183) ----
@@ -2866,7 +2864,7 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
   }
   // ---- spawn, features ----
   feat_spawn(E);
-  const u32 feat8 = feat_features(E, p, cleaned);
+  const u32 feat8 = feat_features(E, p, out.features(), cleaned);
   t += 1;
   const bool done = t == p.horizon;
   // ---- metrics (same layout as the grid kinds) ----
@@ -2918,12 +2916,11 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
     }
   }
   if (E.is_agent) {
-    (p.base_reward + ea)[lane] = (i32)rew;
-    (p.reward + ea)[lane] = rw;
-    (p.info + 2 * ea)[2 * lane] = (uint8_t)eaten;
-    (p.info + 2 * ea)[2 * lane + 1] = (uint8_t)(harvest ? eaten_close : cleaned);
+    (out.base_reward() + ea)[lane] = (i32)rew;
+    (out.reward() + ea)[lane] = rw;
+    (out.info() + 2 * ea)[2 * lane] = (uint8_t)eaten;
+    (out.info() + 2 * ea)[2 * lane + 1] = (uint8_t)(harvest ? eaten_close : cleaned);
   }
-  bool did_reset = false;
   if (done) {  // compute_equality / compute_sustainability (+ the transferred versions of the wrapper)
     const long long sr = E.is_agent ? m_sr : 0, str_ = E.is_agent ? m_str : 0;
     long long eq = 0, total = 0;
@@ -2975,11 +2972,76 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
       did_reset = true;
     }
   }
+  if (lane == 0) out.done()[E.e] = done ? 1 : 0;
+  if (FUSED) return;  // the state stays in registers / LDS for the next step of the launch
   feat_store(E, p);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
-    p.done[E.e] = done ? 1 : 0;
     if (did_reset) p.theta[E.e] = theta;
+  }
+}
+
+template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+                                                                   const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+  const GridParams& p = *pp;
+  __shared__ FeatLds<GK> lds;
+  FEnv<GK> E;
+  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
+  const u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + (size_t)E.e * E.n, E.lane) : 4u;
+  if (ballot(E.is_agent && ACT > (GK == CE_KIND_HARVEST ? 7u : 8u)) != 0) {  // validated before anything is loaded or written
+    if (E.lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
+    return;
+  }
+  feat_load(E, p, true);
+  u32 t = (u32)p.timestep[E.e], fault = 0;
+  double theta = p.theta[E.e];
+  bool did_reset = false;
+  feat_step_core<GK, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
+}
+
+// Fused multi-step rollout of the feature-vector envs (ce_rollout_fused): list stamps, agents and the CPython `random`
+// stream stay on chip for the steps of a launch (the np.random stream is only touched by resets, straight in HBM)
+template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+  static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
+  const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  __shared__ FeatLds<GK> lds;
+  FEnv<GK> E;
+  if (!feat_begin(E, *pp, &lds, rap->env_first, rap->env_end)) return;
+  u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))rap->actions + (size_t)E.e * E.n, E.lane) : 4u;
+  feat_load(E, *pp, true);
+  u32 t = rfl((u32)pp->timestep[E.e]);
+  double theta = shfl_f64(pp->theta[E.e], 0);
+  u32 fault = 0, pl = rap->plane0;
+  bool any_reset = false;
+  const u32 num_steps = rap->num_steps;
+  for (u32 s = 0; s < num_steps; ++s) {
+    const GridParams& p = opaque_block(pp);
+    const RolloutArgs& ra = opaque_block(rap);
+    asm volatile("" : "+v"(E.lane));
+    E.n = opaque_u32(E.n);
+    E.e = opaque_u32(E.e);
+    E.is_agent = E.lane < E.n;
+    const u32 sn = s + 1 < num_steps ? s + 1 : s;
+    const u32 ACTN = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))ra.actions + (size_t)sn * ra.action_plane + (size_t)E.e * E.n, E.lane) : 4u;
+    bool did_reset = false;
+    feat_step_core<GK, true>(E, p, StepOutPlane{ra, pl}, ACT, t, theta, fault, did_reset);
+    ACT = ACTN;
+    pl = pl + 1 == ra.num_planes ? 0u : pl + 1;
+    rng_assert_uniform(E.py);
+    E.py.twists = rfl(E.py.twists);
+    E.next_a = rfl(E.next_a);
+    E.next_w = rfl(E.next_w);
+    t = rfl(t);
+    fault = rfl(fault);
+    any_reset = rfl((u32)(any_reset || did_reset)) != 0;
+    if (did_reset) theta = shfl_f64(theta, 0);
+  }
+  const GridParams& p = opaque_block(pp);
+  feat_store(E, p);
+  if (E.lane == 0) {
+    p.timestep[E.e] = (i32)t;
+    if (any_reset) p.theta[E.e] = theta;
+    if (fault) p.error_flags[E.e] |= fault;
   }
 }
 
@@ -3255,6 +3317,11 @@ void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_construct); }
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_reset); }
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_step); }
+void launch_feat_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+  const u32 count = ra.env_end - ra.env_first;
+  if (kind == CE_KIND_HARVEST_FEATURES) hipLaunchKernelGGL(k_feat_rollout<CE_KIND_HARVEST>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra);
+  else hipLaunchKernelGGL(k_feat_rollout<CE_KIND_CLEANUP>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra);
+}
 
 void launch_synth_actions_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions,
                              void* stream) {

@@ -190,3 +190,29 @@ def test_fused_selfdrive_equals_per_step(n, collision_on, T, per):
     fused.check_faults()
     fused.close()
     ref.close()
+
+
+@pytest.mark.parametrize("kind,n,contract,horizon,T,per", [("harvest_features", 2, "harvest_local", 17, 60, 0),
+                                                          ("harvest_features", 5, None, 1000, 40, 9),
+                                                          ("cleanup_features", 2, "cleanup", 13, 60, 16),
+                                                          ("cleanup_features", 8, None, 1000, 35, 0)])
+def test_fused_feature_envs_equal_per_step(kind, n, contract, horizon, T, per):
+    """HarvestFeatures / CleanupFeatures: list stamps, agents and the CPython `random` stream resident across the steps
+    of a launch; in-launch resets draw from both generators"""
+    E = 150
+    fused, ref = _pair(kind, E, n, contract=contract, horizon=horizon, auto_reset=True)
+    acts = _actions(fused, T)
+    traj = fused.alloc_trajectory(T)
+    fused.rollout_fused(acts.data_ptr(), T, per, traj)
+    fused.synchronize()
+    host = {f: traj.tensors[f].cpu().numpy() for f in traj.tensors}
+    for t in range(T):
+        ref.step_device(acts.data_ptr() + t * E * n)
+        for f in ("features", "base_reward", "reward", "done", "info"):
+            want = ref.download(f, raw=True)
+            assert host[f][t].reshape(want.shape).tobytes() == want.tobytes(), "%s plane %d" % (f, t)
+    _same(fused, ref, ["grid", "agents", "rng", "timestep", "theta", "int_metrics", "f64_metrics", "final_int_metrics",
+                       "final_f64_metrics", "error_flags"], "feature env state")
+    fused.check_faults()
+    fused.close()
+    ref.close()

@@ -230,7 +230,7 @@ def test_full_size_partition_invariance_and_oracle_sample(cfg):
     if kind != "selfdrive":
         kw["horizon"] = c["horizon"]  # several in-launch auto-resets inside the window
     fields = FULL_FIELDS[kind]
-    fused_ok = kind in ("cleanup", "harvest", "selfdrive")
+    fused_ok = True  # every family has a fused rollout kernel
 
     def digest(envs):
         h = hashlib.sha256()
