@@ -28,7 +28,11 @@ constexpr int kRngStride = CE_RNG_WORDS_GRID;  // words per env row
 // the interior either.
 template <int KIND> struct Geo;
 template <> struct Geo<CE_KIND_CLEANUP> {
-  static constexpr int H = 25, W = 18, CELLS = 450, PW = 32, PH = 39, PCELLS = PW * PH;
+  // PW = 36 (9 dwords), not 32: the crop gathers of the observation pass read a 15 x 15 window with 60 lanes; with a
+  // 32-byte pitch four lanes of every left / right facing view and two of every up / down facing one land on the same
+  // LDS bank (ds_read_u8 banks: (a / 4) mod 32 per 32-lane half) — 128 of the step's 210 conflict cycles; 36 makes the
+  // left / right views conflict free and leaves one extra cycle on the up / down ones
+  static constexpr int H = 25, W = 18, CELLS = 450, PW = 36, PH = 39, PCELLS = PW * PH;
   static constexpr int NAPPLE = 103, NWASTE = 119, RANDW = 2 * (103 + 119), NSPAWN_CTOR = 10;
   // LDS keeps the words of the apple doubles only; of a waste double only "u < 0.5" matters, which is
   // bit 31 of its first word (kept as one byte per double)

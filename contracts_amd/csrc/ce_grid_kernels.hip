@@ -655,7 +655,7 @@ template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return __umul24(row + 
 // Exact small-range divisions by multiply-shift with 24-bit multiplies (v_mul_u32_u24 is full rate, the
 // 32-bit v_mul_lo/hi the compiler emits for `/ constant` are quarter rate): valid for idx < 640 / pad < 1600.
 template <int KIND> DEVINL u32 div_pw(u32 pad) {  // pad / PW
-  return KIND == CE_KIND_CLEANUP ? (pad >> 5) : (__umul24(pad, 1261u) >> 16);
+  return KIND == CE_KIND_CLEANUP ? (__umul24(pad, 1821u) >> 16) : (__umul24(pad, 1261u) >> 16);  // / 36, / 52
 }
 template <int KIND> DEVINL u32 row_of(u32 pad) { return div_pw<KIND>(pad) - kView; }
 template <int KIND> DEVINL u32 col_of(u32 pad) { return pad - __umul24(div_pw<KIND>(pad), (u32)Geo<KIND>::PW) - kView; }

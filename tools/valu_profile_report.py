@@ -13,7 +13,7 @@ def load(k):
     w = acc["SQ_WAVES"][0] / acc["SQ_WAVES"][1]
     return {c: s / k2 / w for c, (s, k2) in acc.items()}
 prev = {}
-cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
+cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SMEM"]
 print("%-42s" % "phase (per wave)" + "".join("%12s" % c.replace("SQ_", "").replace("INSTS_", "") for c in cols))
 for k in order:
     cur = load(k)
