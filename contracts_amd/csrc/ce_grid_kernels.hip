@@ -614,6 +614,12 @@ template <int KIND> struct alignas(16) WaveLds {
 // cell" query of the beam / spawn code into the LDS read that is needed anyway.
 constexpr uint8_t kAgentBit = 0x80;
 constexpr u32 kCodeMask = 0x7fu;
+// The LDS map of the grid kernels holds every cell code PRE-SCALED by 4 (bits 2..6): a map byte is then directly the
+// byte offset of its colour in the LUT, which saves the observation pass one shift per pixel (32 VALU per step at
+// n = 8).  HBM images, tables and the feature-vector kernels keep the plain CE_CELL_* codes.
+constexpr u32 kScale = 2;
+constexpr u32 kEmpty = CE_CELL_EMPTY << kScale, kWall = CE_CELL_WALL << kScale, kApple = CE_CELL_APPLE << kScale,
+              kWaste = CE_CELL_WASTE << kScale, kRiver = CE_CELL_RIVER << kScale;
 // Predicated store into the padded map without touching exec: lanes that are off aim at byte 0 — the corner of the
 // view border, CE_CELL_EMPTY in both maps and never anything else — and write 0 there.  Two v_cndmask instead of a
 // compare + exec save / restore + branch; the scalar unit is the busier one in these kernels.
@@ -740,13 +746,13 @@ template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const u64 m = (u64)bits[2 * r] | (u64)bits[2 * r + 1] << 32;
-    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), lane_bit(m, E.lane) ? CE_CELL_APPLE : CE_CELL_EMPTY);
+    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), lane_bit(m, E.lane) ? kApple : kEmpty);
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const u64 m = (u64)bits[4 + 2 * r] | (u64)bits[5 + 2 * r] << 32;
-      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), lane_bit(m, E.lane) ? CE_CELL_WASTE : CE_CELL_RIVER);
+      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), lane_bit(m, E.lane) ? kWaste : kRiver);
     }
   }
 }
@@ -758,14 +764,14 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p, bo
   u32 w = 0;  // lane k < 8 assembles state dword k
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
-    const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == CE_CELL_APPLE));
+    const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == kApple));
     if (E.lane == 2 * r) w = (u32)m;
     if (E.lane == 2 * r + 1) w = (u32)(m >> 32);
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE));
+      const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
       if (E.lane == 4 + 2 * r) w = (u32)m;
       if (E.lane == 5 + 2 * r) w = (u32)(m >> 32);
     }
@@ -859,7 +865,7 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   // ---- LDS image ----
   u32* pm32 = (u32*)E.L->pmap;
 #pragma unroll
-  for (int r = 0; r < GROUNDS; ++r) pm32[min(lane + 64u * r, kLastMapWord)] = gw[r];
+  for (int r = 0; r < GROUNDS; ++r) pm32[min(lane + 64u * r, kLastMapWord)] = gw[r] << kScale;  // codes <= 5: no carry between bytes
   wave_sync();
   paint_presence(E, gbits);
   E.L->rgb[lane & 15] = rgbv;
@@ -899,7 +905,7 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
   u32 tgt = E.P;
   if (mover) {
     u32 cand = (u32)((i32)E.P + dr * G::PW + dc);
-    if (E.L->pmap[cand] != CE_CELL_WALL) tgt = cand;
+    if (E.L->pmap[cand] != kWall) tgt = cand;
   }
   const u32 TGT0 = tgt;
   if (E.is_agent && (ACT == 5 || ACT == 6)) E.O = (E.O + (ACT == 5 ? 1u : 3u)) & 3u;
@@ -1042,9 +1048,9 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, const GridParams& p, u32 
   const u32 cell = in_beam ? (u32)(start + (i32)(step + 1) * dd) : 0u;
   const u32 raw = E.L->pmap[cell];
   const u32 code = raw & kCodeMask;
-  const bool invalid = code == CE_CELL_WALL;
+  const bool invalid = code == kWall;
   const bool agent_here = in_beam && (raw & kAgentBit) != 0;
-  const bool stopper = invalid || agent_here || (is_clean && code == CE_CELL_WASTE);
+  const bool stopper = invalid || agent_here || (is_clean && code == kWaste);
   const u64 S = ballot(in_beam && stopper);
   const u32 rb = (u32)(S >> (5 * ray)) & 31u;
   const u32 f = rb ? (u32)__builtin_ctz(rb) : 5u;  // first stopping cell of this ray
@@ -1056,10 +1062,10 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, const GridParams& p, u32 
   }
   u32 cleaned = 0;
   if (is_clean) {
-    const bool upd = processed && code == CE_CELL_WASTE;
+    const bool upd = processed && code == kWaste;
     cleaned = popc64(ballot(upd));
     wave_sync();
-    pm_put(E.L->pmap, upd, cell, CE_CELL_RIVER | (raw & kAgentBit));
+    pm_put(E.L->pmap, upd, cell, kRiver | (raw & kAgentBit));
     wave_sync();
   } else {
     const u64 hm0 = ballot(processed && agent_here);
@@ -1143,7 +1149,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
-      nH += popc64(ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE)));
+      nH += popc64(ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
     }
     waste_on = (T.apple_thresh[nH] & kWasteOnBit) != 0;
   }
@@ -1151,7 +1157,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   for (int r = 0; r < AR; ++r) {
     const bool v = lane + 64 * r < (u32)G::NAPPLE;
     const u32 cell = cell_pad(E.AP[r]);
-    elig[r] = both(v, pm[cell] == CE_CELL_EMPTY);
+    elig[r] = both(v, pm[cell] == kEmpty);
     if (KIND == CE_KIND_CLEANUP) {
       thrA[r] = T.apple_thresh[nH] & ~kWasteOnBit;
     } else {
@@ -1161,7 +1167,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
         for (int j = -1; j <= 1; ++j)
 #pragma unroll
-          for (int k = -1; k <= 1; ++k) num += pm[(i32)cell + j * G::PW + k] == CE_CELL_APPLE ? 1u : 0u;
+          for (int k = -1; k <= 1; ++k) num += pm[(i32)cell + j * G::PW + k] == kApple ? 1u : 0u;
       }
       thrA[r] = T.apple_thresh[num < 3 ? num : 3];
     }
@@ -1256,8 +1262,8 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
         const u32 t00 = bperm(E.WS[0], w0), t01 = bperm(E.WS[1], w0 - 64u);
         const u32 t10 = bperm(E.WS[0], w1), t11 = bperm(E.WS[1], w1 - 64u);
         const u32 c0 = cell_pad(w0 < 64u ? t00 : t01), c1 = cell_pad(w1 < 64u ? t10 : t11);
-        const bool cand0 = (pm[c0] & kCodeMask) != CE_CELL_WASTE;
-        const bool cand1 = both(v1, (pm[c1] & kCodeMask) != CE_CELL_WASTE);
+        const bool cand0 = (pm[c0] & kCodeMask) != kWaste;
+        const bool cand1 = both(v1, (pm[c1] & kCodeMask) != kWaste);
         const u64 cb0 = ballot(cand0), cb1 = ballot(cand1);
         const u64 sel0 = ballot(cand0 && popc64(cb0 & lt) == tstar);
         const u64 sel1 = ballot(cand1 && popc64(cb0) + popc64(cb1 & lt) == tstar);
@@ -1274,10 +1280,10 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   wave_sync();
 #pragma unroll
   for (int r = 0; r < AR; ++r)
-    pm_put(pm, spawnA[r], cell_pad(E.AP[r]), CE_CELL_APPLE);
+    pm_put(pm, spawnA[r], cell_pad(E.AP[r]), kApple);
   {
     const bool wput = waste_found && lane == 0;
-    pm_put(pm, wput, waste_cell, CE_CELL_WASTE | (pm[pm_sel(wput, waste_cell)] & kAgentBit));
+    pm_put(pm, wput, waste_cell, kWaste | (pm[pm_sel(wput, waste_cell)] & kAgentBit));
   }
   wave_sync();
 }
@@ -1307,12 +1313,12 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
       const u32 pa = bperm(E.P, a), pb = bperm(E.P, b);
       const u64 cov = ballot(a < b && b < E.n && pa == pb);
       const bool top = ((u32)(cov >> ((lane & 7u) << 3)) & 0xffu) == 0;  // lane a < 8 reads its own row of pairs
-      pm_put(pm, E.is_agent && top, E.P, 6 + lane);
+      pm_put(pm, E.is_agent && top, E.P, (6 + lane) << kScale);
       wave_sync();
     } else {
       for (u32 a = 0; a < E.n; ++a) {
         const u32 pa = rdl(E.P, a);
-        pm_put(pm, lane == 0, pa, 6 + a);
+        pm_put(pm, lane == 0, pa, (6 + a) << kScale);
         wave_sync();
       }
     }
@@ -1347,10 +1353,11 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24;
     const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)(vw & 0xffffu);
     const i32 off1 = off0 + B, off2 = off1 + B, off3 = off2 + B;  // a chain of adds with the scalar B
-    const u32 c0 = rgb[pm[off0]];
-    const u32 c1 = rgb[pm[off1]];
-    const u32 c2 = rgb[pm[off2]];
-    u32 c3 = rgb[pm[off3]];
+    const auto lut = [&](i32 off) { return *(const u32*)((const char*)rgb + pm[off]); };  // a map byte is code * 4
+    const u32 c0 = lut(off0);
+    const u32 c1 = lut(off1);
+    const u32 c2 = lut(off2);
+    u32 c3 = lut(off3);
     c3 = padded ? 0u : c3;
     u32x3 d;
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
@@ -1475,7 +1482,7 @@ template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, dou
   {  // reset_map + custom_reset: the static padded base map
     const u32* src = (const u32*)c_tab[KIND].base_pmap;
     u32* dst = (u32*)E.L->pmap;
-    for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k];
+    for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k] << kScale;
   }
   mark_agents(E);
   zero_metrics(E, p);
@@ -1549,7 +1556,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     bool f = false;
     u32 rc = 0;
     if (r < 3) {
-      f = both(lane + 64 * r < (u32)G::NAPPLE, pm[cell_pad(E.AP[r < 3 ? r : 0])] == CE_CELL_APPLE);
+      f = both(lane + 64 * r < (u32)G::NAPPLE, pm[cell_pad(E.AP[r < 3 ? r : 0])] == kApple);
       rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
     napples += popc64(ballot(f));
@@ -1558,7 +1565,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (u32 r = 0; r < 2; ++r) {
-      const bool f = both(lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == CE_CELL_WASTE);
+      const bool f = both(lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste);
       nwaste += popc64(ballot(f));
       keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
     }
@@ -1605,9 +1612,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       const i32 pa = (i32)bperm(E.P, ag < n ? ag : 0u);
       const i32 o0 = (i32)T.close_off[j], o1 = (i32)T.close_off[8 + j], o2 = (i32)T.close_off[min(16u + j, 20u)];
       const bool live = ag < n;
-      const u64 b0 = ballot(both(live, pm[live ? pa + o0 : 0] == CE_CELL_APPLE));
-      const u64 b1 = ballot(both(live, pm[live ? pa + o1 : 0] == CE_CELL_APPLE));
-      const u64 b2 = ballot(both(live && j < 5, pm[live ? pa + o2 : 0] == CE_CELL_APPLE));
+      const u64 b0 = ballot(both(live, pm[live ? pa + o0 : 0] == kApple));
+      const u64 b1 = ballot(both(live, pm[live ? pa + o1 : 0] == kApple));
+      const u64 b2 = ballot(both(live && j < 5, pm[live ? pa + o2 : 0] == kApple));
       const u32 sh8 = (lane & 7u) << 3;  // lane a < 8: its own byte of the three pair masks
       close_now = __builtin_popcount((u32)(b0 >> sh8) & 0xffu) + __builtin_popcount((u32)(b1 >> sh8) & 0xffu) +
                   __builtin_popcount((u32)(b2 >> sh8) & 0xffu);
@@ -1615,7 +1622,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     } else {
       for (u32 a = 0; a < n; ++a) {
         const u32 pa = rdl(E.P, a);
-        const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
+        const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == kApple);
         const u32 cnt = popc64(ballot(v));
         if (lane == a) close_now = cnt;
       }
@@ -1832,13 +1839,13 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 
   // eaten_apples: final position held an apple when the step was entered (nothing has touched
   // the map yet, so the pre-consume map IS the reference's current_apple_points)
-  const bool onA = both(E.is_agent, pm[E.is_agent ? E.P : 0] == CE_CELL_APPLE);
+  const bool onA = both(E.is_agent, pm[E.is_agent ? E.P : 0] == kApple);
   u32 eaten = onA ? 1u : 0u, eaten_close = 0, cleaned = 0;
   if (KIND == CE_KIND_HARVEST) {
     for (u64 om = ballot(onA); om; om &= om - 1) {  // count_apples_in_radius(5, pos) < 4
       const u32 a = ctz64(om);
       const u32 pa = rdl(E.P, a);
-      const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == CE_CELL_APPLE);
+      const bool v = both(lane < 21, pm[(i32)pa + (i32)T.close_off[lane < 21 ? lane : 0]] == kApple);
       const u32 cnt = popc64(ballot(v));
       if (lane == a && cnt < 4) eaten_close = 1;
     }
@@ -1855,7 +1862,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     }
     if (onA && first) E.RW += 1;
     wave_sync();
-    pm_put(pm, onA, E.P, CE_CELL_EMPTY);
+    pm_put(pm, onA, E.P, kEmpty);
     mark_agents(E);
   }
   {  // update_custom_moves: always shuffles the n ids, then fires in that order
