@@ -1151,7 +1151,30 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
       nH += popc64(ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
     }
-    waste_on = (T.apple_thresh[nH] & kWasteOnBit) != 0;
+    const u64 th = T.apple_thresh[nH];
+    waste_on = (th & kWasteOnBit) != 0;
+    if (th == 0) {
+      // waste density >= 0.4 (cleanup_new.py:357-359): both probabilities are zero, so nothing can spawn and the
+      // rand(222) call only moves the stream — about half the steps of a steady-state episode (the density hovers at
+      // the threshold: a spawned waste switches the model off until the next one is cleaned)
+      Rng& g = E.rng;
+      rng_assert_uniform(g);
+      if (g.pos >= (u32)kMtN) {
+        mt_twist(g.mt, lane);
+        g.twists += 1;
+        g.pos = 0;
+      }
+      const u32 left = (u32)kMtN - g.pos;
+      if (left < (u32)G::RANDW) {
+        mt_twist(g.mt, lane);
+        g.twists += 1;
+        g.pos = (u32)G::RANDW - left;
+      } else {
+        g.pos += (u32)G::RANDW;
+      }
+      g.ccount = 0;
+      return;
+    }
   }
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
@@ -1697,7 +1720,10 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #define CE_HARVEST_WAVES 8
 #endif
 #ifndef CE_CLEANUP_WAVES
-#define CE_CLEANUP_WAVES 7
+#define CE_CLEANUP_WAVES 8  // the step kernel: 64 VGPRs (two spilled dwords on a rare path) for the hardware maximum
+#endif
+#ifndef CE_CLEANUP_ROLLOUT_WAVES
+#define CE_CLEANUP_ROLLOUT_WAVES 7  // the fused loop carries more across its body: 72 VGPRs beat 64 with 33 spills
 #endif
 constexpr int kWavesPerBlock = 1;
 
@@ -2171,7 +2197,7 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
   return *(const T*)(cptr)(((u64)opaque_u32((u32)((u64)q >> 32)) << 32) | opaque_u32((u32)(u64)q));
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_ROLLOUT_WAVES : CE_HARVEST_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
