@@ -39,6 +39,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ce_config), offsetof(ce_config, env_index_base),
          offsetof(ce_config, contract_low), offsetof(ce_config, start_vel_ambulance), sizeof(ce_buffers),
          offsetof(ce_buffers, grid), offsetof(ce_buffers, error_flags));
+  printf("%zu %zu %zu %zu %zu %d\n", offsetof(ce_buffers, sd_info), sizeof(ce_traj), offsetof(ce_traj, obs),
+         offsetof(ce_traj, features), offsetof(ce_traj, sd_info), CE_ABI_VERSION);
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -47,9 +49,10 @@ int main(void) {
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(x) for x in subprocess.check_output([exe]).split()]
-    cfg, buf = _lib.CeConfig, _lib.CeBuffers
+    cfg, buf, traj = _lib.CeConfig, _lib.CeBuffers, _lib.CeTraj
     want = [C.sizeof(cfg), cfg.env_index_base.offset, cfg.contract_low.offset, cfg.start_vel_ambulance.offset,
-            C.sizeof(buf), buf.grid.offset, buf.error_flags.offset]
+            C.sizeof(buf), buf.grid.offset, buf.error_flags.offset,
+            buf.sd_info.offset, C.sizeof(traj), traj.obs.offset, traj.features.offset, traj.sd_info.offset, _lib.CE_ABI_VERSION]
     assert got == want
 
 

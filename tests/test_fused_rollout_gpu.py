@@ -40,19 +40,21 @@ def _same(a, b, fields, tag):
         assert x.tobytes() == y.tobytes(), "%s differs (%s)" % (f, tag)
 
 
-@pytest.mark.parametrize("kind,n,contract,firing,horizon,T,per", [
-    ("cleanup", 8, "cleanup", False, 1000, 1, 0),
-    ("cleanup", 8, "cleanup", False, 1000, 7, 0),
-    ("cleanup", 8, "cleanup", False, 25, 64, 0),       # auto-reset inside the launch, twice
-    ("cleanup", 8, "cleanup", False, 25, 64, 5),       # 13 launches of <= 5 steps
-    ("cleanup", 4, "cleanup", True, 1000, 40, 16),     # FIRE + CLEAN beams
-    ("cleanup", 9, None, True, 30, 50, 0),             # n = 9: odd feature pitch, serial paint path
-    ("harvest", 8, "harvest_local", False, 20, 64, 0),
-    ("harvest", 5, None, True, 1000, 33, 8),
+@pytest.mark.parametrize("kind,n,contract,firing,horizon,T,per,extra", [
+    ("cleanup", 8, "cleanup", False, 1000, 1, 0, None),
+    ("cleanup", 8, "cleanup", False, 1000, 7, 0, None),
+    ("cleanup", 8, "cleanup", False, 25, 64, 0, None),       # auto-reset inside the launch, twice
+    ("cleanup", 8, "cleanup", False, 25, 64, 5, None),       # 13 launches of <= 5 steps
+    ("cleanup", 4, "cleanup", True, 1000, 40, 16, None),     # FIRE + CLEAN beams
+    ("cleanup", 9, None, True, 30, 50, 0, None),             # n = 9: odd feature pitch, serial paint path
+    ("harvest", 8, "harvest_local", False, 20, 64, 0, None),
+    ("harvest", 5, None, True, 1000, 33, 8, None),
+    ("cleanup", 4, "cleanup", True, 20, 45, 0, dict(inequity=True, alpha=5.0, beta=0.05)),  # float reward accumulators
+    ("harvest", 3, "harvest_local", True, 1000, 30, 4, dict(collective=True)),
 ])
-def test_fused_equals_per_step(kind, n, contract, firing, horizon, T, per):
+def test_fused_equals_per_step(kind, n, contract, firing, horizon, T, per, extra):
     E = 193
-    kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True)
+    kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, **(extra or {}))
     fused, ref = _pair(kind, E, n, **kw)
     acts = _actions(fused, T)
     traj = fused.alloc_trajectory(T)
