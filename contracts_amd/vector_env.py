@@ -108,8 +108,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._fresh = list(range(self.num_envs))  # envs whose next poll returns a reset observation
         self._pending = None                       # env ids stepped by the last send_actions
         self._done_ids = set()                     # envs that reported done and have not been reset yet
-        self._reset_obs = {}                       # env_id -> reset observation of the current reset batch (None = lazy)
-        self._reset_lazy = None
+        self._reset_obs = {}                       # env_id -> reset observation (or the lazy map of its reset batch)
         self._acted = None                         # selfdrive: [E, n] which agents acted in the last step
 
     # ---- snapshots: one device -> host copy per field -------------------------------------------------------------
@@ -280,17 +279,15 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         else:
             snap = self._obs_fields()
             lazy = _LazyEnvMap(sorted(ids), lambda e: self._obs_of(snap, e))
-            self._reset_obs = {e: None for e in ids}
-            self._reset_lazy = lazy
+            for e in ids:  # entries of an earlier batch that were not collected yet stay valid
+                self._reset_obs[e] = lazy
         if env_id is None:
-            out = {e: self._take_reset(e) for e in sorted(ids)}
-            self._reset_obs = {}
-            return out
+            return {e: self._take_reset(e) for e in sorted(ids)}
         return {env_id: self._take_reset(env_id)}
 
     def _take_reset(self, e):
         v = self._reset_obs.pop(e)
-        return self._reset_lazy[e] if v is None else v
+        return v[e] if isinstance(v, _LazyEnvMap) else v
 
     def get_sub_environments(self, as_dict=False):
         return {} if as_dict else []

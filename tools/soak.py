@@ -1,5 +1,6 @@
 """Randomised soak: engine vs CPU oracle over random configurations (family, n, flags, horizon, policy mix),
-every persistent and output field compared after every step.  Usage: python tools/soak.py [seconds] [seed]"""
+every persistent and output field compared after every step — or, for half of the configurations, after every fused
+multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed]"""
 import sys
 import time
 import numpy as np
@@ -40,10 +41,26 @@ while time.time() < t_end:
         fields = [f for f in FIELDS if f not in ("spawn_perm", "obs")]
     T = int(rs.choice([40, 120]))
     ok = True
-    for t in range(T):
-        a = rs.choice(na, size=(E, n), p=p).astype(np.uint8)
-        env.step(a)
-        orc.step(a)
+    fused = rs.rand() < 0.5
+    t = 0
+    while t < T:
+        if fused:  # a chunk of steps in one launch on the engine, step by step on the oracle
+            import torch
+            c = int(min(T - t, rs.randint(1, 10)))
+            a = rs.choice(na, size=(c, E, n), p=p).astype(np.uint8)
+            if a.max() >= env.num_actions:  # (the effect-free extra action of the feature envs is a per-step code path)
+                a = np.minimum(a, env.num_actions - 1)
+            dev = torch.from_numpy(a).cuda()
+            env.rollout_fused(dev.data_ptr(), c, int(rs.choice([0, 2, 4])))
+            env.synchronize()
+            for k in range(c):
+                orc.step(a[k])
+            t += c
+        else:
+            a = rs.choice(na, size=(E, n), p=p).astype(np.uint8)
+            env.step(a)
+            orc.step(a)
+            t += 1
         for f in fields:
             x, y = (env.download(f, raw=True) if feat and f == "grid" else env.download(f)), getattr(orc, f)
             if f == "rng":
@@ -51,7 +68,7 @@ while time.time() < t_end:
             same = np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
             if not same:
                 bad = np.nonzero((x != y).reshape(E, -1).any(axis=1))[0]
-                print("MISMATCH", kind, n, kw, "field", f, "step", t, "envs", bad[:6])
+                print("MISMATCH", kind, n, kw, "fused" if fused else "per-step", "field", f, "step", t, "envs", bad[:6])
                 ok = False
                 break
         if not ok:
