@@ -2197,7 +2197,10 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
   return *(const T*)(cptr)(((u64)opaque_u32((u32)((u64)q >> 32)) << 32) | opaque_u32((u32)(u64)q));
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_ROLLOUT_WAVES : CE_HARVEST_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+#ifndef CE_HARVEST_ROLLOUT_WAVES
+#define CE_HARVEST_ROLLOUT_WAVES 7  // as for cleanup: 72 VGPRs and 3 spills beat 64 with 8 spilled registers in the loop (+2 %)
+#endif
+template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_ROLLOUT_WAVES : CE_HARVEST_ROLLOUT_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
