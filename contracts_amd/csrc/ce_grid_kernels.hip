@@ -1719,11 +1719,14 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #ifndef CE_HARVEST_WAVES
 #define CE_HARVEST_WAVES 8
 #endif
+// Launch bounds are chosen to keep the kernels out of scratch: a kernel with spilled VGPRs ran at two speeds on this
+// pool, process by process (the feature-env rollout with 17 spills: 1.57 G or 1.26 G agent-steps/s from the same binary
+// on the same box), and the step kernel at 8 waves with two spilled dwords was no faster than at 7 waves with none.
 #ifndef CE_CLEANUP_WAVES
-#define CE_CLEANUP_WAVES 8  // the step kernel: 64 VGPRs (two spilled dwords on a rare path) for the hardware maximum
+#define CE_CLEANUP_WAVES 7  // the step kernel: 66 VGPRs, no scratch
 #endif
 #ifndef CE_CLEANUP_ROLLOUT_WAVES
-#define CE_CLEANUP_ROLLOUT_WAVES 7  // the fused loop carries more across its body: 72 VGPRs beat 64 with 33 spills
+#define CE_CLEANUP_ROLLOUT_WAVES 7  // 72 VGPRs + 12 spilled: 3 % faster than 94 VGPRs at 5 waves without any
 #endif
 constexpr int kWavesPerBlock = 1;
 
@@ -2198,7 +2201,7 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 }
 
 #ifndef CE_HARVEST_ROLLOUT_WAVES
-#define CE_HARVEST_ROLLOUT_WAVES 7  // as for cleanup: 72 VGPRs and 3 spills beat 64 with 8 spilled registers in the loop (+2 %)
+#define CE_HARVEST_ROLLOUT_WAVES 6  // 76 VGPRs, no scratch (64 with 8 spilled registers in the loop: 2 % slower)
 #endif
 template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_ROLLOUT_WAVES : CE_HARVEST_ROLLOUT_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
@@ -3037,7 +3040,10 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
 
 // Fused multi-step rollout of the feature-vector envs (ce_rollout_fused): list stamps, agents and the CPython `random`
 // stream stay on chip for the steps of a launch (the np.random stream is only touched by resets, straight in HBM)
-template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+#ifndef CE_FEAT_ROLLOUT_WAVES
+#define CE_FEAT_ROLLOUT_WAVES 5  // 90-94 VGPRs, no scratch (see CE_CLEANUP_WAVES)
+#endif
+template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   __shared__ FeatLds<GK> lds;
@@ -3073,7 +3079,7 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_rollout(const 
     if (did_reset) theta = shfl_f64(theta, 0);
   }
   const GridParams& p = opaque_block(pp);
-  feat_store(E, p);
+  feat_store(E, p);  // (stamps and agents only: the static tables are not needed)
   if (E.lane == 0) {
     p.timestep[E.e] = (i32)t;
     if (any_reset) p.theta[E.e] = theta;
