@@ -1144,6 +1144,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   u32 rbase = 0;
   u32 nH = 0;
   bool waste_on = false;
+  bool scan = true;  // wave-uniform: some cell can spawn this step
   if (KIND == CE_KIND_CLEANUP) {
     // compute_probabilities: #H on the map -> host-precomputed 53-bit threshold
 #pragma unroll
@@ -1153,29 +1154,19 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
     const u64 th = T.apple_thresh[nH];
     waste_on = (th & kWasteOnBit) != 0;
-    if (th == 0) {
-      // waste density >= 0.4 (cleanup_new.py:357-359): both probabilities are zero, so nothing can spawn and the
-      // rand(222) call only moves the stream — about half the steps of a steady-state episode (the density hovers at
-      // the threshold: a spawned waste switches the model off until the next one is cleaned)
-      Rng& g = E.rng;
-      rng_assert_uniform(g);
-      if (g.pos >= (u32)kMtN) {
-        mt_twist(g.mt, lane);
-        g.twists += 1;
-        g.pos = 0;
-      }
-      const u32 left = (u32)kMtN - g.pos;
-      if (left < (u32)G::RANDW) {
-        mt_twist(g.mt, lane);
-        g.twists += 1;
-        g.pos = (u32)G::RANDW - left;
-      } else {
-        g.pos += (u32)G::RANDW;
-      }
-      g.ccount = 0;
-      return;
-    }
+    // waste density >= 0.4 (cleanup_new.py:357-359): both probabilities are zero, so nothing can spawn and the rand(222)
+    // call only moves the stream — about half the steps of a steady-state episode (the density hovers at the threshold:
+    // a spawned waste switches the model off until the next one is cleaned).  The per-cell work below is skipped then;
+    // the stream bookkeeping (window, twist) is shared with the full path.
+    scan = th != 0;
   }
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    elig[r] = false;
+    sa[r] = 0;
+    thrA[r] = 0;
+  }
+  if (scan) {
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const bool v = lane + 64 * r < (u32)G::NAPPLE;
@@ -1198,6 +1189,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     sa[r] = 2 * (rbase + popc64(eb & lt));
     rbase += popc64(eb);
   }
+  }
   CE_SUBSTAMP(11);
   // waste walk candidates: the t-th non-waste cell of the (shuffled) list gets double rbase + t
   const u32 ncand = (u32)G::NWASTE - nH;
@@ -1214,28 +1206,35 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   StreamWindow W = window_open<G::RANDW>(E.rng, lane);
   u32 wa[AR], wb[AR], ww[2] = {0, 0};
 #pragma unroll
-  for (int r = 0; r < AR; ++r) {
-    wa[r] = window_read_old(W, elig[r], sa[r]);
-    wb[r] = window_read_old(W, elig[r], sa[r] + 1);
-  }
-  if (KIND == CE_KIND_CLEANUP) {
+  for (int r = 0; r < AR; ++r) wa[r] = wb[r] = 0;
+  if (scan) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) ww[r] = window_read_old(W, needw[r], sw[r]);
+    for (int r = 0; r < AR; ++r) {
+      wa[r] = window_read_old(W, elig[r], sa[r]);
+      wb[r] = window_read_old(W, elig[r], sa[r] + 1);
+    }
+    if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) ww[r] = window_read_old(W, needw[r], sw[r]);
+    }
   }
   if (W.alen < (u32)G::RANDW) {  // the window runs into the next generation
     mt_twist(W.mt, lane);
     E.rng.twists += 1;
+    if (scan) {
 #pragma unroll
-    for (int r = 0; r < AR; ++r) {
-      wa[r] = window_read_new(W, elig[r], sa[r], wa[r]);
-      wb[r] = window_read_new(W, elig[r], sa[r] + 1, wb[r]);
-    }
-    if (KIND == CE_KIND_CLEANUP) {
+      for (int r = 0; r < AR; ++r) {
+        wa[r] = window_read_new(W, elig[r], sa[r], wa[r]);
+        wb[r] = window_read_new(W, elig[r], sa[r] + 1, wb[r]);
+      }
+      if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) ww[r] = window_read_new(W, needw[r], sw[r], ww[r]);
+        for (int r = 0; r < 2; ++r) ww[r] = window_read_new(W, needw[r], sw[r], ww[r]);
+      }
     }
   }
   window_close<G::RANDW>(E.rng, W);
+  if (!scan) return;
   bool spawnA[AR], tie[AR];
   bool any_tie = false;
 #pragma unroll
@@ -1721,9 +1720,10 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #endif
 // Launch bounds are chosen to keep the kernels out of scratch: a kernel with spilled VGPRs ran at two speeds on this
 // pool, process by process (the feature-env rollout with 17 spills: 1.57 G or 1.26 G agent-steps/s from the same binary
-// on the same box), and the step kernel at 8 waves with two spilled dwords was no faster than at 7 waves with none.
+// on the same box), and the step kernel at 8 waves with two spilled dwords was no faster than at 7 waves with none
+// (it is back at 8 waves without spills since the spawn skip shares the stream bookkeeping of the full path).
 #ifndef CE_CLEANUP_WAVES
-#define CE_CLEANUP_WAVES 7  // the step kernel: 66 VGPRs, no scratch
+#define CE_CLEANUP_WAVES 8  // the step kernel: 62 VGPRs, no scratch
 #endif
 #ifndef CE_CLEANUP_ROLLOUT_WAVES
 #define CE_CLEANUP_ROLLOUT_WAVES 7  // 72 VGPRs + 12 spilled: 3 % faster than 94 VGPRs at 5 waves without any
