@@ -57,6 +57,10 @@ class CeTraj(C.Structure):
                 ("reward", _P), ("done", _P), ("done_agents", _P), ("info", _P), ("features", _P), ("sd_info", _P)]
 
 
+class CeFieldReq(C.Structure):
+    _fields_ = [("field", C.c_char_p), ("dst", C.c_void_p), ("dst_bytes", C.c_uint64)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ce_abi_version": (C.c_int, []),
@@ -78,6 +82,7 @@ EXPORTS = {
     "ce_get_buffers": (C.c_int, [C.c_void_p, C.POINTER(CeBuffers)]),
     "ce_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ce_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ce_download_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeFieldReq), C.c_uint32]),
     "ce_upload": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
     "ce_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ce_timing_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -113,6 +113,9 @@ struct ce_engine {
   uint8_t* d_stage_actions;  // E*n*4 bytes
   uint8_t* d_stage_active;   // E*n
   unsigned long long* d_debug;  // E*16 phase stamps (diagnostic builds)
+  char* d_gather;               // ce_download_many: device-side staging of small requests (grown on demand)
+  size_t gather_bytes;
+  std::vector<char> h_gather;   // ... and its host landing buffer
   GridParams* d_gparams;        // device copy of the grid kernels' parameter block
   std::vector<std::pair<void**, size_t>> allocs;
   std::string err;
@@ -189,6 +192,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->d_stage_actions = nullptr;
   h->d_stage_active = nullptr;
   h->d_debug = nullptr;
+  h->d_gather = nullptr;
+  h->gather_bytes = 0;
   h->d_gparams = nullptr;
   std::memset(&h->buf, 0, sizeof(h->buf));
   *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
@@ -298,6 +303,7 @@ extern "C" int ce_destroy(ce_handle h) {
   (void)hipDeviceSynchronize();
   for (auto& a : h->allocs)
     if (*a.first) (void)hipFree(*a.first);
+  if (h->d_gather) (void)hipFree(h->d_gather);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   delete h;
@@ -732,6 +738,55 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "download", e);
+  return CE_OK;
+}
+
+extern "C" int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const ce_field_req* reqs, uint32_t count) {
+  if (!h || !reqs || count == 0) return CE_EINVAL;
+  (void)hipSetDevice(h->cfg.device);
+  if ((uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "slice out of range");
+  std::vector<FieldDesc> f(count);
+  size_t total = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (!reqs[i].field || !reqs[i].dst) return CE_EINVAL;
+    if (is_grid(h->cfg) && std::strcmp(reqs[i].field, "grid") == 0) return fail(h, CE_EINVAL, "ce_download_many: fetch \"grid\" with ce_download");
+    if (!find_field(h, reqs[i].field, &f[i])) return fail(h, CE_EINVAL, "unknown or absent field");
+    if (reqs[i].dst_bytes < (uint64_t)env_count * f[i].env_bytes) return fail(h, CE_EINVAL, "destination too small");
+    total += ((size_t)env_count * f[i].env_bytes + 15) & ~(size_t)15;
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "download_many sync", e);
+  constexpr size_t kGatherMax = 1u << 20;  // above this a staging pass would only double the traffic
+  if (total <= kGatherMax) {
+    if (h->gather_bytes < total) {
+      if (h->d_gather) (void)hipFree(h->d_gather);
+      h->d_gather = nullptr;
+      h->gather_bytes = 0;
+      const size_t want = total < 65536 ? 65536 : total;
+      if ((e = hipMalloc((void**)&h->d_gather, want)) != hipSuccess) return fail(h, CE_ENOMEM, "gather buffer", e);
+      h->gather_bytes = want;
+    }
+    size_t off = 0;
+    for (uint32_t i = 0; i < count && e == hipSuccess; ++i) {
+      const size_t bytes = (size_t)env_count * f[i].env_bytes;
+      e = hipMemcpyAsync(h->d_gather + off, (const char*)f[i].base + (size_t)env_begin * f[i].env_bytes, bytes, hipMemcpyDeviceToDevice, nullptr);
+      off += (bytes + 15) & ~(size_t)15;
+    }
+    if (h->h_gather.size() < total) h->h_gather.resize(total);
+    if (e == hipSuccess) e = hipMemcpy(h->h_gather.data(), h->d_gather, total, hipMemcpyDeviceToHost);  // null stream: after the gathers
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "download_many", e);
+    off = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+      const size_t bytes = (size_t)env_count * f[i].env_bytes;
+      std::memcpy(reqs[i].dst, h->h_gather.data() + off, bytes);
+      off += (bytes + 15) & ~(size_t)15;
+    }
+    return CE_OK;
+  }
+  for (uint32_t i = 0; i < count; ++i) {
+    e = hipMemcpy(reqs[i].dst, (const char*)f[i].base + (size_t)env_begin * f[i].env_bytes, (size_t)env_count * f[i].env_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "download_many", e);
+  }
   return CE_OK;
 }
 

@@ -125,6 +125,7 @@ class BatchedEnv:
         check(self._L.ce_get_buffers(self._h, C.byref(self.b)), self._h, "ce_get_buffers")
         self.num_actions = NUM_ACTIONS.get((kind, self.firing))
         self._tensors = None
+        self._pref = None  # prefetch(): host copies of several fields from ONE call, served by download() until the next launch
 
     # ---- lifecycle -------------------------------------------------------------------
     def close(self):
@@ -139,6 +140,7 @@ class BatchedEnv:
             pass
 
     def set_contract(self, contract, low=None, high=None, null_prob=0.0):
+        self._dirty()
         lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
         lo = lo if low is None else float(low)
         hi = hi if high is None else float(high)
@@ -149,6 +151,7 @@ class BatchedEnv:
 
     def set_flags(self, auto_reset=None, external_theta=None, beam_trace=None):
         """flip the run-time flags of the live handle (see ce_set_flags)"""
+        self._dirty()
         mask = value = 0
         for flag, v in ((_lib.FLAG_AUTO_RESET, auto_reset), (_lib.FLAG_EXTERNAL_THETA, external_theta),
                         (_lib.FLAG_BEAM_TRACE, beam_trace)):
@@ -161,6 +164,7 @@ class BatchedEnv:
     # ---- reference-protocol entry points ---------------------------------------------
     def seed(self, seeds=None, seed0=0, mask=None, replay_constructor=True):
         """np.random.seed(s) (+ random.seed(s)) then construct the env (see ce_seed)."""
+        self._dirty()
         s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         m = self._mask(mask)
         if s is not None and s.size != self.E:  # ce_seed reads E entries from the raw pointer
@@ -179,15 +183,18 @@ class BatchedEnv:
 
     def construct(self, mask=None):
         """replay the constructor's RNG use on the CURRENT generator state (no re-seed)"""
+        self._dirty()
         m = self._mask(mask)
         check(self._L.ce_seed(self._h, None, 0, None if m is None else m.ctypes.data, 2), self._h, "ce_seed")
 
     def reset(self, mask=None, stream=None):
+        self._dirty()
         m = self._mask(mask)
         check(self._L.ce_reset(self._h, None if m is None else m.ctypes.data, stream), self._h, "ce_reset")
 
     def step(self, actions, active=None, stream=None):
         """actions: host numpy array [E, n] (uint8 ids / float32 accelerations) — staged by the library."""
+        self._dirty()
         dt = np.float32 if self.kind == "selfdrive" else np.uint8
         a = np.ascontiguousarray(actions, dt).reshape(self.E, self.n)
         act = None if active is None else np.ascontiguousarray(active, np.uint8).reshape(self.E, self.n)
@@ -196,16 +203,19 @@ class BatchedEnv:
 
     def step_device(self, actions_ptr, active_ptr=None, stream=None):
         """actions_ptr: raw DEVICE pointer (int) to [E, n] actions already resident in HBM."""
+        self._dirty()
         check(self._L.ce_step(self._h, actions_ptr, active_ptr, stream), self._h, "ce_step")
 
     def step_range_device(self, actions_ptr, env_begin, env_count, active_ptr=None, stream=None):
         """step only envs [env_begin, env_begin+env_count); pointers address the full [E, n] planes"""
+        self._dirty()
         check(self._L.ce_step_range(self._h, actions_ptr, active_ptr, int(env_begin), int(env_count), stream), self._h,
               "ce_step_range")
 
     def rollout_device(self, actions_ptr, num_steps, stream_handles=None):
         """num_steps consecutive steps from pre-supplied device action planes [T, E, n]; the launch loop runs
         in C.  stream_handles: list of raw HIP stream handles, one env slice per stream (None = null stream)."""
+        self._dirty()
         if stream_handles:
             arr = (C.c_void_p * len(stream_handles))(*stream_handles)
             check(self._L.ce_rollout(self._h, actions_ptr, int(num_steps), len(stream_handles), arr), self._h, "ce_rollout")
@@ -218,6 +228,7 @@ class BatchedEnv:
         of its outputs — to its plane of `traj` (a Trajectory) or, without one, to the per-step buffers.  Bit-identical
         to num_steps step_device() calls (see ce_rollout_fused).  stream_handles: raw HIP stream handles, one contiguous
         env slice per stream (None = one slice on the null stream)."""
+        self._dirty()
         t = None if traj is None else C.byref(traj.c)
         ns, arr = 1, None
         if stream_handles:
@@ -258,9 +269,23 @@ class BatchedEnv:
             "beam_map": (b.grid_h, b.grid_w), "sd_info": (2,),
         }[field]
 
+    def prefetch(self, fields):
+        """fetch several fields in one call (ce_download_many); download() serves them until the next launch / upload"""
+        self._pref = self.download_many([f for f in fields if f in self._fields_present()])
+
+    def _fields_present(self):
+        b = self.b
+        return {f for f in _FIELD_DTYPES if f != "debug" and getattr(b, f, None)}
+
+    def _dirty(self):
+        self._pref = None
+
     def download(self, field, env_begin=0, env_count=None, raw=False):
         """host copy of a field; grid/obs are returned as [E,H,W] / [E,n,15,15,3] unless raw"""
         cnt = self.E - env_begin if env_count is None else env_count
+        if self._pref is not None and field in self._pref and env_begin == 0 and cnt == self.E:
+            out = self._pref[field]
+            return self._dense_obs(out) if (field == "obs" and not raw) else out
         out = np.empty((cnt,) + self._env_shape(field), _FIELD_DTYPES[field])
         check(self._L.ce_download(self._h, field.encode(), env_begin, cnt, out.ctypes.data, out.nbytes), self._h,
               "ce_download(%s)" % field)
@@ -273,6 +298,24 @@ class BatchedEnv:
             return np.ascontiguousarray(out.reshape(cnt, self.n, b.obs_agent_stride)[:, :, : 15 * b.obs_row_stride]
                                         .reshape(cnt, self.n, 15, b.obs_row_stride)[:, :, :, :45]).reshape(cnt, self.n, 15, 15, 3)
         return out
+
+    def download_many(self, fields, env_begin=0, env_count=None):
+        """{field: host array} for several fields of one env slice in one call (one device synchronize, one staged copy
+        for small slices — what the per-env adapters use for a whole step result).  Arrays come back RAW (obs pitched
+        as in HBM, see _dense_obs); "grid" is not accepted (download() expands it)."""
+        cnt = self.E - env_begin if env_count is None else env_count
+        out = {f: np.empty((cnt,) + self._env_shape(f), _FIELD_DTYPES[f]) for f in fields}
+        reqs = (_lib.CeFieldReq * len(fields))()
+        for i, f in enumerate(fields):
+            reqs[i].field, reqs[i].dst, reqs[i].dst_bytes = f.encode(), out[f].ctypes.data, out[f].nbytes
+        check(self._L.ce_download_many(self._h, env_begin, cnt, reqs, len(fields)), self._h, "ce_download_many")
+        return out
+
+    def _dense_obs(self, raw):
+        """pitched observation rows [cnt, obs_env_stride] -> dense uint8 [cnt, n, 15, 15, 3]"""
+        b, cnt = self.b, raw.shape[0]
+        return np.ascontiguousarray(raw.reshape(cnt, self.n, b.obs_agent_stride)[:, :, : 15 * b.obs_row_stride]
+                                    .reshape(cnt, self.n, 15, b.obs_row_stride)[:, :, :, :45]).reshape(cnt, self.n, 15, 15, 3)
 
     def _grid_image_stride(self):
         """bytes per env of the "grid" download / upload format: the padded map image for the grid kinds (the device
@@ -289,6 +332,7 @@ class BatchedEnv:
                                                strides=(raw.strides[0], b.grid_row_stride, 1))
 
     def upload(self, field, array, env_begin=0):
+        self._dirty()
         arr = np.asarray(array)
         cnt = arr.shape[0]
         if field == "grid" and arr.ndim == 3:

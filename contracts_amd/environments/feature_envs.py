@@ -68,14 +68,20 @@ class _FeatureEnv(_Base):
     def __setstate__(self, d):
         self.__dict__.update(d)
 
+    _RESULT_FIELDS = ("rng", "error_flags", "done", "base_reward", "reward", "info", "features", "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics", "theta")
+
     def _call(self, fn, *args):
+        """one engine call with the process-global generators mirrored around it; the whole result of the call is then
+        fetched in ONE copy (BatchedEnv.prefetch) and the download() calls that follow are served from it"""
         eng = self._ensure_engine()
         if self._rng_mode == "global":
             st = push_global_rng(eng, python_random=True)
             fn(*args)
+            eng.prefetch(self._RESULT_FIELDS)
             pull_global_rng(eng, st, python_random=True)
         else:
             fn(*args)
+            eng.prefetch(self._RESULT_FIELDS)
 
     def seed(self, seed=None):
         if self._rng_mode == "global":

@@ -57,14 +57,20 @@ class SelfAcceleratingCarEnv(_Base):
     def __setstate__(self, d):
         self.__dict__.update(d)
 
+    _RESULT_FIELDS = ("rng", "error_flags", "obs_f64", "base_reward", "reward", "done", "done_agents", "info", "sd_info", "f64_metrics", "theta")
+
     def _call(self, fn, *args):
+        """one engine call with the process-global generators mirrored around it; the whole result of the call is then
+        fetched in ONE copy (BatchedEnv.prefetch) and the download() calls that follow are served from it"""
         eng = self._ensure_engine()
         if self._rng_mode == "global":
             st = push_global_rng(eng, python_random=True)
             fn(*args)
+            eng.prefetch(self._RESULT_FIELDS)
             pull_global_rng(eng, st, python_random=True)
         else:
             fn(*args)
+            eng.prefetch(self._RESULT_FIELDS)
 
     def seed(self, seed=None):
         if self._rng_mode == "global":

@@ -338,6 +338,16 @@ int ce_synchronize(ce_handle h, void* stream);
 int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
 int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);
 
+/* Several fields of one env slice in ONE call (the per-env adapters fetch a whole step result this way): the device is
+ * synchronized once; small requests are gathered on the device into a staging buffer and leave in a single copy.
+ * "grid" (which needs the expand kernel) is not accepted here.  Same slice / size rules as ce_download. */
+typedef struct ce_field_req {
+  const char* field;   /* field name as for ce_download                       */
+  void* dst;           /* host pointer                                        */
+  uint64_t dst_bytes;  /* capacity of dst: >= env_count * bytes per env        */
+} ce_field_req;
+int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const ce_field_req* reqs, uint32_t count);
+
 /* Timing of the last N ce_step launches measured with HIP events on the launch stream
  * (bench.py roofline leg).  ce_timing_begin arms recording, ce_timing_end returns the mean
  * step-kernel duration in milliseconds and the number of launches measured. */
