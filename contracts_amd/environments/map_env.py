@@ -56,6 +56,23 @@ def pull_global_rng(engine, st, python_random=False):
         random.setstate((ps[0], tuple(int(x) for x in words[628:628 + 624]) + (int(words[628 + 624]),), ps[2]))
 
 
+def host_np_draw(env, fn):
+    """fn(rs) with `rs` the numpy stream the reference would draw from right now: the process-global np.random when the
+    adapter mirrors it (rng="global": it is in step with the engine between calls), else the env's private MT19937
+    inside the engine, fetched, advanced on the host and written back"""
+    if env._rng_mode == "global":
+        return fn(np.random)
+    eng = env._ensure_engine()
+    words = np.array(eng.download("rng"), np.uint32)
+    rs = np.random.RandomState()
+    rs.set_state(("MT19937", words[0, :624].copy(), int(words[0, 624])))
+    out = fn(rs)
+    st = rs.get_state()
+    words[0, :624], words[0, 624] = st[1], st[2]
+    eng.upload("rng", words)
+    return out
+
+
 class GridEnvAdapter(_Base):
     KIND = None          # "cleanup" | "harvest"
     GRID_SHAPE = None    # (H, W)

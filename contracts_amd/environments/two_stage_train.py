@@ -23,7 +23,7 @@ import random
 import numpy as np
 
 from .. import spaces
-from .map_env import _Base
+from .map_env import _Base, host_np_draw
 
 
 class SeparateContractEnv(_Base):
@@ -38,11 +38,15 @@ class SeparateContractEnv(_Base):
         self.contract_state = {"a" + str(i): 0 for i in range(self.num_agents)}
         self.convolutional = convolutional
         self.null_prob = null_prob
-        if getattr(contract, "engine_contract", None) is None:
-            raise NotImplementedError("contract %r has no fused engine epilogue" % type(contract).__name__)
-        base_env._contract = contract.engine_spec(null_prob)
-        if base_env._engine is not None:
-            base_env._engine.set_contract(*base_env._contract)
+        # one of the three contracts of contract_list.py: transfer + redistribution run as the step kernel's epilogue.
+        # Anything else (a user's Contract subclass) keeps the reference's host protocol: the engine steps the base
+        # env, `contract.compute_transfer` is called with the reference's arguments and the wrapper redistributes.
+        self._host_contract = getattr(contract, "engine_contract", None) is None
+        if not self._host_contract:
+            base_env._contract = contract.engine_spec(null_prob)
+            if base_env._engine is not None:
+                base_env._engine.set_contract(*base_env._contract)
+        self._host_transfers = 0
         self._external_theta(False)
         if self.convolutional:
             contract_space = spaces.Box(low=np.concatenate((self.contract_low, np.array([0.0]))),
@@ -61,6 +65,19 @@ class SeparateContractEnv(_Base):
 
     def _theta(self):
         return np.array([float(self.base_env._engine.download("theta")[0])])
+
+    def _draw_theta(self):
+        """two_stage_train.py:163-166 for a host contract: the same two draws, from the stream the base env's reset
+        has just advanced (the process-global np.random, or the env's private stream inside the engine)"""
+        def draw(rs):
+            if rs.rand() > self.null_prob:
+                return rs.uniform(low=self.contract_low, high=self.contract_high)
+            return self.contract_low
+        return host_np_draw(self.base_env, draw)
+
+    def _begin_episode(self):
+        self._host_transfers = 0
+        self.transferred_reward_dict = {"a" + str(i): [] for i in range(self.num_agents)}
 
     def _external_theta(self, on):
         """stages that take the contract parameter from an agent's action: the engine draws nothing at reset"""
@@ -82,7 +99,51 @@ class SeparateContractEnv(_Base):
             return out
         return {k: np.concatenate((obs[k], theta, np.array([0]))) for k in keys}
 
+    def _step_host_contract(self, acts):
+        """SeparateContractEnv.step of the reference (two_stage_train.py:62-121) around a user-defined contract: a
+        transfer is a number (split evenly over the other acting agents) or (value, {recipient: proportion})"""
+        raw_obs, base_rew, dones, infos = self.base_env.step(acts)
+        self.obs = {key: raw_obs[key] for key in acts.keys()}
+        transfers = self.contract.compute_transfer(self.obs, acts, base_rew, self.params, infos)
+        rews = {key: base_rew[key] for key in acts.keys()}
+        others = len(acts.keys()) - 1
+        total = 0
+        for i in range(self.num_agents):
+            payer = "a" + str(i)
+            if payer not in acts.keys():
+                continue
+            due = transfers[payer]
+            if type(due) is tuple:
+                amount, shares = due
+                rews[payer] -= amount
+                total += amount
+                for j in range(self.num_agents):
+                    payee = "a" + str(j)
+                    if payee in shares.keys() and payee in rews.keys():
+                        rews[payee] += amount * shares[payee]
+            else:
+                rews[payer] -= due
+                total += due
+                for j in range(self.num_agents):
+                    if i != j and "a" + str(j) in acts.keys():
+                        rews["a" + str(j)] += due / others
+        self._host_transfers += total
+        self.base_env.metrics["transfers"] = self._host_transfers  # the adapter rebuilds its metrics every step
+        for k, v in rews.items():
+            self.transferred_reward_dict[k].append(v)
+        if hasattr(self.base_env, "compute_sustainability") and dones["__all__"]:
+            self.base_env.metrics["transfer_sustainability"] = self.base_env.compute_sustainability(
+                copy.deepcopy(self.transferred_reward_dict))
+            self.base_env.metrics["transfer_equality"] = self.base_env.compute_equality(
+                copy.deepcopy(self.transferred_reward_dict))
+        keys = list(acts.keys())
+        for k in keys:
+            infos[k]["contract_param"] = self.params[k]
+        return self._with_contract(self.obs, keys), rews, dones, infos
+
     def step(self, acts):
+        if self._host_contract:
+            return self._step_host_contract(acts)
         raw_obs, base_rew, dones, infos = self.base_env.step(acts)
         keys = list(acts.keys())
         rew = self.base_env._engine.download("reward")[0]
@@ -107,7 +168,8 @@ class SeparateContractSubgameStage(SeparateContractEnv):
     def reset(self):
         # base reset + theta sampling happen in one engine call, in the reference's RNG order
         base_obs = self.base_env.reset()
-        rand_val = self._theta()
+        rand_val = self._draw_theta() if self._host_contract else self._theta()
+        self._begin_episode()
         self.contract_state = {"a" + str(i): 0 for i in range(self.num_agents)}
         self.params = {key: rand_val for key in ["a" + str(i) for i in range(self.num_agents)]}
         self.obs = base_obs
@@ -185,7 +247,7 @@ class _ProposalStages(SeparateContractEnv):
         self.last_seen_obs = copy.deepcopy(base_obs)
         self.params = None
         self.contract_state = {"a" + str(i): first_state for i in range(self.num_agents)}
-        self.transferred_reward_dict = {"a" + str(i): [] for i in range(self.num_agents)}
+        self._begin_episode()
         zeros = np.zeros(self.contract_low.shape)
         return self._stage_obs(self.obs, {k: zeros for k in self.contract_state})
 
@@ -316,7 +378,7 @@ class NegotiationSolver(SeparateContractEnv):
         self.last_seen_obs = copy.deepcopy(base_obs)
         self.params = None
         self.contract_state = {k: 0 for k in self._agents}
-        self.transferred_reward_dict = {k: [] for k in self._agents}
+        self._begin_episode()
         self.contract_param = self.negotiate()
         self.params = {k: self.contract_param for k in self._agents}
         self._set_theta(self.contract_param)

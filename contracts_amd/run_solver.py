@@ -8,14 +8,18 @@ steps ("batched evaluation of K sampled contracts x E envs on 
 
 `act_fn(obs, theta, t)` is the frozen policy: `obs` is the uint8 observation stack [K, n, 15, 15, 3] (grid kinds; divide
 by 255 for the reference's float view) or the feature rows [K, n, F] (feature kinds), `theta` the per-replica contract
-parameters [K]; it returns the integer actions [K, n].  Rewards are accumulated in the reference's order (step by step,
+parameters [K]; it returns the integer actions [K, n].  For 'selfdrive' `obs` is the float64 rows [K, n, 2n + 7] and
+the actions are accelerations; a car that is done stops acting (its key leaves the reference's dictionaries, so its
+action is ignored and its reward is not counted) and a replica whose episode ended idles while the others finish.
+Rewards are accumulated in the reference's order (step by step,
 agent by agent) so the totals are the same doubles `run_solver` would log."""
 import numpy as np
 
 from . import _lib
 from .engine import BatchedEnv
 
-_CONTRACT_KIND = {"CleanupContract": "cleanup", "HarvestFeaturemodLocalContract": "harvest_local"}
+_CONTRACT_KIND = {"CleanupContract": "cleanup", "HarvestFeaturemodLocalContract": "harvest_local",
+                  "SelfdriveContractDistprop": "selfdrive_distprop"}
 
 
 def evaluate_contracts(kind, num_agents, contract, thetas, seeds, act_fn, horizon=1000, device=0, **engine_kwargs):
@@ -26,8 +30,6 @@ def evaluate_contracts(kind, num_agents, contract, thetas, seeds, act_fn, horizo
     np.random.seed(seeds[k]), constructed the env and reset it.  Returns a dict with `ep_rewards` [K] (sum over agents
     and steps of the transferred rewards, run_solver.py:63-64), `agent_rewards` [K, n], `contract_param` [K], `steps`
     and the reference's summary statistics (`mean reward`, `std reward`, `mean contract`, `std contract`, :69-70)."""
-    if kind == "selfdrive":
-        raise NotImplementedError("selfdrive steps subsets of agents; evaluate it through the per-env adapter")
     thetas = np.ascontiguousarray(thetas, np.float64).reshape(-1)
     seeds = np.ascontiguousarray(seeds, np.uint64).reshape(-1)
     if thetas.shape != seeds.shape:
@@ -41,22 +43,33 @@ def evaluate_contracts(kind, num_agents, contract, thetas, seeds, act_fn, horizo
         env.seed(seeds)
         env.upload("theta", thetas)
         env.reset()
-        feat = kind in _lib.FEAT_KINDS
+        feat, cars = kind in _lib.FEAT_KINDS, kind == "selfdrive"
+        obs_field = "obs_f64" if cars else "features" if feat else "obs"
+        acting = np.ones((K, num_agents), bool)  # selfdrive: run_solver's active_agents, per replica
         agent_rewards = np.zeros((K, num_agents))
         ep_rewards = np.zeros(K)
         steps = 0
         done = np.zeros(K, bool)
         while not done.all() and steps < horizon:
-            obs = env.download("features") if feat else env.download("obs")
-            acts = np.ascontiguousarray(act_fn(obs, thetas, steps), np.uint8).reshape(K, num_agents)
-            env.step(acts)
-            r = env.download("reward")
+            acts = np.asarray(act_fn(env.download(obs_field), thetas, steps)).reshape(K, num_agents)
+            if cars:
+                env.step(acts.astype(np.float32), (acting & ~done[:, None]).astype(np.uint8))
+                r = np.where(acting & ~done[:, None], env.download("reward"), 0.0)
+            else:
+                env.step(acts.astype(np.uint8))
+                r = env.download("reward")
             for a in range(num_agents):  # ep_rewards += r[key] for key in env_obs, in key order
                 ep_rewards += r[:, a]
             agent_rewards += r
+            if cars:
+                acting &= ~env.download("done_agents").astype(bool)
             done = env.download("done").astype(bool)
             steps += 1
-        env.check_faults()
+        faults = env.download("error_flags").copy()
+        if cars:  # replicas that finished early were sent all-inactive steps: that is the idle bit, not a fault
+            faults[done] &= ~np.uint32(_lib.FAULT_STEP_AFTER_DONE)
+        if faults.any():
+            raise _lib.EngineError("env faults: %s" % {int(i): int(faults[i]) for i in np.nonzero(faults)[0][:8]})
     finally:
         env.close()
     return {"ep_rewards": ep_rewards, "agent_rewards": agent_rewards, "contract_param": thetas.copy(), "steps": steps,
