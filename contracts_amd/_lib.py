@@ -87,6 +87,7 @@ EXPORTS = {
     "ce_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ce_timing_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "ce_selftest": (C.c_int, [C.c_int, C.POINTER(C.c_uint32)]),
+    "ce_static_map": (C.c_int, [C.c_uint32, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ce_last_error": (C.c_char_p, [C.c_void_p]),
 }
 
@@ -131,3 +132,16 @@ def check(rc, handle=None, what=""):
             m = load().ce_last_error(handle)
             msg = m.decode() if m else ""
         raise EngineError("%s failed: %s (%d) %s" % (what, ERRORS.get(rc, "?"), rc, msg))
+
+
+def static_map(kind):
+    """the ASCII rows the engine's tables of a map kind are built from (ce_static_map) — a host-only call"""
+    L = load()
+    rows, cols = C.c_uint32(), C.c_uint32()
+    if L.ce_static_map(KIND[kind], None, 0, C.byref(rows), C.byref(cols)) != 0:
+        raise EngineError("%r has no map" % (kind,))
+    buf = C.create_string_buffer(rows.value * cols.value)
+    if L.ce_static_map(KIND[kind], buf, len(buf), None, None) != 0:
+        raise EngineError("ce_static_map(%r) failed" % (kind,))
+    text = buf.raw.decode("ascii")
+    return [text[r * cols.value:(r + 1) * cols.value] for r in range(rows.value)]

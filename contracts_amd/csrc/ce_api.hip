@@ -655,6 +655,20 @@ extern "C" uint64_t ce_synth_hash_host(uint64_t key, uint64_t env_index, uint32_
   return synth_hash(key, env_index, t, agent);
 }
 
+extern "C" int ce_static_map(uint32_t kind, char* out, uint64_t out_bytes, uint32_t* rows, uint32_t* cols) {
+  if (kind == CE_KIND_SELFDRIVE || kind > CE_KIND_CLEANUP_FEATURES) return CE_EINVAL;
+  const bool cleanup = kind == CE_KIND_CLEANUP || kind == CE_KIND_CLEANUP_FEATURES;
+  const uint32_t H = cleanup ? Geo<CE_KIND_CLEANUP>::H : Geo<CE_KIND_HARVEST>::H;
+  const uint32_t W = cleanup ? Geo<CE_KIND_CLEANUP>::W : Geo<CE_KIND_HARVEST>::W;
+  if (rows) *rows = H;
+  if (cols) *cols = W;
+  if (!out) return CE_OK;  // size query
+  if (out_bytes < (uint64_t)H * W) return CE_EINVAL;
+  const char** map = cleanup ? kCleanupMap : kHarvestMap;
+  for (uint32_t r = 0; r < H; ++r) std::memcpy(out + (size_t)r * W, map[r], W);
+  return CE_OK;
+}
+
 extern "C" int ce_get_buffers(ce_handle h, ce_buffers* out) {
   if (!h || !out) return CE_EINVAL;
   *out = h->buf;

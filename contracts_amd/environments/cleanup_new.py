@@ -9,6 +9,14 @@ from .map_env import GridEnvAdapter
 CLEANUP_VIEW_SIZE = 7
 
 
+def __getattr__(name):
+    # CLEANUP_MAP: the layout the engine's tables are built from, read from the library on first use
+    if name == "CLEANUP_MAP":
+        from .._lib import static_map
+        return static_map("cleanup")
+    raise AttributeError(name)
+
+
 class CleanupEnv(GridEnvAdapter):
     KIND = "cleanup"
     GRID_SHAPE = (25, 18)

@@ -7,10 +7,15 @@ The reference draws the spawn shuffle and the respawn doubles from the process-g
 orientations from the process-global `np.random`; with rng="global" (default) both generator states are handed to
 the engine before every call and installed again afterwards, so seeded scripts reproduce.
 
-`image_obs=True` (a crop of the reference's incrementally painted colour map) is not accelerated."""
+`HarvestFeatures(image_obs=True)` returns crops of the reference's incrementally painted colour map
+(harvest_features.py:124-125,259-264): a history-dependent rendering (a cell two agents shared turns black when the
+first one leaves), kept by the adapter on the host from the positions and apple lists the engine returns each step —
+it is a view for the demo `__main__`s, not part of the stepped state.  CleanupFeatures stores the flag and never reads
+it (cleanup_features.py:55), as here."""
 import numpy as np
 
 from .. import spaces
+from .._lib import static_map
 from ..engine import BatchedEnv
 from .map_env import _Base, pull_global_rng, push_global_rng
 
@@ -24,8 +29,6 @@ class _FeatureEnv(_Base):
     N_ACTIONS = None
 
     def __init__(self, num_agents=2, horizon=1000, image_obs=False, rng="global", device=0, **kwargs):
-        if image_obs:
-            raise NotImplementedError("image_obs=True of the feature envs is not accelerated (feature vectors only)")
         self.num_agents = num_agents
         self.horizon = horizon
         self.image_obs = image_obs
@@ -37,6 +40,7 @@ class _FeatureEnv(_Base):
         self.metrics = {}
         self._build_spaces()
         self._call(self._ensure_engine().construct)  # __init__ shuffles the spawn points and draws orientations
+        self._after_layout()
 
     # ------------------------------------------------------------------ engine plumbing
     def _ensure_engine(self):
@@ -53,6 +57,8 @@ class _FeatureEnv(_Base):
                     self._engine.upload(f, arr)
                 self._pending_state = None
         return self._engine
+
+    _paints = False  # HarvestFeatures(image_obs=True) only
 
     _STATE_FIELDS = ("grid", "agents", "rng", "timestep", "theta", "int_metrics", "f64_metrics", "final_int_metrics",
                      "final_f64_metrics")
@@ -118,11 +124,21 @@ class _FeatureEnv(_Base):
         # total_reward_dict holds per-step lists in the reference; the engine keeps the two sums the metrics need
         self._sum_r = [int(mi[4 + 2 * n + i]) for i in range(n)]
 
+    def _after_layout(self):
+        """constructor / reset hook: the agents have just been placed"""
+
+    def _after_step(self, actions):
+        pass
+
+    def _observations(self, keys):
+        return self._feature_obs(keys)
+
     def reset(self):
         self._call(self._ensure_engine().reset)
         self.timesteps = 0
         self._refresh_metrics(False)
-        return self._feature_obs(self._keys)
+        self._after_layout()
+        return self._observations(self._keys)
 
     def step(self, acts):
         keys = list(acts.keys())
@@ -137,12 +153,13 @@ class _FeatureEnv(_Base):
         done = bool(eng.download("done")[0])
         base = eng.download("base_reward")[0]
         info = eng.download("info")[0]
-        obs = self._feature_obs(keys)
+        feats = self._feature_obs(keys)
         rewards = {k: float(base[i]) for i, k in enumerate(self._keys)}
-        infos = self._infos(info, obs)
+        infos = self._infos(info, feats)
         dones = {"__all__": done, "a0": done, "a1": done}
         self._refresh_metrics(done)
-        return obs, rewards, dones, infos
+        self._after_step(a[0])
+        return (feats if not self._paints else self._observations(keys)), rewards, dones, infos
 
     def render(self):
         pass
@@ -173,6 +190,10 @@ class _FeatureEnv(_Base):
             self._engine = None
 
 
+HARVEST_VIEW_SIZE = 7
+_WALL_RGB, _APPLE_RGB, _PLAYER_RGB = (180, 180, 180), (0, 255, 0), (159, 67, 255)  # DEFAULT_COLOURS b"@", b"A", b"P" (harvest_features.py:39-57)
+
+
 class HarvestFeatures(_FeatureEnv):
     KIND = "harvest_features"
     N_ACTIONS = 7  # Discrete(7); the code path also accepts 7 (a fire action without effect)
@@ -180,6 +201,16 @@ class HarvestFeatures(_FeatureEnv):
     def _build_spaces(self):
         H, W = HARVEST_SHAPE
         na = N_APPLE[self.KIND]
+        self._paints = bool(self.image_obs)
+        if self._paints:
+            self.map = static_map(self.KIND)
+            self._apple_cells = np.array([(r, c) for r in range(H) for c in range(W) if self.map[r][c] == "A"])
+            self._wall = np.array([[ch == "@" for ch in row] for row in self.map])
+            self.observation_space = spaces.Box(low=0, high=255, shape=(2 * HARVEST_VIEW_SIZE + 1, 2 * HARVEST_VIEW_SIZE + 1, 3),
+                                                dtype=np.uint8)
+            self.action_space = spaces.Discrete(7)
+            self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(7,))
+            return
         self.observation_space = spaces.Box(low=np.array([0.0] * (10 + 2 * self.num_agents)),
                                             high=np.array([H, W, 4, H, W, 4, H, W, na + 1, na + 1] + [1] * (2 * self.num_agents)))
         self.action_space = spaces.Discrete(7)
@@ -192,6 +223,47 @@ class HarvestFeatures(_FeatureEnv):
     def _infos(self, info, obs):
         return {k: {"eaten_apples": int(info[i, 0]), "eaten_close_apples": int(info[i, 1]), "feature_obs": obs[k]}
                 for i, k in enumerate(self._keys)}
+
+    # ---- image_obs=True: the painted colour map (single_update_map, harvest_features.py:124-125) ----
+    def _state_now(self):
+        pos = self._engine.download("agents")[0][:, :2].astype(np.int64)
+        present = self._engine.feature_state()[0][0][:len(self._apple_cells)] != 0xFFFF
+        return pos, present
+
+    def _paint(self, cells, rgb):
+        self.world_map_color[cells[:, 0] + HARVEST_VIEW_SIZE, cells[:, 1] + HARVEST_VIEW_SIZE] = rgb
+
+    def _after_layout(self):
+        """__init__ / reset: a fresh map; initialize_arrays paints the walls and EVERY apple point (:99-113),
+        initialize_players the agents (:115-122)"""
+        if not self._paints:
+            return
+        H, W = HARVEST_SHAPE
+        self.world_map_color = np.zeros((H + 2 * HARVEST_VIEW_SIZE, W + 2 * HARVEST_VIEW_SIZE, 3), np.uint8)
+        self._paint(np.argwhere(self._wall), _WALL_RGB)
+        self._paint(self._apple_cells, _APPLE_RGB)
+        self._pos, self._present = self._state_now()
+        self._paint(self._pos, _PLAYER_RGB)
+
+    def _after_step(self, actions):
+        """a move that went through blackens the cell left and paints the cell entered, agent by agent in key order
+        (:194-195) — eating paints nothing more (:206); then the apples spawned this step turn green (:151)"""
+        if not self._paints:
+            return
+        pos, present = self._state_now()
+        for i in range(self.num_agents):
+            if actions[i] < 4 and (pos[i] != self._pos[i]).any():
+                self._paint(self._pos[i:i + 1], (0, 0, 0))
+                self._paint(pos[i:i + 1], _PLAYER_RGB)
+        self._paint(self._apple_cells[present & ~self._present], _APPLE_RGB)
+        self._pos, self._present = pos, present
+
+    def _observations(self, keys):
+        if not self._paints:
+            return self._feature_obs(keys)
+        w = 2 * HARVEST_VIEW_SIZE + 1
+        return {k: self.world_map_color[self._pos[int(k[1:])][0]:self._pos[int(k[1:])][0] + w,
+                                        self._pos[int(k[1:])][1]:self._pos[int(k[1:])][1] + w].copy() for k in keys}
 
 
 class CleanupFeatures(_FeatureEnv):

@@ -9,6 +9,14 @@ from .map_env import GridEnvAdapter
 HARVEST_VIEW_SIZE = 7
 
 
+def __getattr__(name):
+    # HARVEST_MAP: the layout the engine's tables are built from, read from the library on first use
+    if name == "HARVEST_MAP":
+        from .._lib import static_map
+        return static_map("harvest")
+    raise AttributeError(name)
+
+
 class HarvestEnv(GridEnvAdapter):
     KIND = "harvest"
     GRID_SHAPE = (16, 38)

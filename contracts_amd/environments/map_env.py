@@ -15,6 +15,7 @@ very same stream, interleaved correctly with any other user of `np.random` in th
 import numpy as np
 
 from .. import spaces
+from .._lib import static_map
 from ..engine import BatchedEnv
 
 try:  # the real base class when RLlib is installed, so RLlib's isinstance checks pass
@@ -81,8 +82,12 @@ class GridEnvAdapter(_Base):
     def __init__(self, ascii_map=None, num_agents=1, disable_firing=True, image_obs=True, return_agent_actions=False,
                  use_collective_reward=False, inequity_averse_reward=False, alpha=0.0, beta=0.0, horizon=1000,
                  one_hot_id=False, rng="global", device=0, **kwargs):
-        if ascii_map is not None:
-            raise NotImplementedError("custom ascii maps are not supported by the HIP engine (static map tables)")
+        if ascii_map is not None and [str(r) for r in ascii_map] != static_map(self.KIND):
+            # the reference's constructors pass their module's map explicitly (cleanup_new.py:62, harvest_new.py:51):
+            # that layout is accepted; any other one would need tables and per-map draw counts the kernels fix at
+            # compile time
+            raise NotImplementedError("the HIP engine steps the shipped %s layout only (ce_static_map); "
+                                      "other ascii maps are not supported" % self.KIND)
         if inequity_averse_reward:
             assert num_agents > 1, "Cannot use inequity aversion with only one agent!"  # map_env.py:294
         self.num_agents = num_agents

@@ -361,6 +361,11 @@ int ce_selftest(int device, uint32_t* failed_mask);
 /* 64-bit counter hash behind ce_synth_actions (selfdrive: action = ((hash>>40) / 2^24) * 0.2f - 0.1f) */
 uint64_t ce_synth_hash_host(uint64_t key, uint64_t env_index, uint32_t t, uint32_t agent);
 
+/* The ASCII layout the engine's static tables of a map kind are built from — the reference's CLEANUP_MAP
+ * (cleanup_new.py:10-36) / HARVEST_MAP (harvest_new.py:10-27), which the feature kinds share: rows*cols bytes,
+ * row-major, no terminators.  out == NULL only reports the shape.  CE_EINVAL for selfdrive (no map) or a short buffer. */
+int ce_static_map(uint32_t kind, char* out, uint64_t out_bytes, uint32_t* rows, uint32_t* cols);
+
 const char* ce_last_error(ce_handle h);
 
 #ifdef __cplusplus

@@ -111,6 +111,38 @@ def run_trace(R, kind, n, seed, T, episodes=2, contract=True, horizon=1000, acti
     return out
 
 
+def run_image_trace(R, n, seed, T, horizon):
+    """HarvestFeatures(image_obs=True): the observations are crops of the incrementally painted colour map
+    (harvest_features.py:124-125,259-264); the feature rows still travel in the infos"""
+    from environments.harvest_features import HarvestFeatures
+    np.random.seed(seed)
+    random.seed(seed)
+    env = HarvestFeatures(num_agents=n, horizon=horizon, image_obs=True)
+    keys = ["a%d" % i for i in range(n)]
+    ars = np.random.RandomState(seed + 1)
+    rec = {k: [] for k in ("actions", "obs", "feature_obs", "rew", "done", "ep_start", "reset_obs", "world")}
+    out = {"kind": "harvest_features", "n": n, "seed": seed, "horizon": horizon,
+           "obs_space_shape": np.array(env.observation_space.shape), "ctor_world": env.world_map_color.copy()}
+    step_idx = 0
+    for ep, steps in enumerate(T):
+        o = env.reset()
+        rec["ep_start"].append(step_idx)
+        rec["reset_obs"].append(np.stack([np.array(o[k]) for k in keys]))
+        for t in range(steps):
+            a = ars.choice(7, size=n, p=[.2, .2, .2, .2, .1, .05, .05])
+            o, r, d, info = env.step({k: int(a[i]) for i, k in enumerate(keys)})
+            rec["actions"].append(a.astype(np.uint8))
+            rec["obs"].append(np.stack([np.array(o[k]) for k in keys]))
+            rec["feature_obs"].append(np.stack([np.asarray(info[k]["feature_obs"], np.float64) for k in keys]))
+            rec["rew"].append(np.array([float(r[k]) for k in keys]))
+            rec["done"].append(np.uint8(d["__all__"]))
+            rec["world"].append(int(hashlib.sha256(env.world_map_color.tobytes()).hexdigest()[:8], 16))
+            step_idx += 1
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    return out
+
+
 def main():
     R = load_reference()
     S0 = 73907
@@ -125,6 +157,11 @@ def main():
         "feat_cleanup_n8_nocontract": dict(kind="cleanup_features", n=8, seed=S0 + 45, T=[150, 40], horizon=150, contract=False),
     }
     only = set(sys.argv[1:])
+    if not only or "featimg_harvest_n6" in only:  # not a feat_* name: the oracle replays skip it (adapter-level rendering)
+        out = run_image_trace(R, n=6, seed=S0 + 46, T=[260, 60], horizon=260)
+        path = os.path.join(HERE, "featimg_harvest_n6.npz")
+        np.savez_compressed(path, **out)
+        print("%-30s steps=%5d  %7.1f KB" % ("featimg_harvest_n6", len(out["actions"]), os.path.getsize(path) / 1024))
     for name, kw in jobs.items():
         if only and name not in only:
             continue

@@ -602,6 +602,57 @@ def test_batched_selfdrive_contract_evaluation_matches_sequential_episodes():
     np.testing.assert_allclose(got["ep_rewards"], np.array(want, np.float64), rtol=0, atol=1e-9)
 
 
+def test_harvest_features_image_obs_trace():
+    """HarvestFeatures(image_obs=True) against the reference's trace: crops of the incrementally painted colour map
+    (incl. the steps where a cell two agents shared has turned black under the one that stayed), the whole map's hash,
+    the feature rows in the infos; plus a pickle round trip in mid-episode"""
+    from contracts_amd.environments.feature_envs import CleanupFeatures, HarvestFeatures
+    g = gc.load("featimg_harvest_n6")
+    n, seed = int(g["n"]), int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    env = HarvestFeatures(num_agents=n, horizon=int(g["horizon"]), image_obs=True)
+    assert env.observation_space.shape == tuple(g["obs_space_shape"]) and env.observation_space.dtype == np.uint8
+    assert np.array_equal(env.world_map_color, g["ctor_world"])
+    keys = ["a%d" % i for i in range(n)]
+    ep_start = list(g["ep_start"]) + [len(g["actions"])]
+    quirk = 0
+    for ep in range(len(g["ep_start"])):
+        o = env.reset()
+        assert np.array_equal(np.stack([o[k] for k in keys]), g["reset_obs"][ep])
+        for t in range(ep_start[ep], ep_start[ep + 1]):
+            if t == 100:
+                env = pickle.loads(pickle.dumps(env))
+            o, r, d, info = env.step({k: int(g["actions"][t][i]) for i, k in enumerate(keys)})
+            got = np.stack([o[k] for k in keys])
+            assert got.dtype == np.uint8 and np.array_equal(got, g["obs"][t]), t
+            assert int(hashlib.sha256(env.world_map_color.tobytes()).hexdigest()[:8], 16) == int(g["world"][t]), t
+            assert np.array_equal(np.stack([info[k]["feature_obs"] for k in keys]), g["feature_obs"][t])
+            assert [float(r[k]) for k in keys] == list(g["rew"][t]) and d["__all__"] == bool(g["done"][t])
+            quirk += int((got[:, 7, 7] != np.array([159, 67, 255])).any())
+    assert quirk > 0
+    env.close()
+    c = CleanupFeatures(num_agents=2, image_obs=True)  # the reference stores the flag and never reads it
+    assert c.image_obs and c.reset()["a0"].shape == (14,)
+    c.close()
+
+
+def test_shipped_ascii_map_is_accepted_and_others_are_refused():
+    from contracts_amd.environments import cleanup_new, harvest_new
+    assert len(cleanup_new.CLEANUP_MAP) == 25 and len(harvest_new.HARVEST_MAP[0]) == 38
+    first = []
+    for kw in (dict(ascii_map=cleanup_new.CLEANUP_MAP), {}):  # the former is what the reference's default argument does
+        np.random.seed(3)
+        env = cleanup_new.CleanupEnv(num_agents=2, **kw)
+        first.append(env.reset())
+        env.close()
+    assert all(np.array_equal(first[0][k]["image"], first[1][k]["image"]) for k in ("a0", "a1"))
+    other = list(harvest_new.HARVEST_MAP)
+    other[3] = other[3].replace("A", " ", 1)
+    with pytest.raises(NotImplementedError, match="shipped harvest layout"):
+        harvest_new.HarvestEnv(ascii_map=other, num_agents=2)
+
+
 def test_run_rendering_writes_episode_videos(tmp_path):
     """run_render.py's loop over the drop-in env: frames from device state, one file per rendered episode"""
     from contracts_amd.environments.cleanup_new import CleanupEnv

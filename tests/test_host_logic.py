@@ -123,3 +123,22 @@ def test_video_export_nearest_upscale(tmp_path):
         for i in range(4):
             im.seek(i)
             assert np.array_equal(np.asarray(im.convert("RGB"))[::20, ::20], frames[i])
+
+
+def test_static_map_matches_the_fixture_tables():
+    """ce_static_map (no GPU needed): the layout the engine builds its tables from, against the apple / spawn / waste
+    point lists the reference's own envs reported when the fixtures were made"""
+    import golden_check as gc
+    from contracts_amd import _lib
+    for kind, fixture in (("harvest_features", "feat_harvest_n2"), ("cleanup_features", "feat_cleanup_n2")):
+        rows = _lib.static_map(kind)
+        g = gc.load(fixture)
+        apple = "A" if kind.startswith("harvest") else "B"
+        cells = lambda chars: [[r, c] for r, row in enumerate(rows) for c, ch in enumerate(row) if ch in chars]
+        assert cells(apple) == g["apple_points"].tolist() and cells("P") == g["spawn_points"].tolist()
+        if kind.startswith("cleanup"):
+            assert cells("HR") == g["waste_points"].tolist()
+    assert _lib.static_map("harvest") == _lib.static_map("harvest_features")
+    import pytest
+    with pytest.raises(_lib.EngineError):
+        _lib.static_map("selfdrive")
