@@ -121,6 +121,8 @@ struct ce_engine {
   std::string err;
   // timing
   hipEvent_t ev_start, ev_stop;
+  hipEvent_t ev_mask;  // recorded behind the last launch that reads d_mask: the staging buffer is reused only after it
+  bool mask_in_flight;
   bool timing_armed;
   uint32_t timed_launches;
 };
@@ -166,17 +168,21 @@ static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.
 static bool is_feat(const ce_config& c) { return c.kind == CE_KIND_HARVEST_FEATURES || c.kind == CE_KIND_CLEANUP_FEATURES; }
 static bool u8_actions(const ce_config& c) { return is_grid(c) || is_feat(c); }  // one byte per agent (selfdrive: float32)
 
+static int contract_ok(uint32_t kind, uint32_t contract) {
+  if (contract == CE_CONTRACT_NONE) return 1;
+  if (kind == CE_KIND_CLEANUP) return contract == CE_CONTRACT_CLEANUP;
+  if (kind == CE_KIND_HARVEST || kind == CE_KIND_HARVEST_FEATURES) return contract == CE_CONTRACT_HARVEST_LOCAL;
+  if (kind == CE_KIND_CLEANUP_FEATURES) return contract == CE_CONTRACT_CLEANUP;
+  return contract == CE_CONTRACT_SELFDRIVE_DISTPROP;
+}
+
 extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (!cfg || !out) return CE_EINVAL;
   *out = nullptr;
   if (cfg->abi_version != CE_ABI_VERSION || cfg->kind > CE_KIND_CLEANUP_FEATURES || cfg->num_envs == 0) return CE_EINVAL;
   const uint32_t maxn = cfg->kind == CE_KIND_SELFDRIVE ? 10 : kMaxGridAgents;
   if (cfg->num_agents < 1 || cfg->num_agents > maxn) return CE_EINVAL;
-  if (cfg->kind == CE_KIND_CLEANUP && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_CLEANUP) return CE_EINVAL;
-  if (cfg->kind == CE_KIND_HARVEST && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
-  if (cfg->kind == CE_KIND_SELFDRIVE && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_SELFDRIVE_DISTPROP) return CE_EINVAL;
-  if (cfg->kind == CE_KIND_CLEANUP_FEATURES && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_CLEANUP) return CE_EINVAL;
-  if (cfg->kind == CE_KIND_HARVEST_FEATURES && cfg->contract != CE_CONTRACT_NONE && cfg->contract != CE_CONTRACT_HARVEST_LOCAL) return CE_EINVAL;
+  if (!contract_ok(cfg->kind, cfg->contract)) return CE_EINVAL;
   if (is_feat(*cfg) && (cfg->flags & (CE_FLAG_COLLECTIVE_REWARD | CE_FLAG_INEQUITY_AVERSE | CE_FLAG_FIRING_ENABLED))) return CE_EINVAL;
   if ((cfg->flags & CE_FLAG_INEQUITY_AVERSE) && cfg->num_agents < 2) return CE_EINVAL;  // map_env.py:294 assertion
   if ((cfg->flags & CE_FLAG_BEAM_TRACE) && !is_grid(*cfg)) return CE_EINVAL;
@@ -186,6 +192,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->cfg = *cfg;
   if (h->cfg.horizon == 0) h->cfg.horizon = 1000;
   h->timing_armed = false;
+  h->mask_in_flight = false;
   h->timed_launches = 0;
   h->d_seeds = nullptr;
   h->d_mask = nullptr;
@@ -206,7 +213,9 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail(h, CE_ENODEV, "hipGetDeviceProperties", e);
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(h, CE_ENODEV, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
-  if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) return fail(h, CE_ENODEV, "hipEventCreate");
+  if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming) != hipSuccess)
+    return fail(h, CE_ENODEV, "hipEventCreate");
 
   const size_t E = cfg->num_envs, n = cfg->num_agents;
   ce_buffers& b = h->buf;
@@ -254,9 +263,15 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (is_grid(*cfg) || is_feat(*cfg)) {
     // static tables (process-wide constants; re-uploading identical bytes is harmless)
     if (rc == CE_OK) {
-      static GridTables t0, t1;
-      build_tables<CE_KIND_CLEANUP>(t0);
-      build_tables<CE_KIND_HARVEST>(t1);
+      struct BothTables {
+        GridTables cleanup, harvest;
+        BothTables() {
+          build_tables<CE_KIND_CLEANUP>(cleanup);
+          build_tables<CE_KIND_HARVEST>(harvest);
+        }
+      };
+      static const BothTables built;  // once per process (thread-safe static); uploaded to this handle's device below
+      const GridTables &t0 = built.cleanup, &t1 = built.harvest;
       const uint32_t lut[16] = {rgb(0, 0, 0),       rgb(180, 180, 180), rgb(0, 255, 0),     rgb(99, 156, 194),
                                 rgb(113, 75, 24),   rgb(113, 75, 24),   rgb(0, 0, 255),     rgb(2, 81, 154),
                                 rgb(204, 0, 204),   rgb(216, 30, 54),   rgb(254, 151, 0),   rgb(100, 255, 255),
@@ -306,16 +321,9 @@ extern "C" int ce_destroy(ce_handle h) {
   if (h->d_gather) (void)hipFree(h->d_gather);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+  if (h->ev_mask) (void)hipEventDestroy(h->ev_mask);
   delete h;
   return CE_OK;
-}
-
-static int contract_ok(uint32_t kind, uint32_t contract) {
-  if (contract == CE_CONTRACT_NONE) return 1;
-  if (kind == CE_KIND_CLEANUP) return contract == CE_CONTRACT_CLEANUP;
-  if (kind == CE_KIND_HARVEST || kind == CE_KIND_HARVEST_FEATURES) return contract == CE_CONTRACT_HARVEST_LOCAL;
-  if (kind == CE_KIND_CLEANUP_FEATURES) return contract == CE_CONTRACT_CLEANUP;
-  return contract == CE_CONTRACT_SELFDRIVE_DISTPROP;
 }
 
 extern "C" int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob) {
@@ -430,7 +438,12 @@ static int check_launch(ce_engine* h, const char* what) {
 static int stage_mask(ce_engine* h, const uint8_t* mask, hipStream_t s, const uint8_t** dmask) {
   *dmask = nullptr;
   if (!mask) return CE_OK;
-  hipError_t e = hipMemcpyAsync(h->d_mask, mask, h->cfg.num_envs, hipMemcpyHostToDevice, s);
+  hipError_t e = hipSuccess;
+  if (h->mask_in_flight) {  // a masked launch on another stream may not have read the previous mask yet
+    if ((e = hipEventSynchronize(h->ev_mask)) != hipSuccess) return fail(h, CE_ENODEV, "mask staging wait", e);
+    h->mask_in_flight = false;
+  }
+  e = hipMemcpyAsync(h->d_mask, mask, h->cfg.num_envs, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "mask upload", e);
   // the host buffer may be reused by the caller right away
   if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(h, CE_ENODEV, "mask upload sync", e);
@@ -505,6 +518,7 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
     p.mask = dmask;
     launch_sd_reset(p, stream);
   }
+  if (dmask && hipEventRecord(h->ev_mask, (hipStream_t)stream) == hipSuccess) h->mask_in_flight = true;
   return check_launch(h, "reset kernel");
 }
 

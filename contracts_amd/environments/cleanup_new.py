@@ -32,11 +32,3 @@ class CleanupEnv(GridEnvAdapter):
 
     def _info_entry(self, eaten, second):
         return {"eaten_apples": eaten, "cleaned_squares": second}
-
-    def _metrics_from(self, mi, mf):
-        n = self.num_agents
-        m = {"total_apples_eaten": int(mi[0]), "raw_env_rewards": self._raw_env_rewards(mi, mf), "transfers": float(mf[0]) if self._contract[0] else 0,
-             "dirt_cleaned": int(mi[2])}
-        for i in range(n):
-            m["a%d-waste_cleaned" % i] = int(mi[4 + i])
-        return m

@@ -18,6 +18,7 @@ from .. import spaces
 from .._lib import static_map
 from ..engine import BatchedEnv
 from .map_env import _Base, pull_global_rng, push_global_rng
+from .metrics import episode_metrics
 
 HARVEST_SHAPE, CLEANUP_SHAPE = (16, 38), (25, 18)
 N_APPLE = {"harvest_features": 155, "cleanup_features": 103}
@@ -116,11 +117,7 @@ class _FeatureEnv(_Base):
         eng, n = self._engine, self.num_agents
         mi = eng.download("final_int_metrics" if final else "int_metrics")[0]
         mf = eng.download("final_f64_metrics" if final else "f64_metrics")[0]
-        self.metrics = self._metrics_dict(mi, mf)
-        if final:
-            self.metrics["equality"], self.metrics["sustainability"] = float(mf[1]), float(mf[2])
-            if self._contract[0] is not None:
-                self.metrics["transfer_equality"], self.metrics["transfer_sustainability"] = float(mf[3]), float(mf[4])
+        self.metrics = episode_metrics(self.KIND, n, mi, mf, final, contract=self._contract[0] is not None)
         # total_reward_dict holds per-step lists in the reference; the engine keeps the two sums the metrics need
         self._sum_r = [int(mi[4 + 2 * n + i]) for i in range(n)]
 
@@ -216,10 +213,6 @@ class HarvestFeatures(_FeatureEnv):
         self.action_space = spaces.Discrete(7)
         self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(7,))
 
-    def _metrics_dict(self, mi, mf):
-        return {"total_apples_eaten": int(mi[0]), "low_density_apples_eaten": int(mi[3]), "raw_env_rewards": float(mi[1]),
-                "transfers": float(mf[0]) if self._contract[0] is not None else 0}
-
     def _infos(self, info, obs):
         return {k: {"eaten_apples": int(info[i, 0]), "eaten_close_apples": int(info[i, 1]), "feature_obs": obs[k]}
                 for i, k in enumerate(self._keys)}
@@ -278,10 +271,6 @@ class CleanupFeatures(_FeatureEnv):
                                                            self.potential_waste_area + 1] + [np.inf] * self.num_agents))
         self.action_space = spaces.Discrete(8)
         self.continuous_action_space = spaces.Box(low=-10.0, high=10.0, shape=(8,))
-
-    def _metrics_dict(self, mi, mf):
-        return {"dirt_cleaned": int(mi[2]), "raw_env_rewards": float(mi[1]),
-                "transfers": float(mf[0]) if self._contract[0] is not None else 0}
 
     def _infos(self, info, obs):
         return {k: {"cleaned_squares": int(info[i, 1])} for i, k in enumerate(self._keys)}

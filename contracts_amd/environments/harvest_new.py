@@ -32,12 +32,3 @@ class HarvestEnv(GridEnvAdapter):
 
     def _info_entry(self, eaten, second):
         return {"eaten_apples": eaten, "eaten_close_apples": second}
-
-    def _metrics_from(self, mi, mf):
-        n = self.num_agents
-        m = {"total_apples_eaten": int(mi[0]), "low_density_apples_eaten": int(mi[3]), "raw_env_rewards": self._raw_env_rewards(mi, mf),
-             "transfers": float(mf[0]) if self._contract[0] else 0}
-        for i in range(n):
-            m["a%d-apples_consumed" % i] = int(mi[4 + i])
-            m["a%d-close_apples_consumed" % i] = int(mi[4 + n + i])
-        return m

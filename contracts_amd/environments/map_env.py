@@ -17,6 +17,7 @@ import numpy as np
 from .. import spaces
 from .._lib import static_map
 from ..engine import BatchedEnv
+from .metrics import episode_metrics
 
 try:  # the real base class when RLlib is installed, so RLlib's isinstance checks pass
     from ray.rllib.env import MultiAgentEnv as _Base  # pragma: no cover
@@ -337,20 +338,11 @@ class GridEnvAdapter(_Base):
             avg_times.append(t_sum / denom)
         return np.mean(avg_times)
 
-    def _raw_env_rewards(self, mi, mf):
-        """metrics['raw_env_rewards']: an int, or — under inequity aversion, where the env's rewards are floats and the
-        reference sums those (cleanup_new.py:229-234) — the float accumulator CE_MF_RAW_ENV_REWARDS_F"""
-        return float(mf[5 + 2 * self.num_agents]) if self.inequity_averse_reward else int(mi[1])
-
     def _refresh_metrics(self, final):
         eng = self._engine
         self._set_metrics(eng.download("final_int_metrics" if final else "int_metrics")[0],
                           eng.download("final_f64_metrics" if final else "f64_metrics")[0], final)
 
     def _set_metrics(self, mi, mf, final):
-        m = self._metrics_from(mi, mf)
-        if final:
-            m["equality"], m["sustainability"] = float(mf[1]), float(mf[2])
-            if self._contract[0] is not None:
-                m["transfer_equality"], m["transfer_sustainability"] = float(mf[3]), float(mf[4])
-        self.metrics = m
+        self.metrics = episode_metrics(self.KIND, self.num_agents, mi, mf, final, contract=self._contract[0] is not None,
+                                       inequity=self.inequity_averse_reward)

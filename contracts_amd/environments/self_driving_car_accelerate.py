@@ -6,6 +6,7 @@ import numpy as np
 
 from .. import spaces
 from ..engine import BatchedEnv
+from .metrics import episode_metrics
 from .map_env import _Base, pull_global_rng, push_global_rng
 
 ACCEL_LOW_THRESH, ACCEL_HIGH_THRESH = -0.1, 0.1
@@ -143,7 +144,7 @@ class SelfAcceleratingCarEnv(_Base):
         r = {k: float(base[int(k[1:])]) for k in keys}
         if int(self._engine.download("info")[0][int(keys[0][1:]), 1]):  # crash: every car is penalised, acting or not (:211)
             r = {k: -10000.0 for k in self._keys}
-        self.metrics = {"transfers": float(self._engine.download("f64_metrics")[0][0])}
+        self.metrics = episode_metrics("selfdrive", self.num_agents, None, self._engine.download("f64_metrics")[0], False)
         return self._base_obs(keys), r, self._dones(), self._infos(keys)
 
     def render(self, mode="rgb"):

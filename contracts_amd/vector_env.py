@@ -26,6 +26,7 @@ import numpy as np
 
 from . import _lib
 from .engine import BatchedEnv
+from .environments.metrics import episode_metrics
 
 try:  # pragma: no cover - RLlib is absent in the build image
     from ray.rllib.env import BaseEnv as _RLlibBaseEnv
@@ -94,6 +95,47 @@ class _LazyEnvMap(Mapping):
         return len(self._ids)
 
 
+class _SubEnvView:
+    """one sub-env as callbacks see it: `.metrics` (computed on access), `.base_env` (the reference's wrapper chain)"""
+
+    def __init__(self, venv, env_id):
+        self._venv, self.env_id = venv, env_id
+
+    @property
+    def metrics(self):
+        return self._venv.env_metrics(self.env_id)
+
+    @property
+    def base_env(self):
+        return self
+
+    @property
+    def num_agents(self):
+        return self._venv.num_agents
+
+
+class _SubEnvs:
+    """list-like over the E sub-env views, built on access (nobody wants 16 384 objects per worker)"""
+
+    def __init__(self, venv):
+        self._venv = venv
+
+    def __len__(self):
+        return self._venv.num_envs
+
+    def __getitem__(self, e):
+        if isinstance(e, slice):
+            return [self[i] for i in range(*e.indices(len(self)))]
+        if e < 0:
+            e += len(self)
+        if not 0 <= e < len(self):
+            raise IndexError(e)
+        return _SubEnvView(self._venv, e)
+
+    def __iter__(self):
+        return (self[e] for e in range(len(self)))
+
+
 class BatchedBaseEnv(_RLlibBaseEnv):
     def __init__(self, kind, num_envs, num_agents, contract=None, seed0=73907, convolutional=True, **engine_kwargs):
         self.kind, self.num_envs, self.num_agents = kind, int(num_envs), int(num_agents)
@@ -108,6 +150,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._fresh = list(range(self.num_envs))  # envs whose next poll returns a reset observation
         self._pending = None                       # env ids stepped by the last send_actions
         self._done_ids = set()                     # envs that reported done and have not been reset yet
+        self._episode_over = set()                 # envs whose last step ended an episode (metrics: the final rows)
         self._reset_obs = {}                       # env_id -> reset observation (or the lazy map of its reset batch)
         self._acted = None                         # selfdrive: [E, n] which agents acted in the last step
 
@@ -204,6 +247,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         elif self.kind in _GRID:
             snap["features"] = eng.download("features")
         self._done_ids = {int(e) for e in np.nonzero(snap["done"])[0]}
+        self._episode_over = set(self._done_ids)
         self._reset_obs = {}
         sd = self.kind == "selfdrive"
 
@@ -289,8 +333,25 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         v = self._reset_obs.pop(e)
         return v[e] if isinstance(v, _LazyEnvMap) else v
 
+    # ---- episode metrics: what the reference's MetricsCallback (utils/logger_utils.py:126-150) reads per episode ----
+    def env_metrics(self, env_id):
+        """the `metrics` dictionary of sub-env `env_id`, with the single-env adapters' keys: the finished episode's
+        (equality / sustainability included) from the done tick until the env steps again — a reset in between does
+        not clear them — the running episode's otherwise"""
+        eng, e = self.engine, int(env_id)
+        if not 0 <= e < self.num_envs:
+            raise IndexError(env_id)
+        final = e in self._episode_over
+        mi = eng.download("final_int_metrics" if final else "int_metrics", e, 1)[0]
+        mf = eng.download("final_f64_metrics" if final else "f64_metrics", e, 1)[0]
+        return episode_metrics(self.kind, self.num_agents, mi, mf, final and self.kind != "selfdrive",
+                               contract=bool(self.contract), inequity=bool(eng.cfg.flags & _lib.FLAG_INEQUITY))
+
     def get_sub_environments(self, as_dict=False):
-        return {} if as_dict else []
+        """per-env views for callbacks (`base_env.get_sub_environments()[env_index].metrics`); `.base_env` is the view
+        itself, so the reference's wrapper.base_env.metrics chain resolves too"""
+        views = _SubEnvs(self)
+        return {e: views[e] for e in range(self.num_envs)} if as_dict else views
 
     def stop(self):
         self.engine.close()

@@ -161,3 +161,80 @@ def test_vector_hook_scales_to_the_headline_batch():
     rate_t = 20 * E / (time.perf_counter() - t2)
     assert tens["obs"].shape == (E, n, 15, 15, 3) and rate_t > 10 * rate
     venv.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,contract", [("cleanup", "cleanup"), ("harvest_features", "harvest_local"), ("selfdrive", "selfdrive_distprop")])
+def test_episode_metrics_reach_the_callback(kind, contract):
+    """MetricsCallback.on_episode_end on the batched hook: the finished episode's metrics of the env RLlib names by
+    env_index — equal to what a single-env adapter with the same private seed reports — also after the batched reset
+    that the first try_reset of the tick triggers for every done env"""
+    from contracts_amd.contract import contract_list as cl
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.feature_envs import HarvestFeatures
+    from contracts_amd.environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    from contracts_amd.utils.logger_utils import MetricsCallback
+    from contracts_amd.vector_env import BatchedBaseEnv
+    E, n, horizon, seed0 = 5, 3, 12, 4242
+    kw = {} if kind == "selfdrive" else {"horizon": horizon}
+    venv = BatchedBaseEnv(kind, E, n, contract=contract, seed0=seed0, convolutional=kind == "cleanup", **kw)
+    keys = ["a%d" % i for i in range(n)]
+
+    def action(e, t, i):
+        return np.array([0.05 + 0.01 * ((e + t + i) % 5)]) if kind == "selfdrive" else (e * 7 + t * 3 + i) % 7
+
+    class Episode:
+        custom_metrics = None
+
+    # the same episodes through single-env adapters on private streams with the same seeds
+    want = []
+    for e in range(E):
+        if kind == "cleanup":
+            base, con = CleanupEnv(num_agents=n, horizon=horizon, rng="private"), cl.CleanupContract(n)
+        elif kind == "harvest_features":
+            base, con = HarvestFeatures(num_agents=n, horizon=horizon, rng="private"), cl.HarvestFeaturemodLocalContract(n)
+        else:
+            base, con = SelfAcceleratingCarEnv(num_agents=n, rng="private"), cl.SelfdriveContractDistprop(n)
+        base._ensure_engine().seed(np.array([seed0 + e], np.uint64))  # replays the constructor like the batched API
+        top = SeparateContractSubgameStage(base, con, n, kind == "cleanup")
+        top.reset()
+        alive, t, d = list(keys), 0, {"__all__": False}
+        while not d["__all__"]:
+            _, _, d, _ = top.step({k: action(e, t, int(k[1:])) for k in alive})
+            alive = [k for k in alive if not d.get(k, False)] if kind == "selfdrive" else alive
+            t += 1
+        want.append((t, dict(base.metrics)))
+        base.close()
+
+    cb, got, t = MetricsCallback(), {}, 0
+    venv.poll()
+    alive = {e: list(keys) for e in range(E)}
+    finished = set()
+    while len(got) < E:
+        venv.send_actions({e: {k: action(e, t, int(k[1:])) for k in alive[e]} if e not in finished else {} for e in range(E)}
+                          if kind == "selfdrive" else {e: {k: action(e, t, i) for i, k in enumerate(keys)} for e in range(E)})
+        obs, rew, dones, infos, _ = venv.poll()
+        t += 1
+        done_now = [e for e in range(E) if dones[e]["__all__"] and e not in got]
+        for j, e in enumerate(done_now):
+            assert t == want[e][0]
+            if j == 1 and kind != "selfdrive":
+                venv.try_reset(done_now[0])  # resets every done env of the tick; the others' final metrics must survive
+            ep = Episode()
+            cb.on_episode_start(base_env=venv, episode=ep)
+            cb.on_episode_end(base_env=venv, episode=ep, env_index=e)
+            got[e] = ep.custom_metrics
+            finished.add(e)
+        if kind == "selfdrive":
+            for e in range(E):
+                alive[e] = [k for k in alive[e] if not dones[e].get(k, False)]
+            if len(got) < E and finished:
+                break  # selfdrive replicas end at different ticks and a done env cannot idle in send_actions
+    for e, m in got.items():
+        assert set(m) == set(want[e][1]), (set(m) ^ set(want[e][1]))
+        for k, v in want[e][1].items():
+            assert abs(float(m[k]) - float(v)) < 1e-9, (e, k, m[k], v)
+    assert got and (kind == "selfdrive" or len(got) == E)
+    assert len(venv.get_sub_environments()) == E and venv.get_sub_environments()[-1].env_id == E - 1
+    venv.stop()
