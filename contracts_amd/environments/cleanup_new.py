@@ -32,3 +32,35 @@ class CleanupEnv(GridEnvAdapter):
 
     def _info_entry(self, eaten, second):
         return {"eaten_apples": eaten, "cleaned_squares": second}
+
+    # ---- inspection helpers (cleanup_new.py:351-394), from the engine's state ----
+    @property
+    def potential_waste_area(self):
+        return self.POTENTIAL_WASTE_AREA
+
+    @property
+    def waste_points(self):
+        """the waste list in its current order — np.random.shuffle permutes it in place whenever waste may spawn
+        (cleanup_new.py:339); the engine keeps the permutation"""
+        pts = [[r, c] for r, row in enumerate(self._static_rows) for c, x in enumerate(row) if x in "HR"]
+        return [pts[i] for i in self._engine.download("waste_perm")[0]]
+
+    @property
+    def current_waste_points(self):
+        return self._cells(b"H")
+
+    def compute_current_wastes(self):
+        """see compute_current_apples"""
+
+    def compute_permitted_area(self):
+        return self.POTENTIAL_WASTE_AREA - int((self.world_map == b"H").sum())
+
+    def compute_probabilities(self):
+        """cleanup_new.py:351-368 on the map as it is now (the reference refreshes these two attributes at the start of
+        custom_map_update, i.e. before the step's own spawn)"""
+        density = 1 - self.compute_permitted_area() / self.POTENTIAL_WASTE_AREA
+        if density >= 0.4:
+            self.current_apple_spawn_prob = self.current_waste_spawn_prob = 0
+        else:
+            self.current_waste_spawn_prob = 0.5
+            self.current_apple_spawn_prob = 0.05 if density <= 0.0 else (1 - (density - 0.0) / (0.4 - 0.0)) * 0.05

@@ -32,3 +32,15 @@ class HarvestEnv(GridEnvAdapter):
 
     def _info_entry(self, eaten, second):
         return {"eaten_apples": eaten, "eaten_close_apples": second}
+
+    def count_apples_in_radius(self, radius, loc):
+        """harvest_new.py: apples with j^2 + k^2 <= radius around loc (the env's own feature uses radius 5)"""
+        grid = self.world_map
+        H, W = self.GRID_SHAPE
+        total = 0
+        for j in range(-radius, radius + 1):
+            for k in range(-radius, radius + 1):
+                r, c = loc[0] + j, loc[1] + k
+                if j ** 2 + k ** 2 <= radius and 0 <= r < H and 0 <= c < W and grid[r, c] == b"A":
+                    total += 1
+        return total

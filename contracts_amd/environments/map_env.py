@@ -75,6 +75,31 @@ def host_np_draw(env, fn):
     return out
 
 
+class AgentView:
+    """read-only stand-in for the reference's agent objects (Agent.py:25-160): where an agent is and which way it faces,
+    from the engine's state; `env.agents['a3'].pos`, `.orientation`, `.get_char_id()` keep working"""
+
+    def __init__(self, agent_id, row, col, orientation, view_len):
+        self.agent_id = agent_id
+        self.pos = np.array([row, col])
+        self.list_pos = [row, col]
+        self.int_orientation = int(orientation)
+        self.orientation = ORIENT_NAMES[self.int_orientation]
+        self.row_size = self.col_size = view_len
+
+    def get_pos(self):
+        return self.pos
+
+    def get_orientation(self):
+        return self.orientation
+
+    def get_char_id(self):
+        return bytes(str(int(self.agent_id[-1]) + 1), encoding="ascii")  # Agent.py:81-82
+
+    def translate_pos_to_egocentric_coord(self, pos):
+        return [self.row_size, self.col_size] + (np.asarray(pos) - self.pos)
+
+
 class GridEnvAdapter(_Base):
     KIND = None          # "cleanup" | "harvest"
     GRID_SHAPE = None    # (H, W)
@@ -273,6 +298,67 @@ class GridEnvAdapter(_Base):
     @property
     def world_map(self):
         return CELL_CHARS[self._engine.download("grid")[0]]
+
+    # ---- inspection helpers of MapEnv / CleanupEnv / HarvestEnv, computed from the engine's state on demand ----
+    @property
+    def agents(self):
+        a = self._engine.download("agents")[0]
+        return {k: AgentView(k, int(a[i, 0]), int(a[i, 1]), int(a[i, 2]), self.view_len) for i, k in enumerate(self._keys)}
+
+    def get_map_with_agents(self):
+        """map_env.py:353-374: the character map with the agents' ids ('1'..'9', later agents on top) and, over them,
+        the beams of the last step"""
+        grid = self.world_map.copy()
+        for i, a in enumerate(self._engine.download("agents")[0]):
+            grid[a[0], a[1]] = bytes(str(i + 1), encoding="ascii")
+        beam = self._engine.download("beam_map")[0]
+        grid[beam == 1] = b"F"
+        grid[beam == 2] = b"C"
+        return grid
+
+    def color_view(self, agent):
+        """map_env.py:397-411: the agent's rotated 15 x 15 crop — the engine's observation of the last step / reset"""
+        key = agent.agent_id if hasattr(agent, "agent_id") else agent
+        return self._engine.download("obs")[0][int(key[1:])]
+
+    def test_if_in_bounds(self, pos):
+        H, W = self.GRID_SHAPE
+        return 0 <= pos[0] < H and 0 <= pos[1] < W
+
+    def find_visible_agents(self, agent_id):
+        """map_env.py:880-913: which other agents (sorted by id) stand inside this agent's 15 x 15 window"""
+        a = self._engine.download("agents")[0][:, :2].astype(int)
+        me = a[int(agent_id[1:])]
+        others = [a[int(k[1:])] for k in sorted(self._keys) if k != agent_id]
+        return np.array([1 if (abs(o[0] - me[0]) <= self.view_len and abs(o[1] - me[1]) <= self.view_len) else 0 for o in others],
+                        dtype=np.uint8)
+
+    def _cells(self, char):
+        return [[int(r), int(c)] for r, c in np.argwhere(self.world_map == char)]
+
+    @property
+    def current_apple_points(self):
+        return self._cells(b"A")  # row-major scan of the map as it is now (cleanup_new.py:378-385, harvest_new.py)
+
+    def compute_current_apples(self):
+        """the reference refreshes its `current_apple_points` attribute here; the property above is always current"""
+
+    @property
+    def _static_rows(self):
+        return static_map(self.KIND)
+
+    @property
+    def apple_points(self):
+        ch = "B" if self.KIND == "cleanup" else "A"
+        return [[r, c] for r, row in enumerate(self._static_rows) for c, x in enumerate(row) if x == ch]
+
+    @property
+    def spawn_points(self):
+        """the spawn list in its current (persistently shuffled) order, map_env.py:821"""
+        pts = [[r, c] for r, row in enumerate(self._static_rows) for c, x in enumerate(row) if x == "P"]
+        if self.KIND == "cleanup":
+            pts = pts + pts  # the constructor collects the 'P' cells a second time (cleanup_new.py:114-115): 20 entries
+        return [pts[i] for i in self._engine.download("spawn_perm")[0][:len(pts)]]
 
     def full_map_to_colors(self):
         """map_env.py:354-392: the map, the agents in agent order, then the beams the last step fired (`beam_pos`,
