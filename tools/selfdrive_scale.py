@@ -1,4 +1,4 @@
-import sys, time, json
+import sys, time
 sys.path.insert(0, ".")
 import torch
 from contracts_amd.engine import BatchedEnv

@@ -4,7 +4,6 @@
   <tag>_bench_line.json    the bench line of the profiled run (slower than an unprofiled one)
   traffic.json             PMC HBM bytes per env-step, read by bench.py into roofline.traffic
 Usage: python tools/summarise_profiles.py [gpurun_out/prof_r02] [r02]"""
-import csv
 import glob
 import json
 import os

@@ -2,7 +2,6 @@
 steps it with the library named by CONTRACTS_AMD_LIB (a truncated build leaves the state untouched, so
 every step repeats the same work).  Usage: python3 tools/valu_profile_run.py make|run STATEFILE"""
 import sys
-import numpy as np
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
