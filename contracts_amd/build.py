@@ -18,7 +18,7 @@ HEADERS = ["ce_device.h", "ce_grid_probe.inc", os.path.join("..", "..", "include
 # -ffp-contract=off: float64 reward/transfer arithmetic must round exactly like the reference's
 # separate multiply and add; no fast-math anywhere.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
