@@ -429,6 +429,14 @@ static SdParams sd_params(ce_engine* h) {
   return p;
 }
 
+// Every entry point that launches starts here: the calling thread's current device, and a clean per-thread error
+// state — hipGetLastError is sticky, and an error some earlier, unrelated HIP call of this thread left behind (another
+// library's, or one already reported) must not be blamed on the launches that follow.
+static void begin_call(ce_engine* h) {
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipGetLastError();
+}
+
 static int check_launch(ce_engine* h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, CE_ENODEV, what, e);
@@ -453,7 +461,7 @@ static int stage_mask(ce_engine* h, const uint8_t* mask, hipStream_t s, const ui
 
 extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int mode) {
   if (!h) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   const uint32_t E = h->cfg.num_envs;
   std::vector<uint64_t> tmp;
   if (!seeds) {
@@ -501,7 +509,7 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
 
 extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   if (!h) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   const uint8_t* dmask;
   int rc = stage_mask(h, mask, (hipStream_t)stream, &dmask);
   if (rc) return rc;
@@ -526,7 +534,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
                              uint32_t env_count, void* stream) {
   if (!h || !actions) return CE_EINVAL;
   if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
@@ -571,7 +579,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
   if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   if (traj && traj->num_planes == 0) return fail(h, CE_EINVAL, "ce_traj.num_planes must be at least 1");
   if (traj && traj->first_plane >= traj->num_planes) return fail(h, CE_EINVAL, "ce_traj.first_plane out of range");
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   const ce_buffers& b = h->buf;
   const uint64_t E = h->cfg.num_envs, n = h->cfg.num_agents;
   RolloutArgs ra;
@@ -635,7 +643,7 @@ extern "C" int ce_step(ce_handle h, const void* actions, const uint8_t* active, 
 
 extern "C" int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) {
   if (!h || !host_actions) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
   const size_t abytes = cnt * (u8_actions(h->cfg) ? 1 : 4);
   hipError_t e = hipMemcpyAsync(h->d_stage_actions, host_actions, abytes, hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -647,7 +655,7 @@ extern "C" int ce_step_host(ce_handle h, const void* host_actions, const uint8_t
 
 extern "C" int ce_synth_actions(ce_handle h, uint64_t key, uint32_t t0, uint32_t T, void* out, void* stream) {
   if (!h || !out || T == 0) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   const ce_config& c = h->cfg;
   if (is_feat(c)) {  // Discrete(7) / Discrete(8) action spaces of the feature envs
     launch_synth_actions_u8((uint8_t*)out, key, c.env_index_base, c.num_envs, c.num_agents, t0, T, c.kind == CE_KIND_HARVEST_FEATURES ? 7 : 8, stream);
@@ -691,7 +699,7 @@ extern "C" int ce_get_buffers(ce_handle h, ce_buffers* out) {
 
 extern "C" int ce_synchronize(ce_handle h, void* stream) {
   if (!h) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "hipStreamSynchronize", e);
   return CE_OK;
@@ -743,7 +751,7 @@ static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
 
 extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes) {
   if (!h || !field || !dst) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   FieldDesc f;
   if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
@@ -771,7 +779,7 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
 
 extern "C" int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const ce_field_req* reqs, uint32_t count) {
   if (!h || !reqs || count == 0) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "slice out of range");
   std::vector<FieldDesc> f(count);
   size_t total = 0;
@@ -820,7 +828,7 @@ extern "C" int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_co
 
 extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes) {
   if (!h || !field || !src) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   FieldDesc f;
   if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs || src_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
@@ -846,7 +854,7 @@ extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uin
 
 extern "C" int ce_timing_begin(ce_handle h, void* stream) {
   if (!h) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   hipError_t e = hipEventRecord(h->ev_start, (hipStream_t)stream);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "hipEventRecord", e);
   h->timing_armed = true;
@@ -856,7 +864,7 @@ extern "C" int ce_timing_begin(ce_handle h, void* stream) {
 
 extern "C" int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches) {
   if (!h || !h->timing_armed) return CE_EINVAL;
-  (void)hipSetDevice(h->cfg.device);
+  begin_call(h);
   hipError_t e = hipEventRecord(h->ev_stop, (hipStream_t)stream);
   if (e == hipSuccess) e = hipEventSynchronize(h->ev_stop);
   float ms = 0.f;

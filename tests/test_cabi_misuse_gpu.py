@@ -92,3 +92,40 @@ def test_create_rejects_bad_device_and_reports_why():
     cfg = make_config(kind="cleanup", num_envs=4, num_agents=2)
     cfg.abi_version = 1
     assert L.ce_create(C.byref(cfg), C.byref(h)) == EINVAL
+
+
+def test_distinct_handles_from_concurrent_threads():
+    """handles are independent: created, stepped and destroyed from four threads at once (ctypes releases the GIL), each
+    ends in the state a serial twin reaches — the `one host thread per handle` use of SURVEY §8(e)"""
+    import threading
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    specs = [("cleanup", 8, "cleanup"), ("harvest", 5, "harvest_local"), ("selfdrive", 4, "selfdrive_distprop"),
+             ("cleanup_features", 3, "cleanup")]
+    T, E = 80, 300
+
+    def run(spec, out, idx):
+        kind, n, contract = spec
+        env = BatchedEnv(kind, E, n, contract=contract, auto_reset=True, **({} if kind == "selfdrive" else {"horizon": 31}))
+        env.seed(seed0=100 + idx)
+        env.reset()
+        stream = torch.cuda.Stream()
+        acts = torch.empty((T, E, n), dtype=torch.float32 if kind == "selfdrive" else torch.uint8, device="cuda")
+        env.synth_actions(9, 0, T, acts.data_ptr(), stream=stream.cuda_stream)
+        env.rollout_device(acts.data_ptr(), T, [stream.cuda_stream])
+        env.synchronize(stream.cuda_stream)
+        env.check_faults()
+        out[idx] = {f: env.download(f, raw=True).tobytes() for f in ("rng", "reward", "done", "f64_metrics")}
+        env.close()
+
+    threaded, serial = {}, {}
+    threads = [threading.Thread(target=run, args=(s, threaded, i)) for i, s in enumerate(specs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i, s in enumerate(specs):
+        run(s, serial, i)
+    assert sorted(threaded) == list(range(len(specs)))
+    for i in range(len(specs)):
+        assert threaded[i] == serial[i], specs[i]
