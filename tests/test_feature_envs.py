@@ -33,7 +33,9 @@ def test_engine_feature_golden(name):
 @pytest.mark.parametrize("kind,n,contract,horizon", [("harvest_features", 2, "harvest_local", 1000),
                                                      ("harvest_features", 8, None, 37),
                                                      ("cleanup_features", 5, "cleanup", 61),
-                                                     ("cleanup_features", 9, None, 1000)])
+                                                     ("cleanup_features", 9, None, 1000),
+                                                     ("harvest_features", 1, None, 1),     # an episode per step, one agent
+                                                     ("cleanup_features", 2, "cleanup", 2)])
 def test_engine_feature_rollout_vs_oracle(kind, n, contract, horizon):
     """random rollouts with auto-reset: every persistent and output field after every step"""
     from contracts_amd.engine import BatchedEnv

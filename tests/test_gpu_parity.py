@@ -69,6 +69,12 @@ def _compare(env, orc, fields, tag):
     ("harvest", 8, "harvest_local", False, 50, 512, 120),
     ("harvest", 3, None, True, 1000, 128, 100),
     ("cleanup", 5, None, False, 40, 130, 90),
+    # degenerate shapes: an episode per step (every step ends in an in-launch reset), one env, one agent, nine agents
+    ("cleanup", 8, "cleanup", True, 1, 65, 40),
+    ("harvest", 9, None, True, 2, 3, 60),
+    ("cleanup", 1, None, False, 3, 1, 80),
+    ("harvest", 1, None, True, 1000, 2, 80),
+    ("cleanup", 9, None, True, 1000, 1, 60),
 ])
 def test_random_rollout_vs_oracle(kind, n, contract, firing, horizon, E, T):
     """many envs, distinct seeds, auto-reset across episode boundaries; everything compared every step"""
