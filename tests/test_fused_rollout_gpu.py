@@ -51,6 +51,8 @@ def _same(a, b, fields, tag):
     ("harvest", 5, None, True, 1000, 33, 8, None),
     ("cleanup", 4, "cleanup", True, 20, 45, 0, dict(inequity=True, alpha=5.0, beta=0.05)),  # float reward accumulators
     ("harvest", 3, "harvest_local", True, 1000, 30, 4, dict(collective=True)),
+    ("cleanup", 8, "cleanup", True, 1, 20, 0, None),         # an episode per step: every step resets inside the launch
+    ("harvest", 1, None, False, 2, 30, 7, None),             # one agent
 ])
 def test_fused_equals_per_step(kind, n, contract, firing, horizon, T, per, extra):
     E = 193
@@ -171,7 +173,8 @@ def test_fused_full_episode_vs_oracle_sample():
     ref.close()
 
 
-@pytest.mark.parametrize("n,collision_on,T,per", [(4, False, 150, 0), (4, True, 90, 16), (3, False, 120, 7), (6, False, 80, 0)])
+@pytest.mark.parametrize("n,collision_on,T,per", [(4, False, 150, 0), (4, True, 90, 16), (3, False, 120, 7), (6, False, 80, 0),
+                                                  (1, False, 70, 0), (10, True, 70, 16), (2, True, 60, 5)])
 def test_fused_selfdrive_equals_per_step(n, collision_on, T, per):
     """selfdrive: cars resident in registers across the steps of a launch; several episodes (in-launch auto-resets,
     both MT19937 streams advanced by them) inside the window"""
