@@ -142,3 +142,64 @@ def test_static_map_matches_the_fixture_tables():
     import pytest
     with pytest.raises(_lib.EngineError):
         _lib.static_map("selfdrive")
+
+
+def test_episode_metrics_mapping_and_callback_layouts():
+    """host logic without a GPU: the engine's metric rows under the reference's keys, and MetricsCallback over the
+    layouts it has to serve (the reference's one-env BaseEnv, a wrapper around a base env, the batched hook's views)"""
+    from contracts_amd.environments.metrics import episode_metrics
+    from contracts_amd.utils.logger_utils import MetricsCallback, episode_env_metrics
+    n = 3
+    mi = np.arange(40)
+    mf = np.arange(40) / 4.0
+    m = episode_metrics("cleanup", n, mi, mf, final=True, contract=True)
+    assert m["total_apples_eaten"] == 0 and m["raw_env_rewards"] == 1 and m["dirt_cleaned"] == 2 and m["transfers"] == 0.0
+    assert [m["a%d-waste_cleaned" % i] for i in range(n)] == [4, 5, 6]
+    assert (m["equality"], m["sustainability"], m["transfer_equality"], m["transfer_sustainability"]) == (0.25, 0.5, 0.75, 1.0)
+    m = episode_metrics("harvest", n, mi, mf, final=False, inequity=True)
+    assert "equality" not in m and m["transfers"] == 0 and m["raw_env_rewards"] == mf[5 + 2 * n]
+    assert m["a2-close_apples_consumed"] == mi[4 + n + 2] and m["low_density_apples_eaten"] == 3
+    assert set(episode_metrics("cleanup_features", 2, mi, mf, False)) == {"dirt_cleaned", "raw_env_rewards", "transfers"}
+    assert episode_metrics("selfdrive", 4, None, mf, False) == {"transfers": 0.0}
+
+    class Env:
+        def __init__(self, metrics, base=None):
+            self.metrics = metrics
+            if base is not None:
+                self.base_env = base
+
+    class OneEnvBaseEnv:  # RLlib's wrapper around a single MultiAgentEnv, as the reference's callback expects it
+        def __init__(self, env):
+            self._unwrapped_env = env
+
+    class Vector:
+        def __init__(self, envs):
+            self._envs = envs
+
+        def get_sub_environments(self):
+            return self._envs
+
+    assert episode_env_metrics(OneEnvBaseEnv(Env({"x": 1}))) == {"x": 1}
+    wrapped = Env({"accepted": 1}, base=Env({"transfers": 2.0, "accepted": 0}))
+    assert episode_env_metrics(OneEnvBaseEnv(wrapped)) == {"transfers": 2.0, "accepted": 1}  # the wrapper's keys win
+    vec = Vector([Env({"k": 0}), Env({"k": 1}), Env({"k": 2})])
+    assert episode_env_metrics(vec, env_index=2) == {"k": 2}
+
+    class Episode:
+        custom_metrics = None
+
+    ep, cb = Episode(), MetricsCallback()
+    cb.on_episode_start(base_env=vec, episode=ep)
+    assert ep.custom_metrics == {}
+    cb.on_episode_step(base_env=vec, episode=ep)
+    cb.on_episode_end(base_env=vec, episode=ep, env_index=1)
+    assert ep.custom_metrics == {"k": 1}
+
+
+def test_agent_view_mirrors_the_reference_agent_fields():
+    from contracts_amd.environments.map_env import AgentView
+    a = AgentView("a7", 3, 11, 2, 7)
+    assert a.pos.tolist() == [3, 11] and a.list_pos == [3, 11] and a.orientation == "DOWN" and a.int_orientation == 2
+    assert a.get_char_id() == b"8" and a.get_pos() is a.pos and a.get_orientation() == "DOWN"
+    assert a.row_size == a.col_size == 7
+    assert list(a.translate_pos_to_egocentric_coord([4, 9])) == [8, 5]
