@@ -21,7 +21,15 @@ tools/pmc_run.sh ${TAG}_fused k_grid_rollout $ES "$G1" "$G2" "$G3" "FETCH_SIZE" 
 ES5=$((64*32768))
 tools/pmc_run.sh ${TAG}_sd_step k_sd_step $ES5 "$G1" "FETCH_SIZE" "WRITE_SIZE" -- --kind selfdrive --agents 4 --envs 32768 --mode step --steps 64 > $OUT/pmc_sd_step.txt 2>&1
 tools/pmc_run.sh ${TAG}_sd_fused k_sd_rollout $ES5 "$G1" "FETCH_SIZE" "WRITE_SIZE" -- --kind selfdrive --agents 4 --envs 32768 --mode fused --steps 64 --T 16 > $OUT/pmc_sd_fused.txt 2>&1
-for k in step fused sd_step sd_fused; do cp $R/gpurun_out/pmc/${TAG}_$k/summary.json $OUT/pmc_$k.json; done
+# HBM traffic of the other BASELINE configs (FETCH_SIZE / WRITE_SIZE only)
+ES3=$((64*16384)); ES2=$((64*4096))
+tools/pmc_run.sh ${TAG}_c3_step k_grid_step $ES3 "FETCH_SIZE" "WRITE_SIZE" -- --kind harvest --agents 8 --envs 16384 --mode step --steps 64 > $OUT/pmc_c3_step.txt 2>&1
+tools/pmc_run.sh ${TAG}_c3_fused k_grid_rollout $ES3 "FETCH_SIZE" "WRITE_SIZE" -- --kind harvest --agents 8 --envs 16384 --mode fused --steps 64 --T 16 > $OUT/pmc_c3_fused.txt 2>&1
+tools/pmc_run.sh ${TAG}_c2_step k_grid_step $ES2 "FETCH_SIZE" "WRITE_SIZE" -- --kind cleanup --agents 4 --envs 4096 --mode step --steps 64 > $OUT/pmc_c2_step.txt 2>&1
+tools/pmc_run.sh ${TAG}_c2_fused k_grid_rollout $ES2 "FETCH_SIZE" "WRITE_SIZE" -- --kind cleanup --agents 4 --envs 4096 --mode fused --steps 64 --T 16 > $OUT/pmc_c2_fused.txt 2>&1
+tools/pmc_run.sh ${TAG}_c1_step k_feat_step $ES3 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" -- --kind harvest_features --agents 2 --envs 16384 --mode step --steps 64 > $OUT/pmc_c1_step.txt 2>&1
+tools/pmc_run.sh ${TAG}_c1_fused k_feat_rollout $ES3 "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" -- --kind harvest_features --agents 2 --envs 16384 --mode fused --steps 64 --T 16 > $OUT/pmc_c1_fused.txt 2>&1
+for k in step fused sd_step sd_fused c3_step c3_fused c2_step c2_fused c1_step c1_fused; do cp $R/gpurun_out/pmc/${TAG}_$k/summary.json $OUT/pmc_$k.json; done
 find $OUT -name '*_agent_info.csv' -delete
 find $OUT -name '*kernel_trace.csv' -delete
 du -sh $OUT

@@ -38,8 +38,8 @@ def main():
     plane = a.envs * a.agents * (4 if a.kind == "selfdrive" else 1)
     streams = [torch.cuda.Stream() for _ in range(a.streams)]
     handles = [s.cuda_stream for s in streams] if a.streams > 1 else None
-    if a.preroll:  # with the OTHER mode's kernel where there is one, so that the profiled kernel only sees the measured steps
-        if a.mode == "step" and a.kind in ("cleanup", "harvest", "selfdrive"):
+    if a.preroll:  # with the OTHER mode's kernel, so that the profiled kernel only sees the measured steps
+        if a.mode == "step":
             env.rollout_fused(acts.data_ptr(), a.preroll, 50, None, handles)
         else:
             env.rollout_device(acts.data_ptr(), a.preroll, handles)

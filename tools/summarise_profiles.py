@@ -12,8 +12,13 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
-ALGO = {"step": 7235, "fused": 7235, "sd_step": 863, "sd_fused": 863}
-KIND = {"step": ("cleanup", 8), "fused": ("cleanup", 8), "sd_step": ("selfdrive", 4), "sd_fused": ("selfdrive", 4)}
+ALGO = {"step": 7235, "fused": 7235, "sd_step": 863, "sd_fused": 863, "c3_step": 7313, "c3_fused": 7313, "c2_step": 4211,
+        "c2_fused": 4211, "c1_step": 887, "c1_fused": 887}
+KIND = {"step": ("cleanup", 8), "fused": ("cleanup", 8), "sd_step": ("selfdrive", 4), "sd_fused": ("selfdrive", 4),
+        "c3_step": ("harvest", 8), "c3_fused": ("harvest", 8), "c2_step": ("cleanup", 4), "c2_fused": ("cleanup", 4),
+        "c1_step": ("harvest_features", 2), "c1_fused": ("harvest_features", 2)}
+TRAFFIC_KEY = {"step": "per_step", "fused": "fused", "sd_step": "per_step_C5", "sd_fused": "fused_C5", "c3_step": "per_step_C3",
+               "c3_fused": "fused_C3", "c2_step": "per_step_C2", "c2_fused": "fused_C2", "c1_step": "per_step_C1", "c1_fused": "fused_C1"}
 
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
 shutil.copy(max(stats, key=os.path.getmtime), "profiles/%s_kernel_stats.csv" % tag)
@@ -25,7 +30,7 @@ out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-t
        "a 300-step pre-roll run with the other mode's kernel), summed over the dispatches of the kernel and divided by envs x steps",
        "kernels": {}}
 traffic = {}
-for key in ("step", "fused", "sd_step", "sd_fused"):
+for key in ALGO:
     path = os.path.join(src, "pmc_%s.json" % key)
     if not os.path.exists(path):
         continue
@@ -39,7 +44,7 @@ for key in ("step", "fused", "sd_step", "sd_fused"):
         row["hbm"] = {"fetch_bytes_per_env_step": fetch_b, "write_bytes_per_env_step": write_b,
                       "hbm_bytes_per_env_step": fetch_b + write_b, "algorithmic_bytes_per_env_step": ALGO[key],
                       "ratio_to_algorithmic": (fetch_b + write_b) / ALGO[key]}
-        tk = {"step": "per_step", "fused": "fused", "sd_step": "per_step_C5", "sd_fused": "fused_C5"}[key]
+        tk = TRAFFIC_KEY[key]
         traffic[tk] = {"kind": KIND[key][0], "agents": KIND[key][1], "hbm_bytes_per_env_step": fetch_b + write_b,
                        "source": "profiles/%s_pmc_summary.json (%s; FETCH_SIZE doubled per the gfx950 correction)" % (tag, s["kernel"])}
     if "SQ_LDS_BANK_CONFLICT" in per and per.get("SQ_ACTIVE_INST_LDS"):
