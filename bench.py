@@ -17,6 +17,14 @@ sides and reduced with MAX over ranks; the report carries the median repeat.  Tw
             needs the observation before choosing the next action can use; this is `value`;
   fused     ce_rollout_fused: T consecutive steps per launch with the env state resident on chip, every step's outputs
             written to its plane of a trajectory ring (pre-supplied actions: contract search, random-policy rollouts).
+The line also carries, measured in the same run (rank 0's GPU, N = 1 only for the host-side ones):
+  configs      the other BASELINE configs (C2, C3, C5, C1), per_step and fused, each timed for >= 0.3 s over repeats of
+               --config-steps steps (300, independent of --steps, so the driver's short command and a long run agree),
+               each with its own cpu_baseline;
+  closed_loop  one host iteration per env-step: the step's actions are computed ON THE DEVICE by torch from the previous
+               observation, three env slices double-buffered over ce_step_range — what an RL sampler gets;
+  boundary     the RLlib vector hook (contracts_amd.vector_env.BatchedBaseEnv) at E = 16384: the tensor path
+               (send_actions_array / poll_tensors) and the dict protocol (send_actions / poll), PCIe- and Python-inclusive.
 Prints ONE JSON line on rank 0 (DESIGN.md §5 explains every field).
 """
 import argparse
@@ -70,6 +78,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (C1, C2, C3, C5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--config-steps", type=int, default=300, help="steps per timed repeat of the C1/C2/C3/C5 rows")
+    ap.add_argument("--config-seconds", type=float, default=0.3, help="minimum timed wall per mode of a config row")
+    ap.add_argument("--config-cpu-seconds", type=float, default=2.5, help="CPU baseline sample per config row")
+    ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N self-launch: deadline of the whole job, s")
     return ap.parse_args()
 
 
@@ -101,18 +115,18 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(wl, target_s):
+def cpu_baseline(wl, target_s, single_thread_s=4.0):
     """The CPU oracle (oracle/oracle.c, pinned bit-exact to the reference's golden traces) timed on this box's host cores
     with OpenMP over envs.  Like for like with the GPU run: the first `256 x threads` envs of the same batch (global
     indices 0.., seeds SEED0 + b), the same counter-hash actions (contracts_amd.synth mirrors the device generator), the
-    same horizon / auto-reset, from t = 0; all threads (the reported value) and one thread."""
+    same horizon / auto-reset, from t = 0; all threads (the reported value) and, when single_thread_s > 0, one thread."""
     import ctypes
     from contracts_amd import synth
     from oracle.pyoracle import Oracle
     kind, n, contract = wl["kind"], wl["n"], wl["contract"]
     threads = _usable_cores()
     gomp = ctypes.CDLL("libgomp.so.1")
-    na = {"cleanup": 8, "harvest": 7}[kind]
+    na = {"cleanup": 8, "harvest": 7, "harvest_features": 7, "cleanup_features": 8}.get(kind)
     CH = 32
 
     def run(nthreads, E, seconds):
@@ -122,7 +136,10 @@ def cpu_baseline(wl, target_s):
         orc.reset()
         steps, spent = 0, 0.0
         while spent < seconds:
-            acts = synth.synth_actions_u8(SEED0 + 1, 0, E, n, steps, CH, na)  # generated outside the timed span
+            if kind == "selfdrive":  # generated outside the timed span
+                acts = synth.synth_actions_f32(SEED0 + 1, 0, E, n, steps, CH)
+            else:
+                acts = synth.synth_actions_u8(SEED0 + 1, 0, E, n, steps, CH, na)
             t0 = time.perf_counter()
             for t in range(CH):
                 orc.step(acts[t])
@@ -132,13 +149,17 @@ def cpu_baseline(wl, target_s):
         return E * n * steps / spent, steps, spent
 
     v_all, steps, dt = run(threads, 256 * threads, target_s)
-    v_one, steps1, dt1 = run(1, 256, min(4.0, target_s))
-    return {"value": v_all, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-            "single_thread_value": v_one, "cpu_model": _cpu_model(),
-            "python_reference_per_core": 4259,  # the reference itself, measured by the survey
-            "sample": "envs 0..%d of the same batch (seeds %d + b, the same counter-hash actions, horizon 1000, auto-reset), "
-                      "steps 0..%d, %s n=%d + contract, OpenMP over envs on %d threads, %.1f s of stepping (+ envs 0..255 x %d "
-                      "steps on 1 thread, %.1f s)" % (256 * threads - 1, SEED0, steps - 1, kind, n, threads, dt, steps1, dt1)}
+    out = {"value": v_all, "unit": "agent-steps/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+           "sample": "envs 0..%d of the same batch (seeds %d + b, the same counter-hash actions, horizon 1000, auto-reset), "
+                     "steps 0..%d, %s n=%d + contract, OpenMP over envs on %d threads, %.1f s of stepping"
+                     % (256 * threads - 1, SEED0, steps - 1, kind, n, threads, dt)}
+    if single_thread_s > 0:
+        v_one, steps1, dt1 = run(1, 256, min(single_thread_s, target_s))
+        out["single_thread_value"] = v_one
+        out["sample"] += " (+ envs 0..255 x %d steps on 1 thread, %.1f s)" % (steps1, dt1)
+    if kind == "cleanup" and n == 8:
+        out["python_reference_per_core"] = 4259  # the reference itself, measured by the survey
+    return out
 
 
 def stream_ceiling():
@@ -170,7 +191,7 @@ def stream_ceiling():
 class Runner:
     """one engine handle of this rank + its resident action planes; measures one mode at a time"""
 
-    def __init__(self, group, wl, E, K, W, streams, device_index):
+    def __init__(self, group, wl, E, K, W, streams, device_index, fused_T=0):
         import torch
         from contracts_amd.engine import BatchedEnv
         self.torch, self.group, self.wl, self.E, self.K, self.W = torch, group, wl, E, K, W
@@ -185,8 +206,11 @@ class Runner:
         self.plane = E * n * self.esz
         # all action planes resident in HBM before any timing: pre-roll, warm-up, then K planes reused by every repeat
         # (each repeat continues from the state the previous one left, so no two repeats replay the same trajectory)
-        self.acts = torch.empty((PREROLL + W + K, E, n), dtype=dt, device="cuda")
-        self.env.synth_actions(SEED0 + 1, 0, PREROLL + W + K, self.acts.data_ptr())
+        # fused mode times whole launches: ceil(K / T) * T steps (reported as its own `steps`)
+        self.Kf = -(-K // fused_T) * fused_T if fused_T else K
+        planes = PREROLL + W + max(K, self.Kf)
+        self.acts = torch.empty((planes, E, n), dtype=dt, device="cuda")
+        self.env.synth_actions(SEED0 + 1, 0, planes, self.acts.data_ptr())
         self.env.synchronize()
         S = max(1, min(streams, E))
         self.S = S
@@ -210,8 +234,11 @@ class Runner:
 
     def measure(self, mode, T=0, min_repeats=3, min_seconds=1.0, max_repeats=25):
         torch, K, W, E, n = self.torch, self.K, self.W, self.E, self.wl["n"]
-        if mode == "fused" and self.traj is None:
-            self.traj = self.env.alloc_trajectory(max(1, min(T, K)))  # every per-step output kept, ring of T planes
+        if mode == "fused":
+            K = self.Kf  # whole launches only: every timed launch runs T steps
+            assert K % T == 0
+            if self.traj is None:
+                self.traj = self.env.alloc_trajectory(T)  # every per-step output kept, ring of T planes
         if W:
             self._issue(mode, PREROLL, W, T)
         elapsed, ev_ms = [], []
@@ -233,8 +260,9 @@ class Runner:
         self.env.check_faults()
         med = statistics.median(elapsed)
         units = self.group.world * E * n * K
-        launches_per_step = self.S if mode == "per_step" else self.S / float(T)
-        res = {"mode": mode, "value": units / med, "value_min": units / max(elapsed), "value_max": units / min(elapsed),
+        launches = self.S * K if mode == "per_step" else self.S * (K // T)  # launches actually issued per repeat
+        launches_per_step = launches / float(K)
+        res = {"mode": mode, "steps": K, "value": units / med, "value_min": units / max(elapsed), "value_max": units / min(elapsed),
                "repeats": len(elapsed), "ms_per_step": med / K * 1e3, "timed_seconds": sum(elapsed),
                # HIP events on the launch streams (slowest stream per repeat, median repeat): the device-side time of
                # the same K steps, without the host's launch / synchronize overhead
@@ -280,6 +308,121 @@ class Runner:
         del self.acts
 
 
+def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
+    """The RL-usable rate: one host iteration per env-step.  The batch is `num_slices` independent env slices, each with
+    its own HIP stream; per slice and step, torch computes the actions ON THE DEVICE from the observation the previous
+    step of that slice wrote (the pixel in front of every agent, mixed with a resident random plane so the action
+    distribution stays the benchmark's uniform one: two elementwise torch kernels), then ce_step_range steps the slice
+    from that device pointer.  No joins between slices: one slice's policy and kernel tail overlap another's step."""
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    kind, n = wl["kind"], wl["n"]
+    A = 8 if kind == "cleanup" else 7
+    env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index)
+    env.seed(seed0=SEED0)
+    env.reset()
+    obs = env.torch_tensors()["obs"]  # uint8 [E, n, 15, 15, 3], strided view of the engine's pitched buffer
+    ahead = obs[:, :, 6, 7, 1]        # green channel of the cell in front of the agent: [E, n], stride-only view
+    R = 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    noise = torch.randint(0, 256, (R, E, n), dtype=torch.uint8, device="cuda", generator=g)
+    tmp = torch.empty((E, n), dtype=torch.uint8, device="cuda")
+    acts = torch.zeros((E, n), dtype=torch.uint8, device="cuda")
+    S = max(1, num_slices)
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    bounds = [(E * s // S, E * (s + 1) // S) for s in range(S)]
+    pre = torch.empty((PREROLL, E, n), dtype=torch.uint8, device="cuda")
+    env.synth_actions(SEED0 + 1, 0, PREROLL, pre.data_ptr())
+    env.rollout_device(pre.data_ptr(), PREROLL, [st.cuda_stream for st in streams])
+    torch.cuda.synchronize()
+
+    def tick(t):
+        nz = noise[t % R]
+        for st, (b0, b1) in zip(streams, bounds):
+            with torch.cuda.stream(st):
+                torch.add(ahead[b0:b1], nz[b0:b1], out=tmp[b0:b1])        # uint8 wrap-around: uniform whatever the pixel
+                if A == 8:
+                    torch.bitwise_and(tmp[b0:b1], 7, out=acts[b0:b1])
+                else:
+                    torch.remainder(tmp[b0:b1], A, out=acts[b0:b1])
+                env.step_range_device(acts.data_ptr(), b0, b1 - b0, stream=st.cuda_stream)
+
+    for t in range(50):
+        tick(t)
+    torch.cuda.synchronize()
+    K, elapsed, t = 500, [], 50
+    while len(elapsed) < 3 or sum(elapsed) < min_seconds:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            tick(t)
+            t += 1
+        torch.cuda.synchronize()
+        elapsed.append(time.perf_counter() - t0)
+    env.check_faults()
+    med = statistics.median(elapsed)
+    out = {"value": E * n * K / med, "unit": "agent-steps/s", "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
+           "timed_seconds": sum(elapsed), "slices": S, "host_iterations_per_step": 1, "launches_per_step": 3 * S,
+           "policy": "torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident "
+                     "uniform byte) mod %d — two elementwise kernels per slice and step" % A,
+           "workload": wl["name"]}
+    env.close()
+    return out
+
+
+def boundary(wl, E, device_index):
+    """The RLlib vector hook at the headline batch (contracts_amd.vector_env.BatchedBaseEnv), as a sampler on
+    the host would drive it — PCIe- and Python-inclusive, never `value`:
+      tensor path   send_actions_array(host uint8 [E, n]) + poll_tensors() (observations stay in HBM; rewards / dones read back)
+      dict protocol send_actions({env: {agent: a}}) + poll() with every env's obs / reward / done / info dictionaries built"""
+    import numpy as np
+    from contracts_amd.vector_env import BatchedBaseEnv
+    kind, n = wl["kind"], wl["n"]
+    A = 8 if kind == "cleanup" else 7
+    venv = BatchedBaseEnv(kind, E, n, contract=wl["contract"], seed0=SEED0, horizon=1000, device=device_index)
+    venv.poll()
+    rs = np.random.RandomState(0)
+    planes = rs.randint(A, size=(8, E, n)).astype(np.uint8)
+    out = {"workload": wl["name"], "envs": E}
+    # tensor path
+    for t in range(5):
+        venv.send_actions_array(planes[t % 8])
+        venv.poll_tensors()
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.5 or steps < 20:
+        venv.send_actions_array(planes[steps % 8])
+        tt = venv.poll_tensors()
+        tt["reward"].sum().item()  # the sampler looks at the step's rewards (forces completion)
+        steps += 1
+    dt = time.perf_counter() - t0
+    out["tensor_path"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                          "what": "send_actions_array (host action plane over PCIe) + poll_tensors (zero-copy device views)"}
+    # dict protocol
+    keys = ["a%d" % i for i in range(n)]
+
+    def dict_tick(t):
+        a = planes[t % 8].tolist()
+        venv.send_actions({e: dict(zip(keys, a[e])) for e in range(E)})
+        obs, rew, dones, infos, _ = venv.poll()
+        k = 0
+        for e in obs:  # a sampler touches every env's dictionaries
+            o, r, d, i = obs[e], rew[e], dones[e], infos[e]
+            k += len(o)
+        return k
+
+    dict_tick(0)
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 1.0 or steps < 2:
+        dict_tick(steps + 1)
+        steps += 1
+    dt = time.perf_counter() - t0
+    out["dict_protocol"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "env_steps_per_s": E * steps / dt,
+                            "ms_per_step": dt / steps * 1e3, "steps": steps,
+                            "what": "send_actions + poll with every env's obs (float64 image) / reward / done / info dictionaries materialised"}
+    venv.stop()
+    return out
+
+
 KERNEL = {"cleanup": ("k_grid_step<cleanup>", "k_grid_rollout<cleanup>"), "harvest": ("k_grid_step<harvest>", "k_grid_rollout<harvest>"),
           "selfdrive": ("k_sd_step", "k_sd_rollout"), "harvest_features": ("k_feat_step<harvest>", "k_feat_rollout<harvest>"),
           "cleanup_features": ("k_feat_step<cleanup>", "k_feat_rollout<cleanup>")}
@@ -313,11 +456,12 @@ def run_rank(a):
     E = a.envs_per_gpu or wl["E"]
     K, W = a.steps, a.warmup
 
-    r = Runner(group, wl, E, K, W, a.streams, local_rank)
-    head = r.measure("per_step", min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=1000)
+    do_fused = bool(a.fused_steps) and wl["kind"] in FUSED_KINDS
+    r = Runner(group, wl, E, K, W, a.streams, local_rank, a.fused_steps if do_fused else 0)
+    head = r.measure("per_step", min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=100000)
     fused = None
-    if a.fused_steps and wl["kind"] in FUSED_KINDS:
-        fused = r.measure("fused", T=a.fused_steps, min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=1000)
+    if do_fused:
+        fused = r.measure("fused", T=a.fused_steps, min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=100000)
     stats = r.sanity()
     out = None
     if rank == 0:
@@ -340,32 +484,44 @@ def run_rank(a):
         if fused is not None:
             fr = r.roofline(fused, kfused, "fused") if wl["algo"] else None
             out["fused"] = dict(fused, roofline=fr, note="ce_rollout_fused: %d steps per launch, env state resident on chip, every "
-                                "step's obs / rewards / infos / features / done written to a %d-plane trajectory ring; results "
-                                "bit-identical to per_step (tests/test_fused_rollout_gpu.py)" % (fused["steps_per_launch"], fused["trajectory_planes"]))
+                                "step's obs / rewards / infos / features / done written to a %d-plane trajectory ring; whole launches "
+                                "only (%d timed steps per repeat); results bit-identical to per_step (tests/test_fused_rollout_gpu.py)"
+                                % (fused["steps_per_launch"], fused["trajectory_planes"], fused["steps"]))
     r.close()
 
-    # the other BASELINE configs, same protocol with a shorter timed region (single-GPU workloads: rank 0's GPU only
-    # would idle the others, so every rank runs its shard of them too and the line reports the whole-job value)
+    # the other BASELINE configs, same protocol: repeats of --config-steps steps (independent of --steps) until
+    # --config-seconds of timed wall per mode (single-GPU workloads: rank 0's GPU only would idle the others, so every
+    # rank runs its shard of them too and the line reports the whole-job value)
     if not a.no_configs and not custom:
         rows = []
         for key in ("C2", "C3", "C5", "C1"):
             w = WORKLOADS[key]
-            rr = Runner(group, w, w["E"], min(K, 300), min(W, 20), a.streams, local_rank)
-            m = rr.measure("per_step", min_repeats=3, min_seconds=0.2, max_repeats=5)
+            w_fused = bool(a.fused_steps) and w["kind"] in FUSED_KINDS
+            rr = Runner(group, w, w["E"], a.config_steps, min(W, 20), a.streams, local_rank, a.fused_steps if w_fused else 0)
+            m = rr.measure("per_step", min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
             row = {"config": key, "workload": w["name"], "dtype": DTYPE[w["kind"]], "envs_per_gpu": w["E"], "agents": w["n"],
-                   "value": m["value"], "unit": "agent-steps/s", "ms_per_step": m["ms_per_step"], "repeats": m["repeats"],
-                   "steps": rr.K, "roofline": rr.roofline(m, KERNEL[w["kind"]][0], "per_step_" + key)}
-            if a.fused_steps and w["kind"] in FUSED_KINDS:
-                f = rr.measure("fused", T=a.fused_steps, min_repeats=3, min_seconds=0.2, max_repeats=5)
+                   "value": m["value"], "value_min": m["value_min"], "value_max": m["value_max"], "unit": "agent-steps/s",
+                   "ms_per_step": m["ms_per_step"], "repeats": m["repeats"], "steps": m["steps"],
+                   "timed_seconds": m["timed_seconds"], "roofline": rr.roofline(m, KERNEL[w["kind"]][0], "per_step_" + key)}
+            if w_fused:
+                f = rr.measure("fused", T=a.fused_steps, min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
                 row["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps_per_launch": f["steps_per_launch"],
+                                "steps": f["steps"], "repeats": f["repeats"], "launches_per_step": f["launches_per_step"],
                                 "roofline_frac": rr.roofline(f, KERNEL[w["kind"]][1], "fused_" + key)["frac"]}
             rows.append(row)
             rr.close()
         if out is not None:
             out["configs"] = rows
+    if out is not None and world == 1 and not custom:
+        if not a.no_closed_loop:
+            out["closed_loop"] = closed_loop(WORKLOADS["C4"], E, local_rank, a.streams)
+        if not a.no_boundary:
+            out["boundary"] = boundary(WORKLOADS["C4"], E, local_rank)
     if out is not None:
-        if not a.no_cpu_baseline and world == 1 and wl["kind"] in ("cleanup", "harvest"):
+        if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+            for row in out.get("configs", []):  # the CPU path beside every GPU config, same E rule / seeds / actions
+                row["cpu_baseline"] = cpu_baseline(WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
         print(json.dumps(out), flush=True)
     group.close()
 
@@ -375,7 +531,7 @@ def main():
     if a.gpus > 1 and not parallel.launched_by_torchrun():
         # `python bench.py --gpus N` by itself: N fresh rank processes on this node, one per GPU, started before this
         # process has touched the GPU (no exec over a HIP context); rank 0 prints the line
-        sys.exit(parallel.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+        sys.exit(parallel.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus, timeout=a.launch_timeout))
     run_rank(a)
 
 

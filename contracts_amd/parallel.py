@@ -56,11 +56,18 @@ def free_port():
     return port
 
 
-def spawn_local_ranks(script, argv, nprocs, extra_env=None, timeout=None):
+def spawn_local_ranks(script, argv, nprocs, extra_env=None, timeout=None, poll_s=0.2):
     """`python script argv...` as nprocs fresh processes of one node, rank i with RANK = LOCAL_RANK = i and a 127.0.0.1
     rendezvous — what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` exports.  Must be called before the
     calling process has touched the GPU (children are started with subprocess, never exec'd over a process that holds
-    a HIP context).  Children inherit stdout / stderr (rank 0 prints the report).  Returns the largest exit code."""
+    a HIP context).  Children inherit stdout / stderr (rank 0 prints the report).
+
+    Fail fast: all children are polled together; the first non-zero exit, the overall deadline `timeout` (seconds, one
+    limit for the whole job, not per rank) or a SIGTERM / SIGINT to this process ends the remaining ranks (exactly the
+    processes started here, by PID) instead of leaving them blocked in a barrier their dead sibling will never reach.
+    Returns the largest exit code (124 on the deadline, 143 when terminated)."""
+    import signal
+    import time
     port = free_port()
     procs = []
     for r in range(nprocs):
@@ -71,16 +78,48 @@ def spawn_local_ranks(script, argv, nprocs, extra_env=None, timeout=None):
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    stop = {"sig": 0}
+
+    def on_signal(signum, frame):
+        stop["sig"] = signum
+
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:  # not the main thread: no handler, the deadline still applies
+            pass
+    deadline = None if timeout is None else time.monotonic() + timeout
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait(timeout=timeout)))
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed:
+                rc = max(abs(c) for c in failed)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if stop["sig"]:
+                rc = 128 + stop["sig"]
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                rc = 124
+                break
+            time.sleep(poll_s)
     finally:
         for p in procs:  # exactly the processes started here, by PID
             if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 

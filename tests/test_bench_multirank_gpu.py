@@ -14,18 +14,18 @@ ARGS = ["--gpus", "2", "--steps", "60", "--warmup", "10", "--envs-per-gpu", "204
         "--min-seconds", "0.05"]
 
 
-def _check(out):
+def _check(out, world=2, envs=2048):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout  # only rank 0 reports
     row = json.loads(lines[0])
-    assert row["n_gpus"] == 2 and row["steps"] == 60 and row["scaling"] == "weak" and row["value"] > 0
-    assert row["config"]["global_envs"] == 2 * 2048 and row["config"]["parallelism"].startswith("env-shard x2")
+    assert row["n_gpus"] == world and row["steps"] == 60 and row["scaling"] == "weak" and row["value"] > 0
+    assert row["config"]["global_envs"] == world * envs and row["config"]["parallelism"].startswith("env-shard x%d" % world)
     assert row["repeats"] >= 3 and row["value_min"] <= row["value"] <= row["value_max"]
     assert "cpu_baseline" not in row
     # the roofline figure follows from the wall clock of the line itself
     rf = row["roofline"]
-    assert abs(rf["frac"] * rf["peak"] * 1e9 * row["ms_per_step"] * 1e-3 - 7235 * 2048) < 0.01 * 7235 * 2048
+    assert abs(rf["frac"] * rf["peak"] * 1e9 * row["ms_per_step"] * 1e-3 - 7235 * envs) < 0.01 * 7235 * envs
     assert row["fused"]["value"] > 0 and row["fused"]["steps_per_launch"] == 16
     return row
 
@@ -48,20 +48,44 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_share_one_gpu():
+    """the launch the driver uses for the 8-GPU scaling point (`torch.distributed.run --nproc-per-node 8 bench.py --gpus
+    8`): eight rank processes, rendezvous, shard bases g * E, barrier + MAX over ranks, one line from rank 0 — here all on
+    GPU 0 with a small shard each (functional only)"""
+    env = dict(os.environ, CONTRACTS_BENCH_BACKEND="gloo", CONTRACTS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [a if a != "2" else "8" for a in ARGS]
+    args[args.index("--envs-per-gpu") + 1] = "512"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py")] + args
+    _check(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900), world=8, envs=512)
+
+
+@pytest.mark.gpu
 def test_bench_default_line_has_every_config():
     """one GPU, short: the line carries the headline, the fused mode, every BASELINE config and the CPU baseline"""
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--min-seconds", "0.05",
-           "--cpu-seconds", "1.0"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.05",
+           "--cpu-seconds", "1.0", "--config-steps", "48", "--config-seconds", "0.05", "--config-cpu-seconds", "0.5"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     row = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert row["metric"] == "agent-steps/sec" and row["n_gpus"] == 1 and row["dtype"] == "u8"
     assert [c["config"] for c in row["configs"]] == ["C2", "C3", "C5", "C1"]
     for c in row["configs"]:
-        assert c["value"] > 0 and 0 < c["roofline"]["frac"] < 1
+        assert c["value"] > 0 and 0 < c["roofline"]["frac"] < 1 and c["steps"] == 48
+        assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["cores"] >= 1
+        # fused rows time whole launches and report the launches actually issued
+        assert c["fused"]["steps"] % c["fused"]["steps_per_launch"] == 0
+        assert abs(c["fused"]["launches_per_step"] * c["fused"]["steps_per_launch"] - 3) < 1e-9
     assert row["cpu_baseline"]["kind"] == "port" and row["cpu_baseline"]["value"] > 0
+    # --steps 20 with 16-step fused launches: 32 timed steps, two launches per slice
+    assert row["fused"]["steps"] == 32 and row["fused"]["steps_per_launch"] == 16
+    assert abs(row["fused"]["launches_per_step"] - 3 / 16.0) < 1e-9
+    cl = row["closed_loop"]
+    assert cl["value"] > 0 and cl["host_iterations_per_step"] == 1 and cl["timed_seconds"] >= 0.5
+    bd = row["boundary"]
+    assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > 0
     rf = row["roofline"]
     assert abs(rf["frac"] * 8000e9 * row["ms_per_step"] * 1e-3 - 7235 * 16384) < 0.01 * 7235 * 16384

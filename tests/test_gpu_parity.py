@@ -319,6 +319,82 @@ def test_full_size_partition_invariance_and_oracle_sample(cfg):
 
 
 @pytest.mark.gpu
+def test_eight_shard_global_range_on_one_gpu():
+    """BASELINE config 3 at its GLOBAL size — cleanup_new n = 8 + CleanupContract, 131 072 envs sharded over 8 GPUs as
+    16 384 per rank with env_index_base = g * 16 384 (runner.py:51-82: one env per worker, seeds keyed by the worker
+    index) — on one GPU: one handle that owns all 131 072 envs against eight handles that own one shard each, stepped
+    the way bench.py steps a rank (three slices on three streams), a horizon short enough for several in-launch resets.
+    Every persistent field and every output must be byte-identical, and a sample of envs from shards 0, 3 and 7 (global
+    indices >= 114 688 included) must agree with the CPU oracle seeded with the same global indices."""
+    import hashlib
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    from oracle.pyoracle import Oracle
+    kind, n, G, Eg, T, seed0 = "cleanup", 8, 8, 16384, 26, 73907
+    E = G * Eg
+    kw = dict(contract="cleanup", auto_reset=True, horizon=11)
+    fields = FULL_FIELDS[kind] + ("timestep", "done", "info", "base_reward", "spawn_perm")
+    whole = BatchedEnv(kind, E, n, **kw)
+    acts = torch.empty((T, E, n), dtype=torch.uint8, device="cuda")
+    whole.synth_actions(seed0 + 1, 0, T, acts.data_ptr())  # keyed by the global env index
+    whole.seed(seed0=seed0)
+    whole.reset()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    handles = [s.cuda_stream for s in streams]
+    whole.rollout_device(acts.data_ptr(), T, handles)
+    torch.cuda.synchronize()
+    whole.check_faults()
+    shards = []
+    for g in range(G):
+        env = BatchedEnv(kind, Eg, n, env_index_base=g * Eg, **kw)
+        a_g = acts[:, g * Eg:(g + 1) * Eg].contiguous()
+        # the shard's own generator must give the planes the whole-batch call gave for its index range
+        chk = torch.empty_like(a_g)
+        env.synth_actions(seed0 + 1, 0, T, chk.data_ptr())
+        env.synchronize()
+        assert torch.equal(chk, a_g), "synthetic actions of shard %d are not keyed by the global index" % g
+        env.seed(seed0=seed0)
+        env.reset()
+        env.rollout_device(a_g.data_ptr(), T, handles)
+        torch.cuda.synchronize()
+        env.check_faults()
+        shards.append(env)
+    for f in fields:
+        a = whole.download(f, raw=True)
+        h0 = hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        h = hashlib.sha256()
+        for env in shards:
+            h.update(np.ascontiguousarray(env.download(f, raw=True)).tobytes())
+        assert h.hexdigest() == h0, f
+    assert int(whole.download("int_metrics")[:, 0].sum()) >= 0 and whole.download("timestep").max() <= 11
+    # oracle sample: first / last envs of shards 0, 3, 7 + random picks inside them
+    rs = np.random.RandomState(8)
+    pick = []
+    for g in (0, 3, 7):
+        pick += [g * Eg, g * Eg + 1, (g + 1) * Eg - 1] + list(g * Eg + rs.choice(Eg, size=13, replace=False))
+    pick = np.unique(np.array(pick))
+    assert pick.max() >= 114688
+    orc = Oracle(kind, len(pick), n, **kw)
+    orc.seed((pick + seed0).astype(np.uint64))
+    orc.reset()
+    a_host = acts[:, torch.from_numpy(pick).cuda()].cpu().numpy()
+    for t in range(T):
+        orc.step(a_host[t])
+    for f in FULL_FIELDS[kind] + ("timestep", "done", "info", "base_reward"):
+        a, b = whole.download(f)[pick], getattr(orc, f)
+        if f == "rng":
+            a, b = a[:, :625], b[:, :625]
+        if a.dtype.kind == "f":
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9, err_msg=f)
+        else:
+            assert np.array_equal(a, b), f
+    for env in shards:
+        env.close()
+    whole.close()
+    orc.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,contract", [("cleanup", 4, "cleanup"), ("harvest", 5, "harvest_local"), ("cleanup_features", 3, "cleanup")])
 def test_external_theta_one_contract_per_env(kind, n, contract):
     """CE_FLAG_EXTERNAL_THETA: the caller writes one contract parameter per env (batched evaluation of many sampled

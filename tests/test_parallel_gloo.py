@@ -65,3 +65,25 @@ def test_bench_self_launch_starts_ranks_before_touching_the_gpu(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert p.stderr.count("needs an MI355X") == 2  # both ranks were started and both refused
+
+
+def test_launcher_fails_fast_when_one_rank_dies(tmp_path):
+    """one rank exits non-zero while its sibling would block for a minute (a barrier its dead peer never reaches): the
+    launcher notices within its polling interval, ends the survivor (by PID) and reports the failing exit code"""
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+    t0 = time.monotonic()
+    rc = parallel.spawn_local_ranks(str(script), [], 2, timeout=120)
+    assert rc == 7 and time.monotonic() - t0 < 20
+
+
+def test_launcher_deadline_is_for_the_whole_job(tmp_path):
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text("import time\ntime.sleep(60)\n")
+    t0 = time.monotonic()
+    rc = parallel.spawn_local_ranks(str(script), [], 3, timeout=2.0)
+    assert rc == 124 and time.monotonic() - t0 < 15
