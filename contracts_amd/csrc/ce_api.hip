@@ -123,6 +123,12 @@ struct ce_engine {
   hipEvent_t ev_start, ev_stop;
   hipEvent_t ev_mask;  // recorded behind the last launch that reads d_mask: the staging buffer is reused only after it
   bool mask_in_flight;
+  // ce_reset(stream) followed by steps on OTHER streams (env slices on their own streams): those streams wait for the
+  // reset once (hipStreamWaitEvent), so the common "reset, then roll out on side streams" sequence needs no host sync
+  hipEvent_t ev_reset;
+  void* reset_stream;
+  uint64_t reset_gen;
+  std::vector<std::pair<void*, uint64_t>> reset_seen;  // (stream, generation it has already waited for)
   bool timing_armed;
   uint32_t timed_launches;
 };
@@ -193,6 +199,9 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (h->cfg.horizon == 0) h->cfg.horizon = 1000;
   h->timing_armed = false;
   h->mask_in_flight = false;
+  h->ev_reset = nullptr;
+  h->reset_stream = nullptr;
+  h->reset_gen = 0;
   h->timed_launches = 0;
   h->d_seeds = nullptr;
   h->d_mask = nullptr;
@@ -214,7 +223,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return fail(h, CE_ENODEV, "hipGetDeviceProperties", e);
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(h, CE_ENODEV, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
   if (hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&h->ev_mask, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming) != hipSuccess)
     return fail(h, CE_ENODEV, "hipEventCreate");
 
   const size_t E = cfg->num_envs, n = cfg->num_agents;
@@ -322,6 +332,7 @@ extern "C" int ce_destroy(ce_handle h) {
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   if (h->ev_mask) (void)hipEventDestroy(h->ev_mask);
+  if (h->ev_reset) (void)hipEventDestroy(h->ev_reset);
   delete h;
   return CE_OK;
 }
@@ -437,6 +448,22 @@ static void begin_call(ce_engine* h) {
   (void)hipGetLastError();
 }
 
+// make `stream` wait for the last ce_reset if that ran on a different stream and this one has not waited for it yet
+static void order_after_reset(ce_engine* h, void* stream) {
+  if (h->reset_gen == 0 || stream == h->reset_stream) return;
+  for (auto& it : h->reset_seen) {
+    if (it.first == stream) {
+      if (it.second == h->reset_gen) return;
+      it.second = h->reset_gen;
+      (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
+      return;
+    }
+  }
+  if (h->reset_seen.size() >= 64) h->reset_seen.clear();
+  h->reset_seen.emplace_back(stream, h->reset_gen);
+  (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
+}
+
 static int check_launch(ce_engine* h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, CE_ENODEV, what, e);
@@ -527,6 +554,10 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
     launch_sd_reset(p, stream);
   }
   if (dmask && hipEventRecord(h->ev_mask, (hipStream_t)stream) == hipSuccess) h->mask_in_flight = true;
+  if (hipEventRecord(h->ev_reset, (hipStream_t)stream) == hipSuccess) {
+    h->reset_stream = stream;
+    h->reset_gen += 1;
+  }
   return check_launch(h, "reset kernel");
 }
 
@@ -535,6 +566,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
   if (!h || !actions) return CE_EINVAL;
   if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
   begin_call(h);
+  order_after_reset(h, stream);
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
@@ -626,6 +658,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       ra.env_first = (uint32_t)(E * sl / num_slices);
       ra.env_end = (uint32_t)(E * (sl + 1) / num_slices);
       void* stream = streams ? streams[sl] : nullptr;
+      order_after_reset(h, stream);
       if (is_grid(h->cfg)) launch_grid_rollout((int)h->cfg.kind, h->d_gparams, ra, stream);
       else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);
       else launch_feat_rollout((int)h->cfg.kind, h->d_gparams, ra, stream);
@@ -800,6 +833,7 @@ extern "C" int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_co
       h->gather_bytes = 0;
       const size_t want = total < 65536 ? 65536 : total;
       if ((e = hipMalloc((void**)&h->d_gather, want)) != hipSuccess) return fail(h, CE_ENOMEM, "gather buffer", e);
+      (void)hipMemsetAsync(h->d_gather, 0, want, nullptr);  // the 16-byte alignment gaps between fields are copied back too
       h->gather_bytes = want;
     }
     size_t off = 0;

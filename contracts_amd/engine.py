@@ -85,7 +85,7 @@ class Trajectory:
             shapes = {"obs": ((E, b.obs_env_stride), torch.uint8), "features": ((E, n, b.num_features), torch.int16)}
         shapes.update({"base_reward": ((E, n), torch.int32), "reward": ((E, n), torch.float64), "done": ((E,), torch.uint8),
                        "info": ((E, n, 2), torch.uint8)})
-        self.env, self.P = env, P
+        self.env, self.P, self.E, self.n = env, P, E, n
         self.tensors = {}
         self.c = _lib.CeTraj()
         self.c.num_planes, self.c.first_plane = P, 0
@@ -229,6 +229,10 @@ class BatchedEnv:
         to num_steps step_device() calls (see ce_rollout_fused).  stream_handles: raw HIP stream handles, one contiguous
         env slice per stream (None = one slice on the null stream)."""
         self._dirty()
+        if traj is not None and (traj.E, traj.n, traj.env.kind) != (self.E, self.n, self.kind):
+            # the C side cannot bounds-check caller-owned arrays: a ring allocated for another batch would be overrun
+            raise ValueError("trajectory was allocated for %s E=%d n=%d, this handle is %s E=%d n=%d"
+                             % (traj.env.kind, traj.E, traj.n, self.kind, self.E, self.n))
         t = None if traj is None else C.byref(traj.c)
         ns, arr = 1, None
         if stream_handles:
@@ -270,8 +274,12 @@ class BatchedEnv:
         }[field]
 
     def prefetch(self, fields):
-        """fetch several fields in one call (ce_download_many); download() serves them until the next launch / upload"""
+        """fetch several fields in one call (ce_download_many); download() serves them until the next launch / upload.
+        The cached arrays are handed out read-only (a caller that wants to edit one copies it): mutating a shared cache
+        entry would silently corrupt every later download() of that field."""
         self._pref = self.download_many([f for f in fields if f in self._fields_present()])
+        for a in self._pref.values():
+            a.setflags(write=False)
 
     def _fields_present(self):
         b = self.b
@@ -356,20 +364,43 @@ class BatchedEnv:
         else:
             fields = self._STATE_SD if self.kind == "selfdrive" else [
                 f for f in self._STATE_GRID if not (f == "waste_perm" and self.kind != "cleanup")]
-        out = {f: self.download(f, raw=True) for f in fields}
-        out["_meta"] = np.array([_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon],
-                                np.int64)
+        out = {f: np.array(self.download(f, raw=True)) for f in fields}
+        out["_meta"], out["_meta_f64"] = self._meta()
         return out
+
+    def _meta(self):
+        """what a checkpoint must agree on for the continuation to be bit-identical: the layout (ABI version: field
+        shapes such as the metric rows and the grid pitch follow it), the batch, and every parameter that enters a step"""
+        c = self.cfg
+        return (np.array([_lib.KIND[self.kind], self.E, self.n, c.contract, c.flags, c.horizon, _lib.CE_ABI_VERSION,
+                          c.env_index_base], np.int64),
+                np.array([c.contract_low, c.contract_high, c.null_prob, c.alpha, c.beta, c.low_bound, c.high_bound,
+                          c.start_vel, c.start_vel_ambulance], np.float64))
+
+    _META_NAMES = ("kind", "num_envs", "num_agents", "contract", "flags", "horizon", "abi_version", "env_index_base")
+    _META_F64_NAMES = ("contract_low", "contract_high", "null_prob", "alpha", "beta", "low_bound", "high_bound", "start_vel",
+                       "start_vel_ambulance")
 
     def load_state_dict(self, state):
         meta = [int(x) for x in state["_meta"]]
-        mine = [_lib.KIND[self.kind], self.E, self.n, self.cfg.contract, self.cfg.flags, self.cfg.horizon]
+        mine_i, mine_f = self._meta()
+        mine = [int(x) for x in mine_i]
+        if len(meta) < len(mine) or "_meta_f64" not in state:
+            raise ValueError("checkpoint predates the versioned format (no ABI version / float parameters in _meta): it was "
+                             "written by an older engine build whose field layout this one (ABI v%d) cannot verify"
+                             % _lib.CE_ABI_VERSION)
+        if meta[6] != mine[6]:
+            raise ValueError("checkpoint was written by engine ABI v%d, this build is ABI v%d (field layouts differ)"
+                             % (meta[6], mine[6]))
         if meta[:3] != mine[:3]:
             raise ValueError("checkpoint is for kind/E/n %s, engine has %s" % (meta[:3], mine[:3]))
-        if meta[3:] != mine[3:]:  # stepping on would silently not be bit-identical to the run that was saved
-            raise ValueError("checkpoint was taken with contract/flags/horizon %s, engine has %s" % (meta[3:], mine[3:]))
+        bad = [n for n, a, b in zip(self._META_NAMES, meta, mine) if a != b]
+        theirs_f = [float(x) for x in state["_meta_f64"]]
+        bad += [n for n, a, b in zip(self._META_F64_NAMES, theirs_f, mine_f) if a != float(b)]
+        if bad:  # stepping on would silently not be bit-identical to the run that was saved
+            raise ValueError("checkpoint and engine disagree on %s: continuing would not reproduce the saved run" % ", ".join(bad))
         # error_flags first: the validated grid upload may raise CE_FAULT_BAD_GRID, which must survive the restore
-        for f in sorted((f for f in state if f != "_meta"), key=lambda f: f != "error_flags"):
+        for f in sorted((f for f in state if not f.startswith("_meta")), key=lambda f: f != "error_flags"):
             self.upload(f, state[f])
         self.check_faults()
 

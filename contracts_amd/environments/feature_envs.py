@@ -17,7 +17,8 @@ import numpy as np
 from .. import spaces
 from .._lib import static_map
 from ..engine import BatchedEnv
-from .map_env import _Base, pull_global_rng, push_global_rng
+from .map_env import _Base, pull_global_rng, push_global_rng, restore_pending_state
+from .vector_hook import VectorHookMixin
 from .metrics import episode_metrics
 
 HARVEST_SHAPE, CLEANUP_SHAPE = (16, 38), (25, 18)
@@ -25,7 +26,7 @@ N_APPLE = {"harvest_features": 155, "cleanup_features": 103}
 POTENTIAL_WASTE_AREA = 119
 
 
-class _FeatureEnv(_Base):
+class _FeatureEnv(VectorHookMixin, _Base):
     KIND = None
     N_ACTIONS = None
 
@@ -52,11 +53,7 @@ class _FeatureEnv(_Base):
                 self._engine.set_contract(c, lo, hi, null_prob)
             if getattr(self, "_external_theta", False):
                 self._engine.set_flags(external_theta=True)
-            pending = getattr(self, "_pending_state", None)
-            if pending:
-                for f, arr in pending.items():
-                    self._engine.upload(f, arr)
-                self._pending_state = None
+            restore_pending_state(self, self._engine)
         return self._engine
 
     _paints = False  # HarvestFeatures(image_obs=True) only
@@ -69,6 +66,8 @@ class _FeatureEnv(_Base):
         eng = d.pop("_engine", None)
         if eng is not None:
             d["_pending_state"] = {f: eng.download(f, raw=True) for f in self._STATE_FIELDS}
+            from .._lib import CE_ABI_VERSION
+            d["_pending_abi"] = CE_ABI_VERSION
         d["_engine"] = None
         return d
 
@@ -91,6 +90,7 @@ class _FeatureEnv(_Base):
             eng.prefetch(self._RESULT_FIELDS)
 
     def seed(self, seed=None):
+        self._vector_seed0 = seed
         if self._rng_mode == "global":
             import random
             np.random.seed(seed)

@@ -24,6 +24,8 @@ try:  # the real base class when RLlib is installed, so RLlib's isinstance check
 except Exception:
     _Base = object
 
+from .vector_hook import VectorHookMixin  # noqa: E402  (RLlib's to_base_env entry point)
+
 VIEW = 7
 # colour LUT of the reference (map_env.py:24-42, cleanup_new.py:42-47), indexed by engine cell code,
 # then agents '1'..'9'
@@ -56,6 +58,23 @@ def pull_global_rng(engine, st, python_random=False):
         import random
         ps = random.getstate()
         random.setstate((ps[0], tuple(int(x) for x in words[628:628 + 624]) + (int(words[628 + 624]),), ps[2]))
+
+
+def restore_pending_state(env, engine):
+    """upload the env state a pickled adapter carried over (`__getstate__`), after checking that it was written by the
+    same engine ABI: field layouts (metric rows, grid pitch, ...) follow the ABI version, and an older blob would
+    otherwise fail with an opaque size error inside ce_upload"""
+    from .._lib import CE_ABI_VERSION
+    pending = getattr(env, "_pending_state", None)
+    if not pending:
+        return
+    abi = getattr(env, "_pending_abi", None)
+    if abi != CE_ABI_VERSION:
+        raise ValueError("pickled %s carries env state of engine ABI v%s, this build is ABI v%d: re-create the env instead "
+                         "of unpickling it" % (type(env).__name__, abi, CE_ABI_VERSION))
+    for field, arr in pending.items():
+        engine.upload(field, arr)
+    env._pending_state = None
 
 
 def host_np_draw(env, fn):
@@ -100,7 +119,7 @@ class AgentView:
         return [self.row_size, self.col_size] + (np.asarray(pos) - self.pos)
 
 
-class GridEnvAdapter(_Base):
+class GridEnvAdapter(VectorHookMixin, _Base):
     KIND = None          # "cleanup" | "harvest"
     GRID_SHAPE = None    # (H, W)
     N_ACTIONS = None     # (disable_firing=True, False)
@@ -149,11 +168,7 @@ class GridEnvAdapter(_Base):
                 self._engine.set_contract(c, lo, hi, null_prob)
             if getattr(self, "_external_theta", False):
                 self._engine.set_flags(external_theta=True)
-            pending = getattr(self, "_pending_state", None)
-            if pending:
-                for field, arr in pending.items():
-                    self._engine.upload(field, arr)
-                self._pending_state = None
+            restore_pending_state(self, self._engine)
         return self._engine
 
     def _call(self, fn, *args):
@@ -176,6 +191,8 @@ class GridEnvAdapter(_Base):
         if eng is not None:
             fields = [f for f in self._STATE_FIELDS if not (f == "waste_perm" and self.KIND != "cleanup")]
             d["_pending_state"] = {f: eng.download(f, raw=True) for f in fields}
+            from .._lib import CE_ABI_VERSION
+            d["_pending_abi"] = CE_ABI_VERSION
         d["_engine"] = None
         return d
 
@@ -209,6 +226,7 @@ class GridEnvAdapter(_Base):
     # ------------------------------------------------------------------ reference API
     def seed(self, seed=None):
         """MapEnv.seed (map_env.py:344-345) == np.random.seed(seed)"""
+        self._vector_seed0 = seed  # to_base_env(num_envs > 1): replica i is seeded seed + i
         if self._rng_mode == "global":
             np.random.seed(seed)
         else:

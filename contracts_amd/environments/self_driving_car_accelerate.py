@@ -7,12 +7,13 @@ import numpy as np
 from .. import spaces
 from ..engine import BatchedEnv
 from .metrics import episode_metrics
-from .map_env import _Base, pull_global_rng, push_global_rng
+from .map_env import _Base, pull_global_rng, push_global_rng, restore_pending_state
+from .vector_hook import VectorHookMixin
 
 ACCEL_LOW_THRESH, ACCEL_HIGH_THRESH = -0.1, 0.1
 
 
-class SelfAcceleratingCarEnv(_Base):
+class SelfAcceleratingCarEnv(VectorHookMixin, _Base):
     def __init__(self, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8, num_agents=2,
                  collision_on=False, rng="global", device=0, **kwargs):
         self.num_agents = num_agents
@@ -39,11 +40,7 @@ class SelfAcceleratingCarEnv(_Base):
                 self._engine.set_contract(c, lo, hi, null_prob)
             if getattr(self, "_external_theta", False):  # a negotiate / combined / solver stage owns theta (set before pickling)
                 self._engine.set_flags(external_theta=True)
-            pending = getattr(self, "_pending_state", None)
-            if pending:
-                for f, arr in pending.items():
-                    self._engine.upload(f, arr)
-                self._pending_state = None
+            restore_pending_state(self, self._engine)
         return self._engine
 
     def __getstate__(self):
@@ -52,6 +49,8 @@ class SelfAcceleratingCarEnv(_Base):
         if eng is not None:
             d["_pending_state"] = {f: eng.download(f, raw=True) for f in ("sd_state", "rng", "theta", "f64_metrics", "int_metrics",
                                                                           "done", "done_agents", "error_flags")}
+            from .._lib import CE_ABI_VERSION
+            d["_pending_abi"] = CE_ABI_VERSION
         d["_engine"] = None
         return d
 
@@ -74,6 +73,7 @@ class SelfAcceleratingCarEnv(_Base):
             eng.prefetch(self._RESULT_FIELDS)
 
     def seed(self, seed=None):
+        self._vector_seed0 = seed
         if self._rng_mode == "global":
             import random
             np.random.seed(seed)

@@ -24,9 +24,10 @@ import numpy as np
 
 from .. import spaces
 from .map_env import _Base, host_np_draw
+from .vector_hook import VectorHookMixin
 
 
-class SeparateContractEnv(_Base):
+class SeparateContractEnv(VectorHookMixin, _Base):
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, base_env, contract, num_agents, convolutional, env_params=None, null_prob=0.0, **kwargs):
@@ -176,7 +177,7 @@ class SeparateContractSubgameStage(SeparateContractEnv):
         return self._with_contract(base_obs, ["a" + str(i) for i in range(self.num_agents)])
 
 
-class JointEnv(_Base):
+class JointEnv(VectorHookMixin, _Base):
     """Centralised-control view of a base env (reference two_stage_train.py:476-617): the single agent 'a0' sends one
     action per base agent and receives the summed reward, summed infos and one of three observations —
     `global_obs` (the whole colour map), `concatenated_obs` (all egocentric views stacked on the channel axis) or the

@@ -1,0 +1,130 @@
+"""`to_base_env()` for the drop-in env classes — the point where RLlib turns a `MultiAgentEnv` into the `BaseEnv` its
+sampler polls (ray/rllib/env/multi_agent_env.py: `MultiAgentEnv.to_base_env(make_env, num_envs, remote_envs,
+remote_env_batch_wait_ms, restart_failed_sub_environments)`; reference call sites: the env classes derive from
+`MultiAgentEnv` — environments/map_env.py:60, two_stage_train.py:17, self_driving_car_accelerate.py:18,
+harvest_features.py:60 — and `num_envs_per_worker` reaches RLlib through the trainer config built in
+utils/ray_config_utils.py:126-214).
+
+RLlib's own implementation wraps `num_envs` Python env objects and steps them one after the other.  Here, for
+`num_envs > 1`, the hook returns ONE `BatchedBaseEnv` over one engine handle with `num_envs` replicas configured like the
+env it was called on (kind, agents, horizon, firing / reward flags, contract and its bounds): a sampler tick is one kernel
+launch, with `runner.py` / `ray_config_utils.py` unchanged.  The replicas run private RNG streams seeded
+`seed0 + index` (`seed0` = the value last passed to `env.seed()`, else one draw from the process-global `np.random`, so
+seeded scripts stay reproducible).
+
+Configurations the batched hook does not serve — a single sub-env, remote sub-envs, grid envs in feature-vector or
+one-hot mode, a user-defined host contract, the negotiate / combined / solver stages — get `SubEnvBaseEnv`, which keeps
+RLlib's object-per-sub-env semantics over the adapters themselves (`make_env(i)` builds the additional ones).
+"""
+import numpy as np
+
+from ..vector_env import BatchedBaseEnv, _RLlibBaseEnv
+
+
+class SubEnvBaseEnv(_RLlibBaseEnv):
+    """`BaseEnv` protocol over a list of per-env adapter objects (what RLlib's MultiAgentEnvWrapper does): every
+    sub-env is stepped by its own `step()` call.  The fallback of `to_base_env` and the `num_envs == 1` case."""
+
+    def __init__(self, envs):
+        self.envs = list(envs)
+        self._fresh = set(range(len(self.envs)))
+        self._last = {}
+
+    def poll(self):
+        obs, rew, dones, infos = {}, {}, {}, {}
+        for i in sorted(self._fresh):
+            o = self.envs[i].reset()
+            obs[i], rew[i], dones[i] = o, {k: 0.0 for k in o}, {"__all__": False}
+            infos[i] = {k: {} for k in o}
+        self._fresh.clear()
+        for i, (o, r, d, inf) in self._last.items():
+            obs[i], rew[i], dones[i], infos[i] = o, r, d, inf
+        self._last = {}
+        return obs, rew, dones, infos, {}
+
+    def send_actions(self, action_dict):
+        for i, acts in action_dict.items():
+            self._last[i] = self.envs[i].step(acts)
+
+    def try_reset(self, env_id=None):
+        ids = range(len(self.envs)) if env_id is None else [env_id]
+        return {i: self.envs[i].reset() for i in ids}
+
+    def get_sub_environments(self, as_dict=False):
+        return dict(enumerate(self.envs)) if as_dict else self.envs
+
+    @property
+    def num_envs(self):
+        return len(self.envs)
+
+    def stop(self):
+        for e in self.envs:
+            close = getattr(e, "close", None)
+            if close:
+                close()
+
+
+def _engine_config(base):
+    """(kind, engine kwargs) of a base adapter, or None when the batched hook cannot serve its configuration"""
+    kind = getattr(base, "KIND", None)
+    if kind in ("cleanup", "harvest"):
+        if not base.image_obs or base.one_hot_id:
+            return None  # the vector hook hands out image observations only
+        return kind, dict(horizon=base.horizon, firing=not base.disable_firing, collective=base.use_collective_reward,
+                          inequity=base.inequity_averse_reward, alpha=base.alpha, beta=base.beta)
+    if kind in ("harvest_features", "cleanup_features"):
+        if getattr(base, "image_obs", False) and kind == "harvest_features":
+            return None  # the history-dependent painted map is a host-side view of the single-env adapter
+        return kind, dict(horizon=base.horizon)
+    if type(base).__name__ == "SelfAcceleratingCarEnv":
+        return "selfdrive", dict(collision_on=base.collision_on, low_bound=base.low_bound, high_bound=base.high_bound,
+                                 start_vel=base.start_vel, start_vel_ambulance=base.start_vel_ambulance)
+    return None
+
+
+def vector_seed0(env):
+    s = getattr(env, "_vector_seed0", None)
+    if s is None:
+        s = int(np.random.randint(0, 2 ** 31 - 1))
+    return int(s)
+
+
+def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_batch_wait_ms=0,
+                restart_failed_sub_environments=False, seed0=None):
+    """see the module docstring; `env` is a base adapter or a SeparateContractSubgameStage around one"""
+    from .two_stage_train import SeparateContractSubgameStage
+    num_envs = int(num_envs)
+    base, contract_kw, convolutional = env, {}, True
+    batched_ok = num_envs > 1 and not remote_envs
+    if isinstance(env, SeparateContractSubgameStage):
+        base = env.base_env
+        convolutional = env.convolutional
+        if env._host_contract or getattr(base, "_external_theta", False):
+            batched_ok = False
+        else:
+            name, lo, hi, null_prob = env.contract.engine_spec(env.null_prob)
+            contract_kw = dict(contract=name, contract_low=lo, contract_high=hi, null_prob=null_prob)
+    elif not hasattr(env, "_ensure_engine"):
+        batched_ok = False  # a negotiate / combined / solver stage or JointEnv: host-side protocol per env object
+    cfg = _engine_config(base) if batched_ok else None
+    if cfg is None:
+        envs = [env]
+        if num_envs > 1:
+            if make_env is None:
+                raise ValueError("to_base_env(num_envs=%d) of this configuration needs make_env to build the other sub-envs" % num_envs)
+            envs += [make_env(i) for i in range(1, num_envs)]
+        return SubEnvBaseEnv(envs)
+    kind, kw = cfg
+    kw.update(contract_kw)
+    if seed0 is None:
+        seed0 = vector_seed0(base)
+    return BatchedBaseEnv(kind, num_envs, base.num_agents, seed0=seed0, convolutional=convolutional,
+                          device=getattr(base, "_device", 0), **kw)
+
+
+class VectorHookMixin:
+    """gives an env class RLlib's `to_base_env` entry point (same signature), resolved by `to_base_env` above"""
+
+    def to_base_env(self, make_env=None, num_envs=1, remote_envs=False, remote_env_batch_wait_ms=0,
+                    restart_failed_sub_environments=False):
+        return to_base_env(self, make_env, num_envs, remote_envs, remote_env_batch_wait_ms, restart_failed_sub_environments)

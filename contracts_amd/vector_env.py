@@ -11,9 +11,11 @@ Built to stay usable at E = 16 384:
   * one device -> host copy per field and tick (a snapshot), never per env;
   * the per-env dictionaries are LAZY: `poll()` returns mappings that build an env's entry when it is looked up, straight
     from the snapshot arrays (an env nobody looks at costs nothing);
-  * resets are batched: the first `try_reset` after a tick resets EVERY env that reported done in ONE masked launch and
-    one copy; the following `try_reset(e)` calls are served from that batch — a synchronized horizon (all E envs done
-    in the same tick) costs O(E), not O(E^2);
+  * resets are batched (`batch_done_resets=True`, the default): the first `try_reset` after a tick resets EVERY env that
+    reported done in ONE masked launch and one copy; the following `try_reset(e)` calls are served from that batch — a
+    synchronized horizon (all E envs done in the same tick) costs O(E), not O(E^2).  SIDE EFFECT: a done env the
+    caller never asks about is reset as well (RLlib's sampler resets every done sub-env, so it never notices);
+    `batch_done_resets=False` resets exactly the env asked for;
   * `poll_tensors()` / `send_actions_array()` skip Python containers altogether (observations stay in HBM).
 
 When `ray` is importable the class derives from `ray.rllib.env.BaseEnv`, otherwise it is duck-typed; nothing else in it
@@ -137,10 +139,12 @@ class _SubEnvs:
 
 
 class BatchedBaseEnv(_RLlibBaseEnv):
-    def __init__(self, kind, num_envs, num_agents, contract=None, seed0=73907, convolutional=True, **engine_kwargs):
+    def __init__(self, kind, num_envs, num_agents, contract=None, seed0=73907, convolutional=True, batch_done_resets=True,
+                 **engine_kwargs):
         self.kind, self.num_envs, self.num_agents = kind, int(num_envs), int(num_agents)
         self.contract = contract
         self.convolutional = convolutional
+        self.batch_done_resets = bool(batch_done_resets)
         engine_kwargs.setdefault("auto_reset", False)  # RLlib resets through try_reset
         self.engine = BatchedEnv(kind, num_envs, num_agents, contract=contract, **engine_kwargs)
         self._keys = ["a%d" % i for i in range(self.num_agents)]
@@ -288,6 +292,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             a = np.fromiter((action_dict[e][k] for e in range(E) for k in keys), np.int64, E * n).astype(np.uint8)
             self.engine.step(a.reshape(E, n))
         self.engine.check_faults()
+        self._episode_over = set()  # every env has stepped again: env_metrics() serves the running episode until poll()
         self._pending = list(range(E))
 
     def send_actions_array(self, actions, active=None):
@@ -298,6 +303,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         else:
             self.engine.step(actions)
         self.engine.check_faults()
+        self._episode_over = set()
         self._pending = list(range(self.num_envs))
 
     def poll_tensors(self):
@@ -312,7 +318,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         if env_id is not None and env_id in self._reset_obs:
             return {env_id: self._take_reset(env_id)}
         E = self.num_envs
-        ids = set(range(E)) if env_id is None else (self._done_ids | {env_id})
+        ids = set(range(E)) if env_id is None else ((self._done_ids | {env_id}) if self.batch_done_resets else {env_id})
         mask = np.zeros((E,), np.uint8)
         mask[list(ids)] = 1
         self.engine.reset(mask=mask)
@@ -336,8 +342,8 @@ class BatchedBaseEnv(_RLlibBaseEnv):
     # ---- episode metrics: what the reference's MetricsCallback (utils/logger_utils.py:126-150) reads per episode ----
     def env_metrics(self, env_id):
         """the `metrics` dictionary of sub-env `env_id`, with the single-env adapters' keys: the finished episode's
-        (equality / sustainability included) from the done tick until the env steps again — a reset in between does
-        not clear them — the running episode's otherwise"""
+        (equality / sustainability included) from the poll() that reported the done until the next send_actions — a
+        reset in between does not clear them — the running episode's otherwise"""
         eng, e = self.engine, int(env_id)
         if not 0 <= e < self.num_envs:
             raise IndexError(env_id)

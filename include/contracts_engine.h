@@ -261,7 +261,10 @@ int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* m
 
 /* Replaces: SeparateContractSubgameStage.reset (two_stage_train.py:159-187) ->
  * CleanupEnv/HarvestEnv.reset -> MapEnv.reset (map_env.py:306-342) /
- * SelfAcceleratingCarEnv.reset (…accelerate.py:49-79).  mask as above (host pointer). */
+ * SelfAcceleratingCarEnv.reset (…accelerate.py:49-79).  mask as above (host pointer).
+ * Stream ordering: step / rollout launches issued later on a DIFFERENT stream wait for this reset by themselves (one
+ * hipStreamWaitEvent per stream and reset) — "reset, then roll out env slices on side streams" needs no host sync.
+ * Every other cross-stream dependency (the same envs stepped on two streams in turn) is the caller's to order. */
 int ce_reset(ce_handle h, const uint8_t* mask, void* stream);
 
 /* Replaces: SeparateContractEnv.step (two_stage_train.py:62-121) -> CleanupEnv.step /
@@ -287,7 +290,10 @@ int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t nu
 /* Trajectory arrays of a fused rollout (all DEVICE pointers, caller-owned; each holds `num_planes` planes with the
  * layout of the per-step buffer of the same name in ce_buffers: obs [P][E][obs_env_stride], base_reward [P][E][n], ...).
  * A NULL array means "not wanted as a trajectory": that output is written to the handle's own per-step buffer instead,
- * every step, and holds the last step's values on return — exactly what num_steps ce_step calls leave there. */
+ * every step, and holds the last step's values on return — exactly what num_steps ce_step calls leave there.
+ * The arrays are caller-owned and the library cannot bounds-check them: each non-NULL array MUST hold num_planes
+ * planes of THIS handle's E and n (a ring allocated for another batch size is overrun silently; the Python front end
+ * checks it, contracts_amd/engine.py: rollout_fused). */
 typedef struct ce_traj {
   uint32_t num_planes;   /* planes per array; step s of a call goes to plane (first_plane + s) % num_planes   */
   uint32_t first_plane;
@@ -346,6 +352,8 @@ typedef struct ce_field_req {
   void* dst;           /* host pointer                                        */
   uint64_t dst_bytes;  /* capacity of dst: >= env_count * bytes per env        */
 } ce_field_req;
+/* (uses a per-handle staging buffer: like every entry point taking a handle, not to be called from two threads on the
+ * same handle at once) */
 int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const ce_field_req* reqs, uint32_t count);
 
 /* Timing of the last N ce_step launches measured with HIP events on the launch stream

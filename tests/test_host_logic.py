@@ -26,8 +26,52 @@ def test_contract_specs():
     assert cl.HarvestFeaturemodLocalContract(8).contract_space.high[0] == 10.0
     assert cl.SelfdriveContractDistprop(4).contract_space.high[0] == 100.0
     assert c.engine_contract == "cleanup" and c.num_agents == 4 and c.default_contract[0] == 0.0
-    with pytest.raises(NotImplementedError):
-        c.compute_transfer({}, {}, {}, {}, {})
+
+
+def _flatten_transfers(tr, slots):
+    val, tup, share, present = np.zeros(slots), np.zeros(slots, np.uint8), np.zeros((slots, slots)), np.zeros(slots, np.uint8)
+    for k, v in tr.items():
+        i = int(k[1:])
+        present[i] = 1
+        if type(v) is tuple:
+            tup[i], val[i] = 1, v[0]
+            for r, p in v[1].items():
+                share[i, int(r[1:])] = p
+        else:
+            val[i] = v
+    return val, tup, share, present
+
+
+def test_contract_compute_transfer_matches_reference_vectors():
+    """the public `compute_transfer` of the three contract classes (contract_list.py:22-27,45-54,69-102) against vectors
+    recorded from the reference (tests/golden/make_contract_golden.py): same keys, same numbers, same (value, shares)
+    tuples.  (The wrapper never calls it — the transfer is the step kernel's epilogue; this is the method a user calls
+    on a contract object directly.)"""
+    import os
+    from contracts_amd.contract import contract_list as cl
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contract_transfers.npz"))
+    for name, cls in (("cleanup", cl.CleanupContract), ("harvest", cl.HarvestFeaturemodLocalContract)):
+        for row in g[name]:
+            n, theta = int(row[0]), row[1]
+            cleaned, f8, close, val, present = row[2:10], row[10:18], row[18:26], row[26:34], row[34:42]
+            keys = ["a%d" % i for i in range(n)]
+            infos = {k: {"cleaned_squares": int(cleaned[i]), "eaten_close_apples": int(close[i]),
+                         "feature_obs": np.r_[np.zeros(8), f8[i], np.zeros(3)]} for i, k in enumerate(keys)}
+            tr = cls(n).compute_transfer({}, {k: 0 for k in keys}, {}, {k: np.array([theta]) for k in keys}, infos)
+            v, t, s, pr = _flatten_transfers(tr, 8)
+            assert np.array_equal(v, val) and np.array_equal(pr, present) and not t.any()
+    for row in g["selfdrive"]:
+        n, theta, passed = int(row[0]), row[1], bool(row[2])
+        acting, obs_row = row[3:11][:n].astype(bool), row[11:31][:2 * n + 5]
+        val, tup, share, present = row[31:43], row[43:55], row[55:199].reshape(12, 12), row[199:211]
+        keys = ["a%d" % i for i in range(n)]
+        acts = {k: 0 for i, k in enumerate(keys) if acting[i]}
+        obs = {k: obs_row.copy() for k in acts}
+        obs["a0"] = obs_row.copy()
+        infos = {k: {"just_passed": passed if k == "a0" else False} for k in keys}
+        tr = cl.SelfdriveContractDistprop(n).compute_transfer(obs, acts, {}, {k: np.array([theta]) for k in keys}, infos)
+        v, t, s, pr = _flatten_transfers(tr, 12)
+        assert np.array_equal(v, val) and np.array_equal(t, tup) and np.array_equal(s, share) and np.array_equal(pr, present)
 
 
 def test_sharding():

@@ -239,3 +239,176 @@ def test_episode_metrics_reach_the_callback(kind, contract):
     assert got and (kind == "selfdrive" or len(got) == E)
     assert len(venv.get_sub_environments()) == E and venv.get_sub_environments()[-1].env_id == E - 1
     venv.stop()
+
+
+def _sampler_loop(base_env, policy, ticks):
+    """what RLlib's sampler (`_env_runner`) does with a BaseEnv: poll -> per-episode bookkeeping -> policy -> send_actions,
+    and on a done episode try_reset + continue from the reset observation.  Returns (episodes, agent_steps, transcript)."""
+    episodes, agent_steps, transcript = 0, 0, []
+    for _ in range(ticks):
+        obs, rew, dones, infos, off = base_env.poll()
+        actions = {}
+        for env_id in obs:
+            o = obs[env_id]
+            if dones[env_id]["__all__"]:
+                episodes += 1
+                o = base_env.try_reset(env_id)[env_id]  # RLlib resets the sub-env and feeds the reset obs to the policy
+            actions[env_id] = {k: policy(env_id, k, o[k]) for k in o}
+            agent_steps += len(o)
+            transcript.append((env_id, {k: float(v) for k, v in rew[env_id].items()}, dones[env_id]["__all__"]))
+        base_env.send_actions(actions)
+    return episodes, agent_steps, transcript
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cleanup_contract", "harvest_plain", "harvest_features_contract", "selfdrive_contract"])
+def test_to_base_env_returns_the_batched_hook(which):
+    """`env.to_base_env(num_envs=E)` — the call RLlib's RolloutWorker makes on a MultiAgentEnv with
+    num_envs_per_worker = E — returns ONE BatchedBaseEnv configured like the env (kind, agents, horizon, flags, contract
+    bounds); a sampler loop over it issues exactly one step launch per tick (ce_timing_* counts launches) and its
+    transcript equals the oracle stepping the same seeds.  ray is absent here: the sampler loop above stands in for
+    `_env_runner` and the class derives from ray's BaseEnv only when ray is importable."""
+    from contracts_amd.contract.contract_list import CleanupContract, HarvestFeaturemodLocalContract, SelfdriveContractDistprop
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.feature_envs import HarvestFeatures
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    from contracts_amd.environments.self_driving_car_accelerate import SelfAcceleratingCarEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    from contracts_amd.vector_env import BatchedBaseEnv
+    from oracle.pyoracle import Oracle
+    E, ticks = 24, 75
+    np.random.seed(11)
+    if which == "cleanup_contract":
+        n, kind, contract, horizon = 4, "cleanup", "cleanup", 30
+        env = SeparateContractSubgameStage(CleanupEnv(num_agents=n, horizon=horizon), CleanupContract(n), n, True)
+    elif which == "harvest_plain":
+        n, kind, contract, horizon = 3, "harvest", None, 20
+        env = HarvestEnv(num_agents=n, horizon=horizon, disable_firing=False)
+    elif which == "harvest_features_contract":
+        n, kind, contract, horizon = 2, "harvest_features", "harvest_local", 25
+        env = SeparateContractSubgameStage(HarvestFeatures(num_agents=n, horizon=horizon), HarvestFeaturemodLocalContract(n), n, False)
+    else:
+        n, kind, contract, horizon = 4, "selfdrive", "selfdrive_distprop", None
+        env = SeparateContractSubgameStage(SelfAcceleratingCarEnv(num_agents=n), SelfdriveContractDistprop(n), n, False)
+    base = env.base_env if contract else env
+    base.seed(4321)  # MapEnv.seed: replica i of the vector env runs the stream seeded 4321 + i
+    venv = env.to_base_env(make_env=None, num_envs=E, remote_envs=False, remote_env_batch_wait_ms=0,
+                           restart_failed_sub_environments=False)
+    assert isinstance(venv, BatchedBaseEnv) and venv.num_envs == E and venv.kind == kind and venv.contract == contract
+    cfg = venv.engine.cfg
+    if horizon:
+        assert cfg.horizon == horizon
+    if contract == "cleanup":
+        assert cfg.contract_high == float(np.float32(0.2))  # the Box's float32 bound (two_stage_train.py:39-40)
+    firing = which == "harvest_plain"
+    assert venv.engine.firing == firing
+    na = venv.engine.num_actions
+    rs = np.random.RandomState(3)
+
+    def policy(env_id, key, ob):
+        if kind == "selfdrive":
+            return np.array([rs.uniform(-0.1, 0.1)], np.float32)
+        return int(rs.randint(na))
+
+    venv.engine.timing_begin()
+    episodes, agent_steps, transcript = _sampler_loop(venv, policy, ticks)
+    ms, launches = venv.engine.timing_end()
+    assert launches == ticks, "one step launch per sampler tick, got %d for %d ticks" % (launches, ticks)
+    assert agent_steps >= E * ticks and (episodes >= E or kind == "selfdrive")
+
+    # the same sampler loop over the oracle, behind a minimal BaseEnv face: identical transcript
+    kw = dict(contract=contract)
+    if horizon:
+        kw["horizon"] = horizon
+    if firing:
+        kw["firing"] = True
+    orc = Oracle(kind, E, n, **kw)
+    orc.seed(seed0=4321)
+    orc.reset()
+    keys = ["a%d" % i for i in range(n)]
+
+    class OracleBaseEnv:
+        def __init__(self):
+            self.stepped = False
+            self.acted = np.ones((E, n), np.uint8)
+
+        def _obs(self, e):
+            if kind == "selfdrive":
+                who = range(n) if not self.stepped else np.nonzero(self.acted[e])[0]
+                return {keys[i]: 0 for i in who}
+            return {k: 0 for k in keys}
+
+        def poll(self):
+            if not self.stepped:
+                z = {e: {k: 0.0 for k in keys} for e in range(E)}
+                return ({e: self._obs(e) for e in range(E)}, z, {e: {"__all__": False} for e in range(E)}, {}, {})
+            r = orc.reward if (contract or kind == "selfdrive") else orc.base_reward
+            rew = {e: {keys[i]: float(r[e][i]) for i in range(n) if self.acted[e, i]} for e in range(E)}
+            return ({e: self._obs(e) for e in range(E)}, rew, {e: {"__all__": bool(orc.done[e])} for e in range(E)}, {}, {})
+
+        def try_reset(self, e):
+            m = np.zeros((E,), np.uint8)
+            m[e] = 1
+            orc.reset(m)
+            self.acted[e] = 1
+            return {e: {k: 0 for k in keys}}
+
+        def send_actions(self, acts):
+            if kind == "selfdrive":
+                a = np.zeros((E, n), np.float32)
+                act = np.zeros((E, n), np.uint8)
+                for e in range(E):
+                    for k, v in acts[e].items():
+                        a[e, int(k[1:])] = v[0]
+                        act[e, int(k[1:])] = 1
+                self.acted = act
+                orc.step(a, act)
+            else:
+                orc.step(np.array([[acts[e][k] for k in keys] for e in range(E)], np.uint8))
+            self.stepped = True
+
+    ob = OracleBaseEnv()
+    rs = np.random.RandomState(3)
+    if kind != "selfdrive":  # (selfdrive's per-agent key sets: test_base_env_protocol_selfdrive_matches_oracle)
+        ep2, steps2, transcript2 = _sampler_loop(ob, policy, ticks)
+        assert (ep2, steps2) == (episodes, agent_steps)
+        assert len(transcript) == len(transcript2)
+        for (e1, r1, d1), (e2, r2, d2) in zip(transcript, transcript2):
+            assert e1 == e2 and d1 == d2 and r1.keys() == r2.keys()
+            for k in r1:
+                assert abs(r1[k] - r2[k]) < 1e-9
+    venv.stop()
+    orc.close()
+    env.close() if hasattr(env, "close") else base.close()
+
+
+@pytest.mark.gpu
+def test_to_base_env_fallbacks_keep_object_per_env_semantics():
+    """num_envs == 1, feature-vector grid envs and user-defined host contracts get SubEnvBaseEnv: RLlib's
+    object-per-sub-env wrapper over the adapters themselves, make_env(i) building the additional ones"""
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.vector_hook import SubEnvBaseEnv
+    np.random.seed(5)
+    env = CleanupEnv(num_agents=2, horizon=5)
+    one = env.to_base_env(num_envs=1)
+    assert isinstance(one, SubEnvBaseEnv) and one.get_sub_environments() == [env]
+    obs, rew, dones, infos, _ = one.poll()
+    assert list(obs) == [0] and obs[0]["a0"]["image"].shape == (15, 15, 3)
+    one.send_actions({0: {"a0": 4, "a1": 4}})
+    obs, rew, dones, infos, _ = one.poll()
+    assert rew[0] == {"a0": 0, "a1": 0} and dones[0]["__all__"] is False
+    feat = CleanupEnv(num_agents=2, horizon=5, image_obs=False)
+    made = []
+
+    def make_env(i):
+        made.append(i)
+        return CleanupEnv(num_agents=2, horizon=5, image_obs=False)
+
+    three = feat.to_base_env(make_env=make_env, num_envs=3)
+    assert isinstance(three, SubEnvBaseEnv) and three.num_envs == 3 and made == [1, 2]
+    obs, *_ = three.poll()
+    assert sorted(obs) == [0, 1, 2] and obs[2]["a1"].shape == (14,)
+    with pytest.raises(ValueError):
+        feat.to_base_env(num_envs=2)
+    three.stop()
+    one.stop()
