@@ -2289,6 +2289,14 @@ template <int GK> struct FEnv {
   u32 AP[3], AS[3];  // lane c, round r: packed apple cell c + 64 r and its list stamp (kAbsent = not present)
   u32 WC[2], WS[2];  // cleanup: waste cells and stamps
   u32 next_a, next_w;
+  // Single-step launches do not stage the 2.5 KB CPython generator in LDS up front: a step of HarvestFeatures draws one
+  // double per absent apple cell (5-20 in the steady state), so lane q fetches the two words of double q of the window
+  // [pos, pos + 128) straight from HBM (win_a / win_b, raw) and only the position is written back.  The full state is
+  // brought in (feat_ensure_py) when a step needs more than the window or runs over the generation end (a twist), or
+  // for a reset.  py_resident (wave-uniform): the LDS copy is valid.
+  bool py_resident;
+  u32 win_a, win_b;
+  bool stamps_dirty;  // wave-uniform: the list stamps changed since they were loaded
 };
 
 DEVINL void rng_bind(Rng& r, u32* mt, u32 pos) {
@@ -2355,22 +2363,44 @@ template <int GK> DEVINL void feat_np_draws(FEnv<GK>& E, const GridParams& p, bo
   if (E.lane == 0) rsrc[kMtN] = np.pos;
   wave_sync();
 }
-template <int GK> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool with_state) {
+// the CPython generator's 624 key words into LDS (156 x 16 B); the position is bound separately
+template <int GK> DEVINL void feat_fetch_py(FEnv<GK>& E, const GridParams& p) {
+  const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
+  const auto src4 = (CE_GPTR(const uint4))(rsrc + CE_RNG_WORDS_GRID);
+  uint4* dst4 = (uint4*)E.L->mt_py;
+  // unconditional: the third round's idle lanes repeat the last quad (same value, same address)
+  const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);
+  const uint4 r0 = src4[E.lane], r1 = src4[E.lane + 64], r2 = src4[q2];
+  dst4[E.lane] = r0;
+  dst4[E.lane + 64] = r1;
+  dst4[q2] = r2;
+  E.py_resident = true;
+}
+template <int GK> DEVINL void feat_ensure_py(FEnv<GK>& E, const GridParams& p) {
+  if (!E.py_resident) {
+    wave_sync();
+    feat_fetch_py(E, p);
+    wave_sync();
+  }
+}
+template <int GK, bool LIGHT = false> DEVINL void feat_load(FEnv<GK>& E, const GridParams& p, bool with_state) {
   typedef Geo<GK> G;
   const GridTables& T = c_tab[GK];
   const u32 lane = E.lane;
   const auto rsrc = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  {  // 624 words as 156 x 16 B
-    const auto src4 = (CE_GPTR(const uint4))(rsrc + CE_RNG_WORDS_GRID);
-    uint4* dst4 = (uint4*)E.L->mt_py;
-    // unconditional: the third round's idle lanes repeat the last quad (same value, same address)
-    const u32 q2 = min(lane + 128u, (u32)kMtN / 4 - 1);
-    const uint4 r0 = src4[lane], r1 = src4[lane + 64], r2 = src4[q2];
-    dst4[lane] = r0;
-    dst4[lane + 64] = r1;
-    dst4[q2] = r2;
+  E.py_resident = false;
+  E.stamps_dirty = false;
+  E.win_a = E.win_b = 0;
+  const u32 pypos = rsrc[CE_RNG_WORDS_GRID + kMtN];
+  if (LIGHT) {  // lane q: the two raw words of double q after the current position (clamped inside the generation)
+    const u32 i0 = min(rfl(pypos) + 2u * lane, (u32)kMtN - 2u);
+    const auto w = rsrc + CE_RNG_WORDS_GRID;
+    E.win_a = GAT(w, i0);
+    E.win_b = GAT(w, i0 + 1u);
+  } else {
+    feat_fetch_py(E, p);
   }
-  rng_bind(E.py, E.L->mt_py, rsrc[CE_RNG_WORDS_GRID + kMtN]);
+  rng_bind(E.py, E.L->mt_py, pypos);
   feat_base_map(E);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -2424,29 +2454,34 @@ template <int GK> DEVINL void feat_paint(FEnv<GK>& E) {
     pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WC[r]), E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER);
   wave_sync();
 }
-template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p) {
+// waste_block: also write the waste stamps (HarvestFeatures has none: only its construct / reset launches initialise them)
+template <int GK> DEVINL void feat_store(FEnv<GK>& E, const GridParams& p, bool waste_block = true) {
   typedef Geo<GK> G;
   const u32 lane = E.lane;
   wave_sync();
   const auto rdst = p.rng + (size_t)E.e * CE_RNG_WORDS_SELFDRIVE;
-  if (rfl(E.py.twists) != 0) {
+  if (E.py_resident && rfl(E.py.twists) != 0) {  // the key words only change at a twist
     const auto dst4 = (CE_GPTR(uint4))(rdst + CE_RNG_WORDS_GRID);
     const uint4* src4 = (const uint4*)E.L->mt_py;
     for (u32 k = lane; k < (u32)kMtN / 4; k += 64) dst4[k] = src4[k];
   }
   if (lane == 0) rdst[CE_RNG_WORDS_GRID + kMtN] = E.py.pos;
-  const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
+  if (E.stamps_dirty) {  // most steps neither eat, spawn nor clean anything: the lists are as they were loaded
+    const auto st = (CE_GPTR(uint16_t))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES);
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
-    if (lane + 64 * r < CE_FEAT_APPLE_SLOTS) st[lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NAPPLE ? E.AS[r] : kAbsent);
+    for (int r = 0; r < 3; ++r)
+      if (lane + 64 * r < CE_FEAT_APPLE_SLOTS) st[lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NAPPLE ? E.AS[r] : kAbsent);
+    if (GK == CE_KIND_CLEANUP || waste_block) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-    if (lane + 64 * r < CE_FEAT_WASTE_SLOTS)
-      st[CE_FEAT_APPLE_SLOTS + lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NWASTE ? E.WS[r] : kAbsent);
-  const auto cnt = (CE_GPTR(u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
-  if (lane == 0) {
-    cnt[0] = E.next_a;
-    cnt[1] = E.next_w;
+      for (int r = 0; r < 2; ++r)
+        if (lane + 64 * r < CE_FEAT_WASTE_SLOTS)
+          st[CE_FEAT_APPLE_SLOTS + lane + 64 * r] = (uint16_t)(lane + 64 * r < (u32)G::NWASTE ? E.WS[r] : kAbsent);
+    }
+    const auto cnt = (CE_GPTR(u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
+    if (lane == 0) {
+      cnt[0] = E.next_a;
+      cnt[1] = E.next_w;
+    }
   }
   if (E.is_agent) GAT((CE_GPTR(u32))p.agents + (size_t)E.e * E.n, lane) = row_of<GK>(E.P) | (col_of<GK>(E.P) << 8) | (E.O << 16);
 }
@@ -2456,6 +2491,7 @@ template <int GK> DEVINL void feat_init_arrays(FEnv<GK>& E) {
   typedef Geo<GK> G;
   const GridTables& T = c_tab[GK];
   E.next_a = E.next_w = 0;
+  E.stamps_dirty = true;
 #pragma unroll
   for (int r = 0; r < 3; ++r) E.AS[r] = kAbsent;
 #pragma unroll
@@ -2499,7 +2535,7 @@ template <int GK> DEVINL void feat_init_players(FEnv<GK>& E, u32 orient) {
 // r < p for a double given as tempered words (a, b): exact 53-bit integer compare against ceil(p * 2^53)
 DEVINL bool dbl_below(u32 a, u32 b, u64 thr) { return ((((u64)(a >> 5)) << 26) | (u64)(b >> 6)) < thr; }
 
-template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
+template <int GK> DEVINL void feat_spawn(FEnv<GK>& E, const GridParams& p) {
   typedef Geo<GK> G;
   const GridTables& T = c_tab[GK];
   const u32 lane = E.lane;
@@ -2520,6 +2556,72 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E) {
     ri[r] = nelig + popc64(eb & lt);
     nelig += popc64(eb);
   }
+  if (GK == CE_KIND_HARVEST) {
+    // HarvestFeatures' common case: at most 64 eligible cells and their doubles inside the current generation.  The
+    // eligible cells are compacted to one lane round — lane q = the q-th eligible cell in row-major order with double q
+    // of the stream — so the neighbour counts, the fixed-point iteration and the list appends below run once instead
+    // of once per 64 apple cells, and the stream words come straight from the window (registers, or the resident LDS
+    // state of a fused rollout): nothing of the generator but its position changes.
+    rng_assert_uniform(E.py);
+    if (nelig == 0) return;
+    if (nelig <= 64u && E.py.pos + 2u * nelig <= (u32)kMtN) {
+      u32 wa = E.win_a, wb = E.win_b;
+      if (E.py_resident) {
+        const u32 i0 = min(E.py.pos + 2u * lane, (u32)kMtN - 2u);
+        wa = E.py.mt[i0];
+        wb = E.py.mt[i0 + 1u];
+      }
+      u32* U = E.L->w.U;  // [0, 64): the compacted list; [64, 256): the stamp each owner (cell index) gets back
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        if (elig[r]) U[ri[r]] = cell_pad(E.AP[r]) | (lane + 64u * r) << 16;
+      wave_sync();
+      const bool act = lane < nelig;
+      const u32 ent = U[act ? lane : 0u];
+      const i32 cell = (i32)(ent & 0xffffu);  // idle lanes alias entry 0: a valid interior cell, never written by them
+      const u32 owner = ent >> 16;
+      const u64 X = (((u64)(mt_temper(wa) >> 5)) << 26) | (u64)(mt_temper(wb) >> 6);
+      const u64 t0 = T.apple_thresh[0], t1 = T.apple_thresh[1], t2 = T.apple_thresh[2], t3 = T.apple_thresh[3];
+      bool sp = false;
+      for (;;) {
+        u32 num = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+          for (int k = -1; k <= 1; ++k) {
+            const uint8_t c = pm[cell + j * G::PW + k];
+            const bool earlier = j < 0 || (j == 0 && k < 0);  // row-major: this pass's spawns above / to the left count
+            num += (c == CE_CELL_APPLE || (earlier && c == 0x42)) ? 1u : 0u;
+          }
+        const u64 thr = num == 0 ? t0 : num == 1 ? t1 : num == 2 ? t2 : t3;
+        const bool s2 = act && X < thr;
+        const bool changed = s2 != sp;
+        sp = s2;
+        if (ballot(changed) == 0) break;
+        wave_sync();
+        pm_put(pm, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
+        wave_sync();
+      }
+      wave_sync();
+      const u64 sb = ballot(sp);
+      const u32 stamp = E.next_a + popc64(sb & lt);  // appended in row-major order: stamps continue the list
+      if (sp) pm[cell] = CE_CELL_APPLE;
+      if (act) U[64u + owner] = sp ? stamp : kAbsent;
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        if (elig[r]) E.AS[r] = U[64u + lane + 64u * r];
+      E.next_a += popc64(sb);
+      if (sb) E.stamps_dirty = true;
+      E.py.pos += 2u * nelig;
+      E.py.ccount = 0;
+      wave_sync();
+      return;
+    }
+  }
+  feat_ensure_py(E, p);  // the general path walks the stream in LDS (and may twist it)
+  E.stamps_dirty = true;
   u64 thr_uniform = 0;
   bool waste_on = false;
   u32 nwaste = 0;
@@ -2707,6 +2809,28 @@ template <int GK> DEVINL u32 feat_features(FEnv<GK>& E, const GridParams& p, CE_
       if (lane == a) close_now = cnt;
     }
   }
+  if ((nf & 1u) == 0) {  // dword-aligned rows (every harvest row, cleanup with an even n): a few wide stores per agent
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const auto f32 = (CE_GPTR(u32))f;
+    const u32x4 head = {row_of<GK>(E.P) | col_of<GK>(E.P) << 16, E.O | row_of<GK>(cpp) << 16, col_of<GK>(cpp) | cpo << 16,
+                        (ca >> 8) | (ca & 0xffu) << 16};
+    if (GK == CE_KIND_CLEANUP) {
+      for (u32 b = 0; b < n; b += 2) {
+        const u32 w = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
+        if (E.is_agent) f32[6 + (b >> 1)] = w;
+      }
+      if (E.is_agent) {
+        *(CE_GPTR(u32x4))(f32) = head;
+        f32[4] = (cw >> 8) | (cw & 0xffu) << 16;
+        f32[5] = napples | nwastes << 16;
+      }
+    } else if (E.is_agent) {
+      *(CE_GPTR(u32x4))(f32) = head;
+      f32[4] = close_now | napples << 16;
+      for (u32 b = 0; b < n; ++b) f32[5 + b] = 0u;
+    }
+    return close_now;
+  }
   if (E.is_agent) {
     f[0] = (int16_t)row_of<GK>(E.P);
     f[1] = (int16_t)col_of<GK>(E.P);
@@ -2759,9 +2883,10 @@ template <int GK> DEVINL void feat_zero_outputs(FEnv<GK>& E, const GridParams& p
 // reset(): initialize_arrays, initialize_players, spawn, metrics, theta (wrapper), observation
 template <int GK> DEVINL void feat_reset_env(FEnv<GK>& E, const GridParams& p, u32 orient) {
   feat_init_arrays(E);
+  feat_ensure_py(E, p);  // the spawn shuffle draws from the CPython stream word by word
   feat_init_players(E, orient);
   feat_paint(E);
-  feat_spawn(E);
+  feat_spawn(E, p);
 }
 
 template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
@@ -2778,6 +2903,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_construct(const G
   feat_init_arrays(E);  // __init__: initialize_arrays, (compute_probabilities), initialize_players
   feat_init_players(E, orient);
   feat_zero_outputs(E, p);
+  E.stamps_dirty = true;
   feat_store(E, p);
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
@@ -2801,6 +2927,7 @@ template <int GK> __global__ __launch_bounds__(64) void k_feat_reset(const GridP
   feat_reset_env(E, p, orient);
   feat_zero_outputs(E, p);
   feat_features(E, p, p.features, 0u);
+  E.stamps_dirty = true;
   feat_store(E, p);
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
@@ -2869,6 +2996,7 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if (lane + 64 * r < (u32)G::NAPPLE && cell_pad(E.AP[r]) == pa) E.AS[r] = kAbsent;
+      E.stamps_dirty = true;
       wave_sync();
     }
   // ---- rotations ----
@@ -2892,6 +3020,7 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
       if (lane == a) cleaned = c;
       wave_sync();
       pm_put(pm, hitw, cell, CE_CELL_RIVER);
+      if (c) E.stamps_dirty = true;
       for (u64 hw = ballot(hitw); hw; hw &= hw - 1) {
         const u32 cw = rdl(cell, ctz64(hw));
 #pragma unroll
@@ -2902,7 +3031,7 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
     }
   }
   // ---- spawn, features ----
-  feat_spawn(E);
+  feat_spawn(E, p);
   const u32 feat8 = feat_features(E, p, out.features(), cleaned);
   t += 1;
   const bool done = t == p.horizon;
@@ -2910,29 +3039,41 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
   const auto mi = p.int_metrics + (size_t)E.e * nmi;
   const auto mf = p.f64_metrics + (size_t)E.e * nmf;
-  u32 sum_eaten = 0, sum_close = 0, sum_clean = 0, sum_rew = 0;
-  for (u32 b = 0; b < n; ++b) {
-    sum_eaten += rdl(eaten, b);
-    sum_close += rdl(eaten_close, b);
-    sum_clean += rdl(cleaned, b);
-    sum_rew += rdl(rew, b);
-  }
-  if (lane == 0) {
-    mi[CE_MI_TOTAL_APPLES_EATEN] += sum_eaten;
-    mi[CE_MI_RAW_ENV_REWARDS] += sum_rew;
-    mi[CE_MI_DIRT_CLEANED] += sum_clean;
-    mi[CE_MI_LOW_DENSITY_APPLES] += sum_close;
-  }
+  // read-modify-write only the rows this step really changes (most steps add zero to every accumulator); the done
+  // step needs the per-agent sums for equality / sustainability and loads them regardless
   double rw = (double)rew;
   long long m_sr = 0, m_str = 0;
   double f_sr = 0.0, f_str = 0.0;
-  if (E.is_agent) {
-    mi[CE_MI_AGENT(n, CE_MIA_A, lane)] += harvest ? eaten : cleaned;
-    if (harvest) mi[CE_MI_AGENT(n, CE_MIA_B, lane)] += eaten_close;
-    m_sr = mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] + rew;
-    m_str = mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] + (long long)(t - 1) * rew;
-    mi[CE_MI_AGENT(n, CE_MIA_SUM_R, lane)] = m_sr;
-    mi[CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)] = m_str;
+  {
+    u32 sum_eaten = 0, sum_close = 0, sum_clean = 0, sum_rew = 0;
+    const u64 touched = ballot(E.is_agent && (eaten | eaten_close | cleaned | rew) != 0);
+    for (u64 it = touched; it; it &= it - 1) {
+      const u32 b = ctz64(it);
+      sum_eaten += rdl(eaten, b);
+      sum_close += rdl(eaten_close, b);
+      sum_clean += rdl(cleaned, b);
+      sum_rew += rdl(rew, b);
+    }
+    if (touched != 0 && lane < 4) {
+      long long g_m = GAT(mi, lane);  // lane k < 4 holds global metric k
+      if (lane == CE_MI_TOTAL_APPLES_EATEN) g_m += sum_eaten;
+      if (lane == CE_MI_RAW_ENV_REWARDS) g_m += sum_rew;
+      if (lane == CE_MI_DIRT_CLEANED) g_m += sum_clean;
+      if (lane == CE_MI_LOW_DENSITY_APPLES) g_m += sum_close;
+      GAT(mi, lane) = g_m;
+    }
+    const u32 inc_a = harvest ? eaten : cleaned;
+    if (ballot(inc_a != 0) != 0 && E.is_agent) GAT(mi, CE_MI_AGENT(n, CE_MIA_A, lane)) += inc_a;
+    if (harvest && ballot(eaten_close != 0) != 0 && E.is_agent) GAT(mi, CE_MI_AGENT(n, CE_MIA_B, lane)) += eaten_close;
+    const u64 rew_lanes = ballot(E.is_agent && rew != 0);
+    if ((rew_lanes != 0 || done) && E.is_agent) {
+      m_sr = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) + rew;
+      m_str = GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) + (long long)(t - 1) * rew;
+      if (rew_lanes != 0) {
+        GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_R, lane)) = m_sr;
+        GAT(mi, CE_MI_AGENT(n, CE_MIA_SUM_TR, lane)) = m_str;
+      }
+    }
   }
   if (p.contract != CE_CONTRACT_NONE) {  // SeparateContractEnv.step two_stage_train.py:62-121
     double tr;
@@ -2940,25 +3081,30 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
     else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;
     double total = 0.0;
     const double share = tr / (double)(n - 1);
-    for (u32 i = 0; i < n; ++i) {
+    // agents with a zero transfer are skipped: adding +-0.0 changes neither a reward nor the total (never -0.0)
+    for (u64 it = ballot(E.is_agent && tr != 0.0); it; it &= it - 1) {
+      const u32 i = ctz64(it);
       const double ti = shfl_f64(tr, i), qi = shfl_f64(share, i);
       if (lane == i) rw -= ti;
       else rw += qi;
       total += ti;
     }
-    if (lane == 0) mf[CE_MF_TRANSFERS] += total;
-    if (E.is_agent) {
-      f_sr = mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] + rw;
-      f_str = mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] + (double)(t - 1) * rw;
-      mf[CE_MF_AGENT(n, CE_MFA_SUM_R, lane)] = f_sr;
-      mf[CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)] = f_str;
+    if (total != 0.0 && lane == 0) mf[CE_MF_TRANSFERS] += total;
+    const bool any_rew = ballot(E.is_agent && rw != 0.0) != 0;
+    if ((any_rew || done) && E.is_agent) {
+      f_sr = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) + rw;
+      f_str = GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) + (double)(t - 1) * rw;
+      if (any_rew) {
+        GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_R, lane)) = f_sr;
+        GAT(mf, CE_MF_AGENT(n, CE_MFA_SUM_TR, lane)) = f_str;
+      }
     }
   }
   if (E.is_agent) {
-    (out.base_reward() + ea)[lane] = (i32)rew;
-    (out.reward() + ea)[lane] = rw;
-    (out.info() + 2 * ea)[2 * lane] = (uint8_t)eaten;
-    (out.info() + 2 * ea)[2 * lane + 1] = (uint8_t)(harvest ? eaten_close : cleaned);
+    GAT(out.base_reward() + ea, lane) = (i32)rew;
+    GAT(out.reward() + ea, lane) = rw;
+    const u32 info2 = eaten | (harvest ? eaten_close : cleaned) << 8;  // info[a][0..1] as one short
+    *(CE_GPTR(uint16_t))(out.info() + 2 * ea + 2 * lane) = (uint16_t)info2;
   }
   if (done) {  // compute_equality / compute_sustainability (+ the transferred versions of the wrapper)
     const long long sr = E.is_agent ? m_sr : 0, str_ = E.is_agent ? m_str : 0;
@@ -3013,7 +3159,7 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
   }
   if (lane == 0) out.done()[E.e] = done ? 1 : 0;
   if (FUSED) return;  // the state stays in registers / LDS for the next step of the launch
-  feat_store(E, p);
+  feat_store(E, p, GK == CE_KIND_CLEANUP);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
     if (did_reset) p.theta[E.e] = theta;
@@ -3031,7 +3177,7 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
     if (E.lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
     return;
   }
-  feat_load(E, p, true);
+  feat_load<GK, GK == CE_KIND_HARVEST>(E, p, true);  // HarvestFeatures: stream window instead of the whole generator
   u32 t = (u32)p.timestep[E.e], fault = 0;
   double theta = p.theta[E.e];
   bool did_reset = false;
@@ -3071,6 +3217,8 @@ template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k
     pl = pl + 1 == ra.num_planes ? 0u : pl + 1;
     rng_assert_uniform(E.py);
     E.py.twists = rfl(E.py.twists);
+    E.py_resident = true;
+    E.stamps_dirty = false;
     E.next_a = rfl(E.next_a);
     E.next_w = rfl(E.next_w);
     t = rfl(t);
@@ -3079,7 +3227,8 @@ template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k
     if (did_reset) theta = shfl_f64(theta, 0);
   }
   const GridParams& p = opaque_block(pp);
-  feat_store(E, p);  // (stamps and agents only: the static tables are not needed)
+  E.stamps_dirty = true;
+  feat_store(E, p, GK == CE_KIND_CLEANUP);  // (stamps and agents only: the static tables are not needed)
   if (E.lane == 0) {
     p.timestep[E.e] = (i32)t;
     if (any_reset) p.theta[E.e] = theta;

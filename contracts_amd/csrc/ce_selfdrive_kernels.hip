@@ -350,33 +350,77 @@ template <int N> DEVINL void sd_emit_obs(const SdLane<N>& ln, const Car<N>& c, b
   }
 }
 
+// ---- a stream that runs over the end of its generation, handled by the whole wave ----
+// A reset draws 2n words of the CPython stream and 2 or 4 of numpy's.  Almost always the window lies inside the current
+// generation and the cars fetch their words themselves (sd_reset_group); once per 624 words it does not, and the
+// generation has to be regenerated.  Left to one lane on global memory (624 dependent read-modify-write rounds) that
+// took ~0.3 ms — with 32 768 envs a few waves of EVERY launch hit it, and the steady-state step time was theirs
+// (55 us per step instead of 12).  Here the wave stages the env's 624 words in its LDS block (free between two
+// observation emits), twists them with 64 lanes in three dependent chunks like the grid kernels, and writes them back.
+DEVINL u32 sd_mix(u32 a, u32 b, u32 c) {
+  const u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __noinline__ void sd_twist_lds(u32* mt, u32 lane) {
+  sd_wave_sync();
+  u32 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // words 0..226 read old words only
+    const u32 i = 64 * r + lane, ic = i < 227 ? i : 0;
+    v[r] = sd_mix(mt[ic], mt[ic + 1], mt[ic + kMtM]);
+  }
+  sd_wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (64 * r + lane < 227) mt[64 * r + lane] = v[r];
+  sd_wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // 227..453 read chunk-1 results
+    const u32 i = 227 + 64 * r + lane, ic = i < 454 ? i : 227;
+    v[r] = sd_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+  }
+  sd_wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (227 + 64 * r + lane < 454) mt[227 + 64 * r + lane] = v[r];
+  sd_wave_sync();
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {  // 454..622 read chunk-2 results
+    const u32 i = 454 + 64 * r + lane, ic = i < 623 ? i : 454;
+    v[r] = sd_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
+  }
+  sd_wave_sync();
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (454 + 64 * r + lane < 623) mt[454 + 64 * r + lane] = v[r];
+  sd_wave_sync();
+  if (lane == 0) mt[623] = sd_mix(mt[623], mt[0], mt[396]);
+  sd_wave_sync();
+}
 // SelfAcceleratingCarEnv.reset (:49-79) + the wrapper's theta draw for the groups flagged `go`, lane-parallel: the 2n
 // words of the CPython `random` stream one reset consumes are fetched by the cars themselves (and the <= 4 numpy words
-// by lane 0) unless the window runs over the end of the generation — then lane 0 of the group walks the stream serially.
-template <int N> DEVINL void sd_reset_group(const SdParams& p, const SdLane<N>& ln, Car<N>& c, bool go) {
+// by lane 0) unless the window runs over the end of the generation — then the whole wave serves that group's stream
+// (sd_stage_stream / sd_twist_lds above).  Called by the whole wave; `lds` = the wave's staging block (no observation
+// rows pending in it).
+template <int N> DEVINL void sd_reset_group(const SdParams& p, const SdLane<N>& ln, Car<N>& c, bool go, u32* lds) {
   const u32 e = ln.e;
   u32* np_mt = (u32*)p.rng + (size_t)e * CE_RNG_WORDS_SELFDRIVE;
   u32* py_mt = np_mt + CE_RNG_WORDS_GRID;
   const double low = p.low_bound;
   double u = 0.0, theta = c.theta;
+  const bool draws_theta = !(p.flags & CE_FLAG_EXTERNAL_THETA) && p.contract != CE_CONTRACT_NONE;
+  bool py_fast = true, np_fast = true;
   if (go) {
     const u32 ppos = py_mt[kMtN];
-    const bool py_fast = ppos + 2u * N <= (u32)kMtN;
-    const bool draws_theta = !(p.flags & CE_FLAG_EXTERNAL_THETA) && p.contract != CE_CONTRACT_NONE;
+    py_fast = ppos + 2u * N <= (u32)kMtN;
     const u32 npos = np_mt[kMtN];
-    const bool np_fast = !draws_theta || npos + 4u <= (u32)kMtN;
+    np_fast = !draws_theta || npos + 4u <= (u32)kMtN;
     if (py_fast) {
       if (ln.is_car) u = sd_words_to_double(py_mt[ppos + 2 * ln.k], py_mt[ppos + 2 * ln.k + 1]);
     }
-    // slow paths and everything that writes a stream position: the group's first lane
-    double u_slow[N];
+    // everything that writes a stream position: the group's first lane
     if (ln.k == 0) {
-      if (py_fast) {
-        py_mt[kMtN] = ppos + 2u * N;
-      } else {
-#pragma unroll
-        for (int a = 0; a < N; ++a) u_slow[a] = mtg_double(py_mt);
-      }
+      if (py_fast) py_mt[kMtN] = ppos + 2u * N;
       if (p.flags & CE_FLAG_EXTERNAL_THETA) {  // the caller owns the theta buffer: a reset neither draws nor changes it
         theta = p.theta[e];
       } else if (p.contract == CE_CONTRACT_NONE) {
@@ -390,20 +434,59 @@ template <int N> DEVINL void sd_reset_group(const SdParams& p, const SdLane<N>& 
           theta = p.contract_low;
           np_mt[kMtN] = npos + 2;
         }
-      } else {
-        const double u0 = mtg_double(np_mt);
-        theta = u0 > p.null_prob ? p.contract_low + (p.contract_high - p.contract_low) * mtg_double(np_mt) : p.contract_low;
       }
     }
-    if (!py_fast) {  // hand the serially drawn doubles to their cars
-#pragma unroll
-      for (int a = 0; a < N; ++a) {
-        const double v = sd_shfl(ln.k == 0 ? u_slow[a] : 0.0, ln.gb);
-        if ((int)ln.k == a) u = v;
-      }
-    }
-    theta = sd_shfl(theta, ln.gb);
   }
+  // The rare groups whose window crosses a generation end, one (group, stream) at a time, served by the whole wave.
+  // genrand semantics: words are consumed in order and the generation is regenerated exactly when a word past its end
+  // is consumed — the window's first `tail` words come from the old generation, the rest from the new one.  Lane i
+  // holds word i of the window; ONE code instance serves both streams (the twist is 40 instructions x 3 chunks).
+  const u64 slow_py = __builtin_amdgcn_ballot_w64(go && ln.k == 0 && !py_fast);
+  const u64 slow_np = __builtin_amdgcn_ballot_w64(go && ln.k == 0 && !np_fast);
+  for (u64 it = slow_py | slow_np; it; it &= it - 1) {
+    const u32 L = (u32)__builtin_ctzll(it);  // first lane of the group
+    const u32 eL = (u32)__builtin_amdgcn_readlane((int)e, (int)L);
+    const bool mine = ln.gb == L;
+#pragma unroll 1
+    for (u32 which = 0; which < 2; ++which) {  // 0: CPython `random` (2n words), 1: np.random (2 or 4 words)
+      if ((((which ? slow_np : slow_py) >> L) & 1ull) == 0) continue;
+      u32* mt = (u32*)p.rng + (size_t)eL * CE_RNG_WORDS_SELFDRIVE + (which ? 0u : (u32)CE_RNG_WORDS_GRID);
+      const u32 want = which ? 4u : 2u * N;
+      sd_wave_sync();
+      for (u32 k2 = ln.lane; k2 < (u32)kMtN; k2 += 64) lds[k2] = mt[k2];
+      const u32 pos = (u32)__builtin_amdgcn_readfirstlane((int)mt[kMtN]);
+      const u32 tail = (u32)kMtN - pos;  // words of the window that lie in the old generation
+      sd_wave_sync();
+      u32 x = (ln.lane < want && ln.lane < tail) ? lds[pos + ln.lane] : 0u;
+      u32 consumed = want;
+      if (which && tail >= 2u) {  // u0 is decided by old words: maybe only two words are consumed, and no twist
+        const double u0 = sd_words_to_double((u32)__builtin_amdgcn_readlane((int)x, 0), (u32)__builtin_amdgcn_readlane((int)x, 1));
+        consumed = u0 > p.null_prob ? 4u : 2u;
+      }
+      const bool twist = consumed > tail;
+      if (twist) {
+        sd_twist_lds(lds, ln.lane);
+        if (ln.lane < want && ln.lane >= tail) x = lds[ln.lane - tail];
+        sd_wave_sync();
+        for (u32 k2 = ln.lane; k2 < (u32)kMtN; k2 += 64) mt[k2] = lds[k2];
+      }
+      if (which) {
+        const u32 x0 = (u32)__builtin_amdgcn_readlane((int)x, 0), x1 = (u32)__builtin_amdgcn_readlane((int)x, 1);
+        const u32 x2 = (u32)__builtin_amdgcn_readlane((int)x, 2), x3 = (u32)__builtin_amdgcn_readlane((int)x, 3);
+        const double u0 = sd_words_to_double(x0, x1);
+        consumed = u0 > p.null_prob ? 4u : 2u;  // (tail < 2: decided by the new words; a twist was due either way)
+        const double th = consumed == 4u ? p.contract_low + (p.contract_high - p.contract_low) * sd_words_to_double(x2, x3)
+                                         : p.contract_low;
+        if (mine) theta = th;
+      } else {
+        const u32 w0 = sd_bperm(x, 2u * ln.k), w1 = sd_bperm(x, 2u * ln.k + 1u);
+        if (mine && ln.is_car) u = sd_words_to_double(w0, w1);
+      }
+      if (ln.lane == 0) mt[kMtN] = twist ? consumed - tail : pos + consumed;
+      sd_wave_sync();
+    }
+  }
+  theta = sd_shfl(theta, ln.gb);  // (every lane takes part in the permute; only `go` groups use the value)
   if (go) {
     if (ln.k == 0) {
       c.pos = u * low / 2 + low / 2;
@@ -603,7 +686,8 @@ DEVINL void sd_step_core(const SdParams& p, const SdOut& out, const SdLane<N>& l
   // in-launch auto-reset: the terminal step's rewards / infos / dones stay, the observation becomes the reset one
   const bool go = !skip && c.done_all && (p.flags & CE_FLAG_AUTO_RESET) != 0;
   if (__builtin_amdgcn_ballot_w64(go) != 0) {
-    sd_reset_group<N>(p, ln, c, go && ln.live);
+    sd_wave_sync();  // the terminal observation has left the staging block
+    sd_reset_group<N>(p, ln, c, go && ln.live, (u32*)stage);
     sd_emit_obs<N>(ln, c, go, ln.is_car, 0.0, stage, out.obs_f64);  // every car of a reset env is acting
     if (go && ln.live && k == 0) p.f64_metrics[(size_t)ln.e * CE_MF_COUNT(N) + CE_MF_TRANSFERS] = 0.0;
     did_reset = did_reset || go;
