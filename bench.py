@@ -316,9 +316,14 @@ class Runner:
 def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     """The RL-usable rate: one host iteration per env-step.  The batch is `num_slices` independent env slices, each with
     its own HIP stream; per slice and step, torch computes the actions ON THE DEVICE from the observation the previous
-    step of that slice wrote (the pixel in front of every agent, mixed with a resident random plane so the action
-    distribution stays the benchmark's uniform one: two elementwise torch kernels), then ce_step_range steps the slice
-    from that device pointer.  No joins between slices: one slice's policy and kernel tail overlap another's step."""
+    step of that slice wrote (the pixel in front of every agent, mixed with a resident noise plane so the action
+    distribution stays the benchmark's uniform one: three elementwise torch kernels), then ce_step_range steps the slice
+    from that device pointer.  No joins between slices: one slice's policy and kernel tail overlap another's step.
+    Ways to issue a slice's tick: `eager` (four launches from Python), `graph` (the same four launches captured once per
+    slice into a hipGraph and replayed: one host call per slice and step) — `value` is the faster of these two, both
+    with one host iteration per env-step — and `graph16` (16 consecutive ticks per replay: the loop observation -> policy
+    -> step still closes on the device every step, the host only comes by every 16 steps; reported beside, not as
+    `value`)."""
     import torch
     from contracts_amd.engine import BatchedEnv
     kind, n = wl["kind"], wl["n"]
@@ -328,9 +333,8 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     env.reset()
     obs = env.torch_tensors()["obs"]  # uint8 [E, n, 15, 15, 3], strided view of the engine's pitched buffer
     ahead = obs[:, :, 6, 7, 1]        # green channel of the cell in front of the agent: [E, n], stride-only view
-    R = 64
     g = torch.Generator(device="cuda").manual_seed(1)
-    noise = torch.randint(0, 256, (R, E, n), dtype=torch.uint8, device="cuda", generator=g)
+    noise = torch.randint(0, 256, (E, n), dtype=torch.uint8, device="cuda", generator=g)
     tmp = torch.empty((E, n), dtype=torch.uint8, device="cuda")
     acts = torch.zeros((E, n), dtype=torch.uint8, device="cuda")
     S = max(1, num_slices)
@@ -341,36 +345,63 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     env.rollout_device(pre.data_ptr(), PREROLL, [st.cuda_stream for st in streams])
     torch.cuda.synchronize()
 
-    def tick(t):
-        nz = noise[t % R]
+    def slice_tick(st, b0, b1):  # every pointer is fixed, so the same calls can be captured into a graph
+        torch.add(ahead[b0:b1], noise[b0:b1], out=tmp[b0:b1])  # uint8 wrap-around: uniform whatever the pixel
+        noise[b0:b1].add_(37)                                   # the plane moves on every step (a bijection mod 256)
+        if A == 8:
+            torch.bitwise_and(tmp[b0:b1], 7, out=acts[b0:b1])
+        else:
+            torch.remainder(tmp[b0:b1], A, out=acts[b0:b1])
+        env.step_range_device(acts.data_ptr(), b0, b1 - b0, stream=st.cuda_stream)
+
+    def eager_tick():
         for st, (b0, b1) in zip(streams, bounds):
             with torch.cuda.stream(st):
-                torch.add(ahead[b0:b1], nz[b0:b1], out=tmp[b0:b1])        # uint8 wrap-around: uniform whatever the pixel
-                if A == 8:
-                    torch.bitwise_and(tmp[b0:b1], 7, out=acts[b0:b1])
-                else:
-                    torch.remainder(tmp[b0:b1], A, out=acts[b0:b1])
-                env.step_range_device(acts.data_ptr(), b0, b1 - b0, stream=st.cuda_stream)
+                slice_tick(st, b0, b1)
 
-    for t in range(50):
-        tick(t)
-    torch.cuda.synchronize()
-    K, elapsed, t = 500, [], 50
-    while len(elapsed) < 3 or sum(elapsed) < min_seconds:
+    def timed(tick, K=480, per_tick=1):
+        for _ in range(48 // per_tick):
+            tick()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            tick(t)
-            t += 1
-        torch.cuda.synchronize()
-        elapsed.append(time.perf_counter() - t0)
-    env.check_faults()
-    med = statistics.median(elapsed)
-    out = {"value": E * n * K / med, "unit": "agent-steps/s", "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
-           "timed_seconds": sum(elapsed), "slices": S, "host_iterations_per_step": 1, "launches_per_step": 3 * S,
-           "policy": "torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident "
-                     "uniform byte) mod %d — two elementwise kernels per slice and step" % A,
-           "workload": wl["name"]}
+        elapsed = []
+        while len(elapsed) < 3 or sum(elapsed) < min_seconds:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K // per_tick):
+                tick()
+            torch.cuda.synchronize()
+            elapsed.append(time.perf_counter() - t0)
+        env.check_faults()
+        med = statistics.median(elapsed)
+        return {"value": E * n * K / med, "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
+                "timed_seconds": sum(elapsed)}
+
+    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=4 * S, host_iterations_per_step=1)}
+    for name, ticks in (("graph", 1), ("graph16", 16)):
+        try:  # one hipGraph per slice, replayed on the slice's stream
+            graphs = []
+            for st, (b0, b1) in zip(streams, bounds):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    for _ in range(ticks):
+                        slice_tick(st, b0, b1)
+                graphs.append(gr)
+            torch.cuda.synchronize()
+
+            def graph_tick(graphs=graphs):
+                for st, gr in zip(streams, graphs):
+                    with torch.cuda.stream(st):
+                        gr.replay()
+
+            modes[name] = dict(timed(graph_tick, per_tick=ticks), host_calls_per_step=S / float(ticks),
+                               host_iterations_per_step=1.0 / ticks, device_policy_evaluations_per_step=1)
+        except Exception as exc:  # capture support differs between ROCm builds: the eager figure stands
+            modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    best = max((m for m in ("eager", "graph") if "value" in modes[m]), key=lambda m: modes[m]["value"])
+    out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
+               policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
+                      "byte) mod %d — three elementwise kernels per slice and step" % A,
+               workload=wl["name"])
     env.close()
     return out
 

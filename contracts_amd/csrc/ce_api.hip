@@ -65,6 +65,7 @@ template <int KIND> static void build_tables(GridTables& t) {
         code = CE_CELL_APPLE;  // custom_reset: every apple cell starts as 'A' (harvest_new.py:143-146)
       }
       t.base_pmap[pad] = code;
+      t.base_pmap4[pad] = (uint8_t)(code << 2);
     }
   if (KIND == CE_KIND_CLEANUP)
     for (int i = 0; i < 10; ++i) t.spawn[10 + i] = t.spawn[i];  // cleanup_new.py:114-115

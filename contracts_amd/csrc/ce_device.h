@@ -33,6 +33,7 @@ template <> struct Geo<CE_KIND_CLEANUP> {
   // LDS bank (ds_read_u8 banks: (a / 4) mod 32 per 32-lane half) — 128 of the step's 210 conflict cycles; 36 makes the
   // left / right views conflict free and leaves one extra cycle on the up / down ones
   static constexpr int H = 25, W = 18, CELLS = 450, PW = 36, PH = 39, PCELLS = PW * PH;
+  static constexpr int PQUADS = (PCELLS + 15) / 16;  // the LDS map is padded to whole 16-byte quads
   static constexpr int NAPPLE = 103, NWASTE = 119, RANDW = 2 * (103 + 119), NSPAWN_CTOR = 10;
   // LDS keeps the words of the apple doubles only; of a waste double only "u < 0.5" matters, which is
   // bit 31 of its first word (kept as one byte per double)
@@ -43,6 +44,7 @@ template <> struct Geo<CE_KIND_CLEANUP> {
 };
 template <> struct Geo<CE_KIND_HARVEST> {
   static constexpr int H = 16, W = 38, CELLS = 608, PW = 52, PH = 30, PCELLS = PW * PH;
+  static constexpr int PQUADS = (PCELLS + 15) / 16;
   static constexpr int NAPPLE = 155, NWASTE = 0, RANDW = 2 * 155, NSPAWN_CTOR = 20;
   static constexpr int UWORDS = 192, SBYTES = 16;  // the feature pass's key list (48 four-cell chunks >= 155 apple cells); keeps the wave's LDS slice under 5 KB = 8 waves/SIMD
   static constexpr int IMAGE_STRIDE = (PCELLS + 15) / 16 * 16;  // bytes of the padded image ce_download("grid") returns
@@ -62,6 +64,7 @@ struct GridTables {
   uint64_t apple_thresh[120];  // cleanup: by #H on the map -> ceil(p_apple * 2^53) | kWasteOnBit; harvest: [0..3] by neighbour count
   uint8_t waste_on[120];       // cleanup: by #H -> waste spawn probability is non-zero (host-side copy of the flag bit)
   uint8_t base_pmap[1568];     // padded reset-time map (walls + H/R/S, or harvest apples)
+  uint8_t base_pmap4[1568];    // the same with every code pre-scaled by 4 (the grid kernels' LDS form: 16-byte copies, no shift)
   uint32_t close_off[24];      // harvest: 21 padded-index offsets with j^2+k^2 <= 5 (as int32)
 };
 

@@ -120,63 +120,42 @@ DEVINL u32 mt_mix(u32 a, u32 b, u32 c) {  // new = c ^ twist(a,b)
   return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Regenerates the 624-word state with 64 lanes: three dependent chunks (0..226 read only old
-// words, 227..453 read chunk-1 results, 454..622 read chunk-2 results), then word 623.
+// Regenerates the 624-word state with 64 lanes, four consecutive words (one 16-byte quad) per lane and phase.
+// new[i] = mix(old[i], old[i+1], X[i]) with X[i] = old[i+397] for i < 227 and new[i-227] after that; 397 and -227 are
+// both 1 mod 4, so with the state seen as 156 quads Q[0..155] a lane that owns quad q needs Q[q], the first word of
+// Q[q+1], and the quad r = (q + 99) mod 156 shifted by one word (its last three words and the first of Q[r+1]).
+// Three dependent phases of quads [0,56), [56,112), [112,156) keep every dependence in an earlier phase: phase B reads
+// Q[155] (still old: words 621..623) and Q[0..55] (new), phase C reads Q[55..99] (new), and the wrap-around word of
+// quad 155 is new[0], as in the sequential algorithm.  3 x (2 ds_read_b128 + 2 ds_read_b32 + 20 VALU + 1 ds_write_b128)
+// instead of eleven 64-word rounds of dword accesses (it was ~140 VALU and 45 LDS instructions per twist).
 // (noinline: it is reached from every place that can run the stream dry.  The state pointer is passed in the
 // LDS address space so the body is ds_read / ds_write with 32-bit addresses instead of flat accesses.)
 typedef __attribute__((address_space(3))) u32 lds_u32;
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 __device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) {
+  lds_u32x4* Q = (lds_u32x4*)mt;
+  constexpr u32 kQuads = (u32)kMtN / 4;  // 156
   wave_sync();
-  // chunk 1: words 0..226 (4 lane rounds) read only old words -> all reads first, then all writes
-  {
-    u32 v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = 64 * r + lane, ic = i < 227 ? i : 0;
-      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic + kMtM]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = 64 * r + lane;
-      if (i < 227) mt[i] = v[r];
-    }
-    wave_sync();
-  }
-  // chunk 2: words 227..453 read old words and chunk-1 results
-  {
-    u32 v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = 227 + 64 * r + lane, ic = i < 454 ? i : 227;
-      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const u32 i = 227 + 64 * r + lane;
-      if (i < 454) mt[i] = v[r];
-    }
+  for (int ph = 0; ph < 3; ++ph) {
+    const u32 q0 = ph == 0 ? 0u : ph == 1 ? 56u : 112u, cnt = ph == 2 ? 44u : 56u;
+    const bool on = lane < cnt;
+    const u32 q = q0 + (on ? lane : 0u);  // idle lanes shadow the phase's first quad (reads only)
+    u32 r = q + 99u;
+    r = r >= kQuads ? r - kQuads : r;
+    const u32 q1 = q + 1u == kQuads ? 0u : q + 1u, r1 = r + 1u == kQuads ? 0u : r + 1u;
+    const u32x4_t A = Q[q], R = Q[r];
+    const u32 nx = mt[4u * q1], rx = mt[4u * r1];
+    u32x4_t N;
+    N.x = mt_mix(A.x, A.y, R.y);
+    N.y = mt_mix(A.y, A.z, R.z);
+    N.z = mt_mix(A.z, A.w, R.w);
+    N.w = mt_mix(A.w, nx, rx);
+    wave_sync();  // every read of the phase precedes its writes (a lane's next word is its neighbour's quad)
+    if (on) Q[q] = N;
     wave_sync();
   }
-  // chunk 3: words 454..622 read old words and chunk-2 results
-  {
-    u32 v[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const u32 i = 454 + 64 * r + lane, ic = i < 623 ? i : 454;
-      v[r] = mt_mix(mt[ic], mt[ic + 1], mt[ic - 227]);
-    }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const u32 i = 454 + 64 * r + lane;
-      if (i < 623) mt[i] = v[r];
-    }
-    wave_sync();
-  }
-  if (lane == 0) mt[623] = mt_mix(mt[623], mt[0], mt[396]);
-  wave_sync();
 }
 
 DEVINL void mt_twist(u32* mt, u32 lane) { mt_twist_lds((lds_u32*)mt, lane); }
@@ -605,7 +584,7 @@ template <int KIND> struct alignas(16) WaveLds {
   u32 mt[kMtN];
   u32 U[Geo<KIND>::UWORDS];
   uint8_t S[Geo<KIND>::SBYTES];
-  uint8_t pmap[Geo<KIND>::PCELLS];
+  uint8_t pmap[Geo<KIND>::PQUADS * 16];  // PCELLS bytes used; padded to whole 16-byte quads for the image copy
   u32 rgb[16];
 };
 
@@ -826,13 +805,13 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   const u32 q2 = min(lane + 128u, kLastQuad);
   const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
   const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
-  // map: the constant base image (L2-resident, shared by every env) + this env's 8 presence dwords (one scalar load)
-  const u32* gsrc = (const u32*)T.base_pmap;
-  constexpr int GROUNDS = (G::PCELLS / 4 + 63) / 64;
-  constexpr u32 kLastMapWord = (u32)G::PCELLS / 4 - 1;
-  u32 gw[GROUNDS];
-#pragma unroll
-  for (int r = 0; r < GROUNDS; ++r) gw[r] = gsrc[min(lane + 64u * r, kLastMapWord)];
+  // map: the constant base image, codes pre-scaled (L2-resident, shared by every env), as two rounds of 16-byte copies
+  // + this env's 8 presence dwords (one scalar load)
+  const uint4* gsrc = (const uint4*)T.base_pmap4;
+  static_assert(G::PQUADS > 64 && G::PQUADS <= 128 && G::PQUADS * 16 <= (int)sizeof(T.base_pmap4), "two quad rounds");
+  constexpr u32 kLastMapQuad = (u32)G::PQUADS - 1;
+  const u32 gq1 = min(lane + 64u, kLastMapQuad);  // unconditional: idle lanes repeat the last quad
+  const uint4 gw0 = gsrc[lane], gw1 = gsrc[gq1];
   u32 gbits[8];
   {
     const auto bsrc = (CE_GPTR(const u32))(p.grid + (size_t)E.e * kGridStateBytes);
@@ -863,9 +842,9 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   }
   const u32 rgbv = c_rgb[lane & 15];
   // ---- LDS image ----
-  u32* pm32 = (u32*)E.L->pmap;
-#pragma unroll
-  for (int r = 0; r < GROUNDS; ++r) pm32[min(lane + 64u * r, kLastMapWord)] = gw[r] << kScale;  // codes <= 5: no carry between bytes
+  uint4* pm128 = (uint4*)E.L->pmap;
+  pm128[lane] = gw0;
+  pm128[gq1] = gw1;
   wave_sync();
   paint_presence(E, gbits);
   E.L->rgb[lane & 15] = rgbv;

@@ -84,7 +84,7 @@ def test_bench_default_line_has_every_config():
     assert row["fused"]["steps"] == 32 and row["fused"]["steps_per_launch"] == 16
     assert abs(row["fused"]["launches_per_step"] - 3 / 16.0) < 1e-9
     cl = row["closed_loop"]
-    assert cl["value"] > 0 and cl["host_iterations_per_step"] == 1 and cl["timed_seconds"] >= 0.5
+    assert cl["value"] > 0 and cl["host_iterations_per_step"] == 1 and cl["timed_seconds"] >= 0.5 and "eager" in cl["modes"]
     bd = row["boundary"]
     assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > 0
     rf = row["roofline"]

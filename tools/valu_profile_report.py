@@ -14,9 +14,16 @@ def load(k):
     return {c: s / k2 / w for c, (s, k2) in acc.items()}
 prev = {}
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SMEM"]
-print("%-42s" % "phase (per wave)" + "".join("%12s" % c.replace("SQ_", "").replace("INSTS_", "") for c in cols))
+short = [c.replace("SQ_", "").replace("INSTS_", "") for c in cols]
+print("# k_grid_step<cleanup>, n = 8, 16384 envs, steady state: executed instructions PER ENV-STEP (= per wave), by phase.")
+print("# Method: the kernel is built 12 times, each build ending at one more phase boundary (-DCE_TRUNCATE=k, everything live")
+print("# folded into one store); the PMC counters of consecutive builds are differenced.  The compiler schedules each build")
+print("# on its own, so a phase that mostly hoists work of the NEXT phase can come out a few instructions negative: read")
+print("# the cumulative column for anything finer than ~10 instructions.  Never shipped, never benchmarked.")
+print("%-42s" % "phase" + "".join("%14s" % c for c in short) + "%14s" % "cum VALU" + "%10s" % "cum SALU")
 for k in order:
     cur = load(k)
-    print("%-42s" % names[k] + "".join("%12.1f" % (cur.get(c, 0) - prev.get(c, 0)) for c in cols))
+    print("%-42s" % names[k] + "".join("%14.1f" % (cur.get(c, 0) - prev.get(c, 0)) for c in cols)
+          + "%14.1f%10.1f" % (cur.get("SQ_INSTS_VALU", 0), cur.get("SQ_INSTS_SALU", 0)))
     prev = cur
-print("%-42s" % "total" + "".join("%12.1f" % prev.get(c, 0) for c in cols))
+print("%-42s" % "total (the shipped kernel)" + "".join("%14.1f" % prev.get(c, 0) for c in cols))
