@@ -220,9 +220,8 @@ class Runner:
         self.handles = [st.cuda_stream for st in self.streams] if S > 1 else None
         self.traj = None
         self.preroll = max(PREROLL, int(wl.get("preroll", PREROLL)))
-        for _ in range(self.preroll // PREROLL - 1):  # long pre-rolls replay the pre-roll planes (fused launches: cheap)
-            self.env.rollout_fused(self.acts.data_ptr(), PREROLL, 50, None, self.handles)
-        self.env.rollout_device(self.acts.data_ptr(), PREROLL, self.handles)
+        for _ in range(self.preroll // PREROLL):  # long pre-rolls replay the pre-roll planes (always per-step launches)
+            self.env.rollout_device(self.acts.data_ptr(), PREROLL, self.handles)
         torch.cuda.synchronize()
 
     def _issue(self, mode, first_plane, count, T):

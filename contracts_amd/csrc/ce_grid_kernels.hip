@@ -41,7 +41,7 @@ namespace ce {
 namespace diag {
 constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = false, ablate_obsstore = false,
                ablate_gridstore = false, ablate_rngstore = false, seq_shuffle = false, serial_apply = false,
-               serial_small_shuffle = false;
+               serial_small_shuffle = false, ablate_twist = false;
 }
 }  // namespace ce
 #endif
@@ -158,7 +158,9 @@ __device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) {
   }
 }
 
-DEVINL void mt_twist(u32* mt, u32 lane) { mt_twist_lds((lds_u32*)mt, lane); }
+DEVINL void mt_twist(u32* mt, u32 lane) {
+  if (!diag::ablate_twist) mt_twist_lds((lds_u32*)mt, lane);
+}
 
 struct Rng {
   u32* mt;     // LDS, 624 words
@@ -694,7 +696,7 @@ template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
 }
 template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   wave_sync();
-  if (rfl(E.rng.twists) != 0) {  // the key words only change at a twist; otherwise just the position moves
+  if (rfl(E.rng.twists) != 0 && !diag::ablate_twist) {  // the key words only change at a twist; otherwise just the position moves
     uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
     const uint4* src = (const uint4*)E.L->mt;
     const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
@@ -2258,6 +2260,9 @@ template <int GK> struct alignas(16) FeatLds {
   };
 };
 constexpr u32 kAbsent = CE_FEAT_ABSENT;
+// doubles of the CPython stream a single-step launch of HarvestFeatures fetches speculatively (one per lane): a step
+// draws one per absent apple cell — 5-20 in the steady state, 40 at the 99.9th percentile; more takes the general path
+constexpr u32 kFeatWindow = 40;
 
 template <int GK> struct FEnv {
   FeatLds<GK>* L;
@@ -2371,8 +2376,8 @@ template <int GK, bool LIGHT = false> DEVINL void feat_load(FEnv<GK>& E, const G
   E.stamps_dirty = false;
   E.win_a = E.win_b = 0;
   const u32 pypos = rsrc[CE_RNG_WORDS_GRID + kMtN];
-  if (LIGHT) {  // lane q: the two raw words of double q after the current position (clamped inside the generation)
-    const u32 i0 = min(rfl(pypos) + 2u * lane, (u32)kMtN - 2u);
+  if (LIGHT) {  // lane q < kFeatWindow: the two raw words of double q after the current position (clamped inside the generation)
+    const u32 i0 = min(rfl(pypos) + 2u * min(lane, kFeatWindow - 1u), (u32)kMtN - 2u);
     const auto w = rsrc + CE_RNG_WORDS_GRID;
     E.win_a = GAT(w, i0);
     E.win_b = GAT(w, i0 + 1u);
@@ -2543,7 +2548,7 @@ template <int GK> DEVINL void feat_spawn(FEnv<GK>& E, const GridParams& p) {
     // state of a fused rollout): nothing of the generator but its position changes.
     rng_assert_uniform(E.py);
     if (nelig == 0) return;
-    if (nelig <= 64u && E.py.pos + 2u * nelig <= (u32)kMtN) {
+    if (nelig <= (E.py_resident ? 64u : kFeatWindow) && E.py.pos + 2u * nelig <= (u32)kMtN) {
       u32 wa = E.win_a, wb = E.win_b;
       if (E.py_resident) {
         const u32 i0 = min(E.py.pos + 2u * lane, (u32)kMtN - 2u);

@@ -1,16 +1,18 @@
 #!/bin/bash
 # Runs ON the GPU box (via gpurun): the round's profile set of the headline workload.
-#   tools/collect_profiles.sh [TAG]        (TAG default r02)
-# 1. rocprofv3 --kernel-trace --stats over the default bench command (every config of the line) -> kernel_stats
+#   tools/collect_profiles.sh [TAG]        (TAG default r03)
+# 1. rocprofv3 --kernel-trace --stats over the default bench command (every config of the line) -> kernel_stats, and the
+#    raw trace split by launch size (tools/kernel_trace_by_config.py) -> one row per (kernel, config)
 # 2. PMC passes (separate runs, --pmc only) over tools/pmc_driver.py for the per-step kernel and the fused kernel:
 #    instruction mix / waits / LDS conflicts, then FETCH_SIZE and WRITE_SIZE each in its own pass
 # Output under gpurun_out/prof_$TAG; summarise on the build box with tools/summarise_profiles.py.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
 tail -1 $OUT/kt_bench_line.json | cut -c1-200
+python3 $R/tools/kernel_trace_by_config.py $OUT/kt $OUT/kernel_stats_by_config.csv
 cd $R
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY"
 G2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"

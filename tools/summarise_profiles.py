@@ -1,5 +1,6 @@
 """Turns gpurun_out/prof_<tag> (tools/collect_profiles.sh) into the committed summaries under profiles/:
   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats kernel summary of the default bench command
+  <tag>_kernel_stats_by_config.csv   the same trace split by launch size: one row per (kernel, BASELINE config)
   <tag>_pmc_summary.json   per env-step counter values of the per-step and the fused kernels + HBM traffic
   <tag>_bench_line.json    the bench line of the profiled run (slower than an unprofiled one)
   traffic.json             PMC HBM bytes per env-step, read by bench.py into roofline.traffic
@@ -10,8 +11,8 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ALGO = {"step": 7235, "fused": 7235, "sd_step": 863, "sd_fused": 863, "c3_step": 7313, "c3_fused": 7313, "c2_step": 4211,
         "c2_fused": 4211, "c1_step": 887, "c1_fused": 887}
 KIND = {"step": ("cleanup", 8), "fused": ("cleanup", 8), "sd_step": ("selfdrive", 4), "sd_fused": ("selfdrive", 4),
@@ -22,11 +23,14 @@ TRAFFIC_KEY = {"step": "per_step", "fused": "fused", "sd_step": "per_step_C5", "
 
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
 shutil.copy(max(stats, key=os.path.getmtime), "profiles/%s_kernel_stats.csv" % tag)
+by_cfg = os.path.join(src, "kernel_stats_by_config.csv")
+if os.path.exists(by_cfg):  # the same trace split by launch size: one row per (kernel, config)
+    shutil.copy(by_cfg, "profiles/%s_kernel_stats_by_config.csv" % tag)
 line = [ln for ln in open(os.path.join(src, "kt_bench_line.json")).read().splitlines() if ln.startswith("{")][-1]
 json.dump(json.loads(line), open("profiles/%s_bench_line.json" % tag, "w"), indent=1)
 
 out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 20 "
-       "--no-cpu-baseline --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
+       "--no-cpu-baseline --no-closed-loop --no-boundary --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
        "a 300-step pre-roll run with the other mode's kernel), summed over the dispatches of the kernel and divided by envs x steps",
        "kernels": {}}
 traffic = {}
