@@ -17,8 +17,10 @@ SOURCES = ["ce_api.hip", "ce_grid_kernels.hip", "ce_selfdrive_kernels.hip"]
 HEADERS = ["ce_device.h", "ce_grid_probe.inc", os.path.join("..", "..", "include", "contracts_engine.h")]
 # -ffp-contract=off: float64 reward/transfer arithmetic must round exactly like the reference's
 # separate multiply and add; no fast-math anywhere.
+# -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave launch (gfx950), see
+# k_grid_step in ce_grid_kernels.hip.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def hipcc():

@@ -821,8 +821,7 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
     for (int k = 0; k < 8; ++k) gbits[k] = bsrc[k];
   }
   const u32 aw = GAT((CE_GPTR(const u32))p.agents + (size_t)E.e * E.n, min(lane, E.n - 1u));
-  const u32 sp = GAT(p.spawn_perm + (size_t)E.e * 20, min(lane, 19u));
-  E.SP = lane < 20 ? sp : 0;
+  E.SP = 0;  // the 20-entry spawn list is only needed by a reset: it stays in HBM and is fetched there (grid_step_core)
   E.WP0 = E.WP1 = 0;
   if (KIND == CE_KIND_CLEANUP) {
     const auto wp = p.waste_perm + (size_t)E.e * 119;
@@ -1124,6 +1123,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   u64 thrA[AR];
   u32 rbase = 0;
   u32 nH = 0;
+  u64 hmask[2] = {0, 0};  // cleanup: waste present on static waste cell lane + 64 r (the map as the spawn model sees it)
   bool waste_on = false;
   bool scan = true;  // wave-uniform: some cell can spawn this step
   if (KIND == CE_KIND_CLEANUP) {
@@ -1131,7 +1131,8 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const bool v = lane + 64 * r < (u32)G::NWASTE;
-      nH += popc64(ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
+      hmask[r] = ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
+      nH += popc64(hmask[r]);
     }
     const u64 th = T.apple_thresh[nH];
     waste_on = (th & kWasteOnBit) != 0;
@@ -1257,25 +1258,22 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
       }
       CE_SUBSTAMP(13);
       if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
-        // both halves of the list at once; the static cell of list entry w sits in lane w (mod 64) of E.WS — a lane
-        // permute instead of a dependent table load from memory
+        // both halves of the list at once.  Whether list entry w (a static waste-cell index) is a candidate is bit w of
+        // the presence ballots taken above — no lookup of the entry's cell, no map read; only the chosen entry's cell
+        // is fetched (a readlane of the static table held in E.WS)
         static_assert(KIND != CE_KIND_CLEANUP || (G::NWASTE > 64 && G::NWASTE <= 128), "two lane rounds");
         const bool v1 = lane + 64 < (u32)G::NWASTE;
         const u32 w0 = E.WP0, w1 = v1 ? E.WP1 : 0u;
-        const u32 t00 = bperm(E.WS[0], w0), t01 = bperm(E.WS[1], w0 - 64u);
-        const u32 t10 = bperm(E.WS[0], w1), t11 = bperm(E.WS[1], w1 - 64u);
-        const u32 c0 = cell_pad(w0 < 64u ? t00 : t01), c1 = cell_pad(w1 < 64u ? t10 : t11);
-        const bool cand0 = (pm[c0] & kCodeMask) != kWaste;
-        const bool cand1 = both(v1, (pm[c1] & kCodeMask) != kWaste);
+        const u64 h0 = w0 < 64u ? hmask[0] : hmask[1], h1 = w1 < 64u ? hmask[0] : hmask[1];
+        const bool cand0 = ((h0 >> (w0 & 63u)) & 1ull) == 0;
+        const bool cand1 = both(v1, ((h1 >> (w1 & 63u)) & 1ull) == 0);
         const u64 cb0 = ballot(cand0), cb1 = ballot(cand1);
         const u64 sel0 = ballot(cand0 && popc64(cb0 & lt) == tstar);
         const u64 sel1 = ballot(cand1 && popc64(cb0) + popc64(cb1 & lt) == tstar);
-        if (sel0) {
+        if (sel0 | sel1) {
+          const u32 wsel = sel0 ? rdl(w0, ctz64(sel0)) : rdl(w1, ctz64(sel1));
           waste_found = true;
-          waste_cell = rdl(c0, ctz64(sel0));
-        } else if (sel1) {
-          waste_found = true;
-          waste_cell = rdl(c1, ctz64(sel1));
+          waste_cell = cell_pad(wsel < 64u ? rdl(E.WS[0], wsel) : rdl(E.WS[1], wsel - 64u));
         }
       }
     }
@@ -2075,9 +2073,9 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     for (u32 k = lane; k < nmf; k += 64) p.final_f64_metrics[(size_t)E.e * nmf + k] = mf[k];
     if (p.flags & CE_FLAG_AUTO_RESET) {
       __threadfence_block();
-      if (FUSED) E.SP = GAT(p.spawn_perm + (size_t)E.e * 20, min(lane, 19u));  // the spawn list is only ever needed here
+      E.SP = GAT(p.spawn_perm + (size_t)E.e * 20, min(lane, 19u));  // the spawn list is only ever needed here
       reset_env(E, p, theta, t, fault);
-      if (FUSED) store_perms(E, p, true, false);
+      store_perms(E, p, true, false);
       did_reset = true;
     }
   }
@@ -2091,7 +2089,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   }
   if (!obs_early) store_grid(E, p);
   store_agents(E, p);
-  store_perms(E, p, did_reset, E.waste_perm_dirty);
+  store_perms(E, p, false, E.waste_perm_dirty);  // (the spawn list was written by the reset that changed it)
   if (!diag::ablate_rngstore) store_rng(E, p);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
@@ -2105,45 +2103,36 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   CE_REALSTAMP(15);
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
-                 u32 env_first, u32 env_end) {
+// Entry latency.  A wave can do nothing before its env's state arrives, so the first vector loads should leave as early as
+// possible.  Everything they need comes in as kernel ARGUMENTS — the state pointers, the env range, n — fourteen dwords,
+// which gfx950 preloads into SGPRs when the wave is launched (-mllvm -amdgpu-kernarg-preload-count=16: the kernel's real
+// entry follows a 256-byte compatibility prologue that older firmware runs to fetch them with scalar loads).  The wave
+// starts with its addresses in registers instead of two dependent scalar-load round trips (the kernarg segment, then the
+// head of the parameter block), ~300 cycles each under load.  The parameter block `pp` is still read for everything that
+// is not on the way to the first load (output pointers, flags, contract bounds).
+template <int KIND>
+__global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(
+    const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
+    uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
+  // fourteen dwords — sixteen user SGPRs less the kernarg segment pointer — are preloaded: exactly these arguments.  The
+  // launch has one workgroup per env of its range, so no upper bound travels (kWavesPerBlock == 1).
+  static_assert(kWavesPerBlock == 1, "k_grid_step takes no env_end: the grid is the env range");
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
-  // Entry latency: left to itself the compiler fetches each kernel argument and each parameter-block field with its own
-  // scalar load right before the first use, behind the branches of the range check — five to six serialised ≈ 270-cycle
-  // round trips before the first state load is even issued.  Two batched fetches instead: the 32-byte kernarg segment,
-  // then the head of the block (state pointers) and its scalar fields together; the first phase reads from these copies.
-  typedef u32 u32x8 __attribute__((ext_vector_type(8)));
-  typedef u32 u32x16 __attribute__((ext_vector_type(16)));
-  static_assert(offsetof(GridParams, theta) == 0x30 && offsetof(GridParams, E) == 0xb0 && offsetof(GridParams, num_features) == 0xc8,
-                "preload offsets follow the GridParams layout");
-  u32x8 ka;
-  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ka) : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
-  u32x16 hb;
-  u32x8 sb;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0xb0\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(hb), "=&s"(sb)
-               : "s"((u64)ka[0] | ((u64)ka[1] << 32)));
-  GridParams ph;
-#define CE_HEAD_PTR(field, k) ph.field = (decltype(ph.field))((u64)hb[2 * (k)] | ((u64)hb[2 * (k) + 1] << 32))
-  CE_HEAD_PTR(grid, 0);
-  CE_HEAD_PTR(agents, 1);
-  CE_HEAD_PTR(spawn_perm, 2);
-  CE_HEAD_PTR(waste_perm, 3);
-  CE_HEAD_PTR(rng, 4);
-  CE_HEAD_PTR(timestep, 5);
-  CE_HEAD_PTR(theta, 6);
-#undef CE_HEAD_PTR
+  GridParams ph;  // the fields load_env_state reads, from the arguments
+  ph.rng = (decltype(ph.rng))rng_base;
+  ph.grid = (decltype(ph.grid))grid_base;
+  ph.agents = (decltype(ph.agents))agents_base;
+  ph.waste_perm = (decltype(ph.waste_perm))waste_perm_base;
 #ifdef CE_INSTRUMENTED
   ph.debug = p.debug;  // diagnostic builds stamp through E.dbg
 #else
   ph.debug = nullptr;
 #endif
-  ph.E = sb[0];
-  ph.n = sb[1];
-  const auto acts = (CE_GPTR(const uint8_t))((u64)ka[2] | ((u64)ka[3] << 32));
-  if (!env_begin(E, ph, lds, ka[6], ka[7])) return;
+  ph.n = num_agents;
+  const auto acts = (CE_GPTR(const uint8_t))call_actions;
+  env_begin(E, ph, lds, env_first, 0xffffffffu);
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
 
@@ -2152,8 +2141,8 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE
   CE_STAMP(0);
   CE_REALSTAMP(14);
   load_env_state(E, ph);
-  u32 t = (u32)ph.timestep[E.e];
-  double theta = ph.theta[E.e];
+  u32 t = (u32)p.timestep[E.e];
+  double theta = p.theta[E.e];
   u32 fault = 0;
   bool did_reset = false;
   grid_step_core<KIND, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
@@ -3461,7 +3450,17 @@ static unsigned extra_lds() {
 
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
-void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_step); }
+void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) {
+  const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
+  dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+  // the state pointers travel as kernel arguments (preloaded into SGPRs at wave launch), see k_grid_step
+  if (kind == CE_KIND_CLEANUP)
+    hipLaunchKernelGGL(k_grid_step<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+                       (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+  else
+    hipLaunchKernelGGL(k_grid_step<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+                       (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+}
 
 void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
