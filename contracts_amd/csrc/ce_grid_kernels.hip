@@ -737,28 +737,41 @@ template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8
     }
   }
 }
+// the env's 8 state dwords from presence ballots: presA[r] = apple on apple cell lane + 64 r, presW[r] likewise for waste
+template <int KIND> DEVINL void store_grid_bits(Env<KIND>& E, const GridParams& p, const u64 (&presA)[3], const u64 (&presW)[2], bool blank = false) {
+  typedef Geo<KIND> G;
+  constexpr int AR = (G::NAPPLE + 63) / 64;
+  u32 w = 0;  // lane k < 8 assembles state dword k
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    if (E.lane == 2 * r) w = (u32)presA[r];
+    if (E.lane == 2 * r + 1) w = (u32)(presA[r] >> 32);
+  }
+  if (KIND == CE_KIND_CLEANUP) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (E.lane == 4 + 2 * r) w = (u32)presW[r];
+      if (E.lane == 5 + 2 * r) w = (u32)(presW[r] >> 32);
+    }
+  }
+  if (blank && E.lane == 7) w |= 1u << (kGridBlankBit & 31);
+  if (E.lane < 8) GAT((CE_GPTR(u32))(p.grid + (size_t)E.e * kGridStateBytes), E.lane) = w;
+}
 template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p, bool blank = false) {
   typedef Geo<KIND> G;
   wave_sync();
   const uint8_t* pm = E.L->pmap;
   constexpr int AR = (G::NAPPLE + 63) / 64;
-  u32 w = 0;  // lane k < 8 assembles state dword k
+  u64 presA[3] = {0, 0, 0}, presW[2] = {0, 0};
 #pragma unroll
-  for (int r = 0; r < AR; ++r) {
-    const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == kApple));
-    if (E.lane == 2 * r) w = (u32)m;
-    if (E.lane == 2 * r + 1) w = (u32)(m >> 32);
-  }
+  for (int r = 0; r < AR; ++r)
+    presA[r] = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == kApple));
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const u64 m = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
-      if (E.lane == 4 + 2 * r) w = (u32)m;
-      if (E.lane == 5 + 2 * r) w = (u32)(m >> 32);
-    }
+    for (int r = 0; r < 2; ++r)
+      presW[r] = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
   }
-  if (blank && E.lane == 7) w |= 1u << (kGridBlankBit & 31);
-  if (E.lane < 8) GAT((CE_GPTR(u32))(p.grid + (size_t)E.e * kGridStateBytes), E.lane) = w;
+  store_grid_bits(E, p, presA, presW, blank);
 }
 
 template <int KIND> DEVINL void load_agents(Env<KIND>& E, const GridParams& p) {
@@ -1343,7 +1356,9 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
   // 4 * (l % 4) ..) of that agent's view as 12 bytes (rows are pitched to 16 pixels).  The view parameters of the
   // round are wave-uniform scalars, the lane's (row, column) never changes, and the store is base + lane * 12.
   const u32 row = (lane < 60 ? lane : 59u) >> 2, j0 = (lane & 3u) << 2;
-  const bool padded = j0 == 12;  // column 15 is the row padding
+  // column 15 is the row padding: those lanes' last-word byte selector takes zeros instead of the fourth pixel (one
+  // per-lane selector instead of a select per view)
+  const u32 selz = j0 == 12 ? 0x0c0c0c02u : 0x06050402u;
   const u32 voff = __umul24(lane, 12u);
   const u32* rgb = E.L->rgb;
   const auto dst_env = (CE_GPTR(char))(obs + (size_t)E.e * p.obs_env_stride);
@@ -1358,23 +1373,24 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     const u32 c0 = lut(off0);
     const u32 c1 = lut(off1);
     const u32 c2 = lut(off2);
-    u32 c3 = lut(off3);
-    c3 = padded ? 0u : c3;
+    const u32 c3 = lut(off3);
     u32x3 d;
     d.x = __builtin_amdgcn_perm(c1, c0, 0x04020100u);  // R0 G0 B0 R1
     d.y = __builtin_amdgcn_perm(c2, c1, 0x05040201u);  // G1 B1 R2 G2
-    d.z = __builtin_amdgcn_perm(c3, c2, 0x06050402u);  // B2 R3 G3 B3
+    d.z = __builtin_amdgcn_perm(c3, c2, selz);         // B2 R3 G3 B3 (padding lanes: B2 0 0 0)
     return d;
   };
   auto put_unit = [&](u32 a, const u32x3& dv) {
-    const u32 doff = voff + __umul24(a, (u32)kObsAgentStride);  // 32-bit offset from the wave-uniform env base
+    // the agent's view starts a * 720 bytes into the env's block: folded into the wave-uniform base (scalar add), the
+    // per-lane part of the address stays lane * 12 for every agent
+    const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
     if (diag::ablate_obsstore) {  // traffic experiment: the pixels are computed but not written
       asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
       return;
     }
     // streaming (nontemporal) store: the observation is write-once output and the bulk of the step's bytes; keeping it
     // out of L2 / Infinity Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536)
-    if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_env + doff));
+    if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
   };
   // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
   // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
@@ -1525,7 +1541,10 @@ template <class P> DEVINL void store_feat2(P f, u32 idx, u32 lo, u32 hi, bool al
   }
 }
 
-template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned) {
+// presA / presW (out): the presence ballots of the map as it is now (apple on apple cell lane + 64 r, waste likewise) — the
+// packed map state of a single-step launch is assembled from them (store_grid_bits) instead of scanning the map again
+template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned,
+                                                u64 (&presA)[3], u64 (&presW)[2]) {
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane, n = E.n;
@@ -1560,14 +1579,17 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       f = both(lane + 64 * r < (u32)G::NAPPLE, pm[cell_pad(E.AP[r < 3 ? r : 0])] == kApple);
       rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
-    napples += popc64(ballot(f));
+    const u64 fb = ballot(f);
+    if (r < 3) presA[r < 3 ? r : 0] = fb;
+    napples += popc64(fb);
     keyA[lane + 64 * r] = f ? rc : kNoKey;
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (u32 r = 0; r < 2; ++r) {
       const bool f = both(lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste);
-      nwaste += popc64(ballot(f));
+      presW[r] = ballot(f);
+      nwaste += popc64(presW[r]);
       keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
     }
   }
@@ -1705,7 +1727,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 #define CE_CLEANUP_WAVES 8  // the step kernel: 62 VGPRs, no scratch
 #endif
 #ifndef CE_CLEANUP_ROLLOUT_WAVES
-#define CE_CLEANUP_ROLLOUT_WAVES 7  // 72 VGPRs + 12 spilled: 3 % faster than 94 VGPRs at 5 waves without any
+// 8 waves (64 VGPRs + 21 spilled): measured 3 % faster than 7 waves (72 + 13 spilled) in round 3 — 4.24 vs 4.12 G
+// agent-steps/s, tools/ab.sh, two rounds interleaved — which in round 1 was itself 3 % faster than 5 waves without spills
+#define CE_CLEANUP_ROLLOUT_WAVES 8
 #endif
 constexpr int kWavesPerBlock = 1;
 
@@ -1784,7 +1808,10 @@ template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_gri
   store_rng(E, p);
   clear_step_outputs(E, p);
   if (!E.is_agent) E.P = 0xffffu;
-  compute_features(E, p, p.features, 0u);
+  {
+    u64 pa_[3], pw_[2];
+    compute_features(E, p, p.features, 0u, pa_, pw_);
+  }
   write_obs(E, p, p.obs, false);  // reset() does not paint the agents on the colour map
   if (E.lane == 0) {
     p.timestep[E.e] = 0;
@@ -1926,14 +1953,18 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 
   CE_STAMP(5);
   // ---------------- feature obs, infos, metrics ----------------
-  const u32 feat8 = diag::ablate_features ? 0u : compute_features(E, p, out.features(), cleaned);
+  u64 presA[3] = {0, 0, 0}, presW[2] = {0, 0};
+  const u32 feat8 = diag::ablate_features ? 0u : compute_features(E, p, out.features(), cleaned, presA, presW);
   // The observation (the bulk of the step's stores) goes out as early as the map allows, so that its stores drain
   // under the epilogue's arithmetic instead of at the wave's very end.  It paints the agents over the map bytes,
   // hence after the feature pass and after the map state is packed; a done step with auto-reset writes the reset
   // observation instead and keeps the late path.
   const bool obs_early = t != p.horizon;
   if (obs_early) {
-    if (!FUSED) store_grid(E, p);  // a fused rollout keeps the map in LDS and packs it once, after its last step
+    if (!FUSED) {  // a fused rollout keeps the map in LDS and packs it once, after its last step
+      if (diag::ablate_features) store_grid(E, p);
+      else store_grid_bits(E, p, presA, presW);  // the feature pass has just taken the map's presence ballots
+    }
     write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
