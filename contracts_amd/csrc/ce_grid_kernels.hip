@@ -342,8 +342,9 @@ template <int MODE> DEVINL u32 shuffle_le8(Rng& r, u32& l0, u32 len, u32 lane) {
   }
   const u32 w = r.cache;
   const u32 v7 = w & 7u, v3 = w & 3u, v1 = w & 1u;
-  const u64 B7 = ballot(v7 <= 7u), B6 = ballot(v7 <= 6u), B5 = ballot(v7 <= 5u), B4 = ballot(v7 <= 4u);
-  const u64 B3 = ballot(v3 <= 3u), B2 = ballot(v3 <= 2u), B1 = ballot(v1 <= 1u);
+  // indices 7, 3 and 1 equal their mask: every word is accepted (the next unread one); only 6, 5, 4 and 2 can reject
+  const u64 B7 = ~0ull, B6 = ballot(v7 <= 6u), B5 = ballot(v7 <= 5u), B4 = ballot(v7 <= 4u);
+  const u64 B3 = ~0ull, B2 = ballot(v3 <= 2u), B1 = ~0ull;
   u64 avail = r.cvalid & (~0ull << off);
   u32 i = len - 1;
   u32 next = r.cbase + off;  // stream position after the last consumed word
@@ -462,10 +463,11 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
     const i32 v = d < r.ccount - off ? (i32)(r.cache & mask) : 0x7fffffff;  // read / missing words never accept
     const i32 t0 = (i32)i0 - (i32)d;
     u64 Lm = ballot(v <= (t0 > (i32)lo ? t0 : (i32)lo)), Um = ballot(v <= (i32)i0);
-    while (Lm != Um) {
-      const i32 aL = (i32)rank_in(Lm, lane), aU = (i32)rank_in(Um, lane);
-      Lm = ballot(v <= (i32)i0 - aU);
-      Um = ballot(v <= (i32)i0 - aL);
+    while (Lm != Um) {  // each half-step uses the newest bound of the other side (Gauss-Seidel: fewer rounds than updating both from the old pair)
+      const i32 aL = (i32)rank_in(Lm, lane);
+      Um = ballot(v <= (i32)i0 - aL);  // a_k >= |L below k|  =>  accepted words lie in { v <= i0 - |L below k| }
+      const i32 aU = (i32)rank_in(Um, lane);
+      Lm = ballot(v <= (i32)i0 - aU);  // a_k <= |U below k|  =>  { v <= i0 - |U below k| } is surely accepted
     }
     const u32 a = rank_in(Lm, lane);
     const u32 idx = i0 - a;
@@ -1968,9 +1970,14 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
+  // A quiet step — nobody ate, cleaned, fired or was hit: every reward, transfer and metric increment is zero — skips the
+  // contract arithmetic and the whole metric bookkeeping behind ONE wave-uniform test (two thirds of the steps of the
+  // benchmark; it was half a dozen separate tests, each a ballot, a scalar compare and a branch).
+  const bool done = t == p.horizon;
+  const bool busy = ballot(E.is_agent && (eaten | eaten_close | cleaned | (u32)base_rew) != 0) != 0 || done;
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   double transfers_total = 0.0;
-  if (p.contract != CE_CONTRACT_NONE) {
+  if (busy && p.contract != CE_CONTRACT_NONE) {
     double tr;
     if (p.contract == CE_CONTRACT_CLEANUP) tr = -theta * (double)cleaned;  // contract_list.py:26
     else tr = (feat8 < 4 && eaten_close > 0) ? theta : 0.0;                // contract_list.py:50-53
@@ -1993,12 +2000,11 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   const u32 nmi = CE_MI_COUNT(n), nmf = CE_MF_COUNT(n);
   const auto mi = p.int_metrics + (size_t)E.e * nmi;
   const auto mf = p.f64_metrics + (size_t)E.e * nmf;
-  const bool done = t == p.horizon;
   const u32 inc_a = KIND == CE_KIND_CLEANUP ? cleaned : eaten;
   long long m_sr = 0, m_str = 0;
   double f_sr = 0.0, f_str = 0.0;
   CE_STAMP(6);
-  {
+  if (busy) {
     // eaten / eaten_close are 0/1 flags; cleaned and the base rewards are zero for most agents
     const u32 sum_eaten = popc64(ballot(eaten != 0)), sum_close = popc64(ballot(eaten_close != 0));
     u32 sum_clean = 0;
@@ -2028,7 +2034,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     }
   }
   double b_sr = 0.0, b_str = 0.0;
-  if (p.flags & CE_FLAG_INEQUITY_AVERSE) {
+  if (busy && (p.flags & CE_FLAG_INEQUITY_AVERSE)) {
     // float env rewards: the reference appends / sums the floats themselves (cleanup_new.py:227-234): raw_rewards = 0;
     // raw_rewards += r[k] in agent order; metrics['raw_env_rewards'] += raw_rewards; total_reward_dict[k].append(r[k])
     double raw = 0.0;
@@ -2041,7 +2047,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       GAT(mf, CE_MF_BASE_AGENT(n, CE_MFA_BASE_SUM_TR, lane)) = b_str;
     }
   }
-  if (p.contract != CE_CONTRACT_NONE) {
+  if (busy && p.contract != CE_CONTRACT_NONE) {
     if (transfers_total != 0.0 && lane == 0) mf[CE_MF_TRANSFERS] += transfers_total;
     const bool any_rew = ballot(E.is_agent && rew != 0.0) != 0;  // adding +-0.0 leaves the (never -0.0) sums unchanged
     if ((any_rew || done) && E.is_agent) {
