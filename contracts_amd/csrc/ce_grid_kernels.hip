@@ -719,6 +719,9 @@ template <int KIND> DEVINL void zero_pmap(Env<KIND>& E) {
 
 // lane's bit of a wave-uniform 64-bit mask
 DEVINL bool lane_bit(u64 m, u32 lane) { return (((lane < 32 ? (u32)m : (u32)(m >> 32)) >> (lane & 31u)) & 1u) != 0; }
+// if_set where the lane's bit of the wave-uniform mask is set, else if_clear: a 64-bit SGPR pair IS a lane mask, so this
+// is one v_cndmask (the shift / and / compare form of lane_bit is four)
+DEVINL u32 select_by_mask(u64 m, u32 if_set, u32 if_clear) { return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear; }
 
 // The map image in LDS = constant base map + the env's presence bits (apples; cleanup: waste vs river).
 // `bits` = the env's 8 state dwords in SGPRs (loaded by the caller with one scalar load).
@@ -729,13 +732,13 @@ template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const u64 m = (u64)bits[2 * r] | (u64)bits[2 * r + 1] << 32;
-    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), lane_bit(m, E.lane) ? kApple : kEmpty);
+    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), select_by_mask(m, kApple, kEmpty));
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const u64 m = (u64)bits[4 + 2 * r] | (u64)bits[5 + 2 * r] << 32;
-      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), lane_bit(m, E.lane) ? kWaste : kRiver);
+      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), select_by_mask(m, kWaste, kRiver));
     }
   }
 }
@@ -1662,8 +1665,8 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
                         ((ka_a >> 8) & 0xffu) | (ka_a & 0xffu) << 16};
     if (KIND == CE_KIND_CLEANUP) {
       const u32x2 mid = {((kw_a >> 8) & 0xffu) | (kw_a & 0xffu) << 16, napples | nwaste << 16};
-      u32 cw[4] = {0, 0, 0, 0};  // the cleaned vector, two agents per dword (wave-uniform)
-      if (n == 8) {
+      u32 cw[4] = {0, 0, 0, 0};  // the cleaned vector, two agents per dword (wave-uniform); all zero on most steps
+      if (n == 8 && ballot(cleaned != 0) != 0) {
 #pragma unroll
         for (u32 b = 0; b < 8; b += 2) cw[b >> 1] = rdl(cleaned, b) | rdl(cleaned, b + 1) << 16;
       }
