@@ -478,3 +478,75 @@ def test_beam_trace_random_vs_oracle(kind, n, firing, horizon):
     assert np.array_equal(env.download("beam_map"), last)  # not written (and not cleared) while the trace is off
     env.check_faults()
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 4, 8])
+def test_selfdrive_reset_windows_across_generation_ends(n):
+    """Resets whose stream windows straddle the end of an MT19937 generation, every split: env b starts with the CPython
+    stream at position 624 - (b mod (2n + 2)) (a reset draws 2n words: 0 .. 2n + 1 of them from the old generation) and the
+    numpy stream at 624 - (b // (2n + 2) mod 6) (theta draws 2 or 4 words depending on u0 > null_prob: the regeneration must
+    happen exactly when a consumed word lies past the end).  Explicit ce_reset, then in-launch auto-resets, per-step and
+    fused, against the oracle's word-by-word genrand."""
+    import torch
+    from oracle.pyoracle import Oracle
+    E = 12 * (2 * n + 2) * 2
+    kw = dict(contract="selfdrive_distprop", auto_reset=True, null_prob=0.5)
+    env, orc = _engine("selfdrive", E, n, **kw), Oracle("selfdrive", E, n, **kw)
+    seeds = np.arange(E, dtype=np.uint64) * 31 + 7
+    for o in (env, orc):
+        o.seed(seeds)
+        o.reset()  # generations now filled; positions are overwritten below
+    b = np.arange(E)
+    rng = env.download("rng").copy()
+    assert np.array_equal(rng[:, :625], orc.rng[:, :625]) and np.array_equal(rng[:, 628:1253], orc.rng[:, 628:1253])
+    rng[:, 628 + 624] = 624 - (b % (2 * n + 2))
+    rng[:, 624] = 624 - ((b // (2 * n + 2)) % 6)
+    env.upload("rng", rng)
+    orc.rng[...] = rng
+    orc.import_state()
+    keep = np.r_[0:625, 628:1253]
+
+    def same(tag):
+        for f in ("obs_f64", "reward", "sd_state", "theta", "sd_info"):
+            np.testing.assert_allclose(env.download(f), getattr(orc, f), rtol=0, atol=1e-9, equal_nan=True, err_msg="%s %s" % (f, tag))
+        assert np.array_equal(env.download("rng")[:, keep], orc.rng[:, keep]), "streams " + tag
+        assert np.array_equal(env.download("done"), orc.done), tag
+
+    for o in (env, orc):
+        o.reset()  # explicit reset: every split of both windows at once
+    same("after explicit reset")
+    # in-launch auto-resets: park the positions near the end again and step until every env has reset at least once
+    rng = env.download("rng").copy()
+    rng[:, 628 + 624] = 624 - ((b + 3) % (2 * n + 2))
+    rng[:, 624] = 624 - ((b // (2 * n + 2) + 1) % 6)
+    env.upload("rng", rng)
+    orc.rng[...] = rng
+    orc.import_state()
+    rs = np.random.RandomState(n)
+    resets = np.zeros(E, bool)
+    for t in range(160):
+        a = rs.uniform(0.05, 0.1, size=(E, n)).astype(np.float32)  # everybody accelerates: episodes end quickly
+        env.step(a)
+        orc.step(a)
+        resets |= orc.done.astype(bool)
+        if t % 20 == 19:
+            same("step %d" % t)
+    assert resets.all()
+    same("after per-step auto-resets")
+    # the fused kernel over the same situation
+    rng = env.download("rng").copy()
+    rng[:, 628 + 624] = 624 - ((b + 1) % (2 * n + 2))
+    rng[:, 624] = 624 - ((b // (2 * n + 2) + 2) % 6)
+    env.upload("rng", rng)
+    orc.rng[...] = rng
+    orc.import_state()
+    acts = torch.from_numpy(rs.uniform(0.05, 0.1, size=(150, E, n)).astype(np.float32)).cuda()
+    env.rollout_fused(acts.data_ptr(), 150, 37)
+    env.synchronize()
+    a_host = acts.cpu().numpy()
+    for t in range(150):
+        orc.step(a_host[t])
+    same("after fused auto-resets")
+    env.close()
+    orc.close()
