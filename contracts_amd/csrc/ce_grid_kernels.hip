@@ -343,41 +343,45 @@ template <int MODE> DEVINL u32 shuffle_le8(Rng& r, u32& l0, u32 len, u32 lane) {
   const u32 w = r.cache;
   const u32 v7 = w & 7u, v3 = w & 3u, v1 = w & 1u;
   // indices 7, 3 and 1 equal their mask: every word is accepted (the next unread one); only 6, 5, 4 and 2 can reject
-  const u64 B7 = ~0ull, B6 = ballot(v7 <= 6u), B5 = ballot(v7 <= 5u), B4 = ballot(v7 <= 4u);
-  const u64 B3 = ~0ull, B2 = ballot(v3 <= 2u), B1 = ~0ull;
+  const u64 B6 = ballot(v7 <= 6u), B5 = ballot(v7 <= 5u), B4 = ballot(v7 <= 4u), B2 = ballot(v3 <= 2u);
+  // Straight-line walk: every step is and / find-first / shift / and on 64-bit scalars, no branch inside — running out of
+  // cached words only sets a flag (the find-first then lands on a planted top bit), and the rare failure is redone by the
+  // caller's serial walk from the untouched stream position.  (The earlier form returned from inside each step: the
+  // compiler turned the chain into a state machine of ~20 scalar instructions per step.)
   u64 avail = r.cvalid & (~0ull << off);
-  u32 i = len - 1;
-  u32 next = r.cbase + off;  // stream position after the last consumed word
-#define CE_LE8_STEP(I, B, V)                                    \
-  if (i == (I)) {                                               \
-    const u64 hit = (B) & avail;                                \
-    if (hit == 0) {                                             \
-      r.pos = next;                                             \
-      return (I);                                               \
-    }                                                           \
-    const u32 k = ctz64(hit);                                   \
-    avail &= (~1ull) << k;                                      \
-    next = r.cbase + k + 1;                                     \
-    if (MODE == 1) {                                            \
-      l0 = wrl(rdl((V), k), (I), l0);                           \
-    } else if (MODE == 0) {                                     \
-      const u32 j = rdl((V), k);                                \
-      const u32 vi = rdl(l0, (I)), vj = rdl(l0, j);             \
-      l0 = wrl(vj, (I), l0);                                    \
-      l0 = wrl(vi, j, l0);                                      \
-    }                                                           \
-    i = (I) - 1;                                                \
+  u32 klast = off - 1u;  // no step taken: the position stays
+  bool ok = true;
+  const u32 l0_in = l0;
+#define CE_LE8_STEP(I, A, V)                                     \
+  if (len > (I)) {                                               \
+    const u64 hit = (A) & avail;                                 \
+    ok = ok && hit != 0;                                         \
+    const u32 k = ctz64(hit | (1ull << 63));                     \
+    avail &= (~1ull) << k;                                       \
+    klast = k;                                                   \
+    if (MODE == 1) {                                             \
+      l0 = wrl(rdl((V), k), (I), l0);                            \
+    } else if (MODE == 0) {                                      \
+      const u32 j = rdl((V), k);                                 \
+      const u32 vi = rdl(l0, (I)), vj = rdl(l0, j);              \
+      l0 = wrl(vj, (I), l0);                                     \
+      l0 = wrl(vi, j, l0);                                       \
+    }                                                            \
   }
-  CE_LE8_STEP(7, B7, v7)
+  CE_LE8_STEP(7, ~0ull, v7)
   CE_LE8_STEP(6, B6, v7)
   CE_LE8_STEP(5, B5, v7)
   CE_LE8_STEP(4, B4, v7)
-  CE_LE8_STEP(3, B3, v3)
+  CE_LE8_STEP(3, ~0ull, v3)
   CE_LE8_STEP(2, B2, v3)
-  CE_LE8_STEP(1, B1, v1)
+  CE_LE8_STEP(1, ~0ull, v1)
 #undef CE_LE8_STEP
-  r.pos = next;
-  return 0;
+  if (ok) {
+    r.pos = r.cbase + klast + 1u;
+    return 0;
+  }
+  l0 = l0_in;  // ran out of cached words (needs > 24 rejections in a row-ish: practically never): nothing was consumed
+  return len - 1;
 }
 
 template <int MODE> DEVINL void shuffle_small(Rng& r, u32& L0, u32 len, u32 lane) {
