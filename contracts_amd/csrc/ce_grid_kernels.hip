@@ -2288,7 +2288,7 @@ template <int GK> struct alignas(16) FeatLds {
     u32 mt_np[kMtN];  // the space of the per-step working set
     struct {
       u32 U[256];                     // tempered words of up to 128 respawn doubles (one bulk pass; harvest may take two)
-      uint8_t pmap[Geo<GK>::PCELLS];  // padded map: walls + apples / wastes currently present
+      uint8_t pmap[Geo<GK>::PQUADS * 16];  // padded map (PCELLS bytes used): walls + apples / wastes currently present
     } w;
   };
 };
@@ -2339,15 +2339,14 @@ DEVINL void rng_skip(Rng& r, u32 k, u32 lane) {
 }
 
 template <int GK> DEVINL void feat_base_map(FEnv<GK>& E) {
-  const u32* bsrc = (const u32*)c_tab[GK].base_pmap;
-  u32* pm32 = (u32*)E.L->w.pmap;
-  constexpr int ROUNDS = (Geo<GK>::PCELLS / 4 + 63) / 64;
-  constexpr u32 kLast = (u32)Geo<GK>::PCELLS / 4 - 1;
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {  // unconditional: idle lanes of the last round repeat the last word
-    const u32 k = min(E.lane + 64u * r, kLast);
-    pm32[k] = bsrc[k];
-  }
+  // two rounds of 16-byte copies (the LDS map is padded to whole quads); idle lanes of the second repeat the last quad
+  const uint4* bsrc = (const uint4*)c_tab[GK].base_pmap;
+  uint4* pm128 = (uint4*)E.L->w.pmap;
+  static_assert(Geo<GK>::PQUADS > 64 && Geo<GK>::PQUADS <= 128, "two quad rounds");
+  const u32 q1 = min(E.lane + 64u, (u32)Geo<GK>::PQUADS - 1u);
+  const uint4 w0 = bsrc[E.lane], w1 = bsrc[q1];
+  pm128[E.lane] = w0;
+  pm128[q1] = w1;
 }
 // The np.random draws of a reset — n orientations (one masked word each), then the wrapper's theta — taken in one go
 // on the stream loaded into the borrowed LDS block and written straight back: the two generators are independent,
@@ -2428,10 +2427,13 @@ template <int GK, bool LIGHT = false> DEVINL void feat_load(FEnv<GK>& E, const G
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const u32 idx = lane + 64 * r;
-    const u32 wv = T.waste[G::NWASTE ? min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0)) : 0u];
-    E.WC[r] = idx < (u32)G::NWASTE ? wv : 0;
+    E.WC[r] = 0;
     E.WS[r] = kAbsent;
+    if (G::NWASTE) {  // (HarvestFeatures has no waste cells: nothing to fetch)
+      const u32 idx = lane + 64 * r;
+      const u32 wv = T.waste[min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0))];
+      E.WC[r] = idx < (u32)G::NWASTE ? wv : 0;
+    }
   }
   E.next_a = E.next_w = 0;
   E.P = 0xffffu;
@@ -2443,10 +2445,12 @@ template <int GK, bool LIGHT = false> DEVINL void feat_load(FEnv<GK>& E, const G
       const u32 v = st[min(lane + 64u * r, (u32)CE_FEAT_APPLE_SLOTS - 1u)];
       if (lane + 64 * r < (u32)G::NAPPLE) E.AS[r] = v;
     }
+    if (G::NWASTE) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const u32 v = st[CE_FEAT_APPLE_SLOTS + min(lane + 64u * r, (u32)CE_FEAT_WASTE_SLOTS - 1u)];
-      if (lane + 64 * r < (u32)G::NWASTE) E.WS[r] = v;
+      for (int r = 0; r < 2; ++r) {
+        const u32 v = st[CE_FEAT_APPLE_SLOTS + min(lane + 64u * r, (u32)CE_FEAT_WASTE_SLOTS - 1u)];
+        if (lane + 64 * r < (u32)G::NWASTE) E.WS[r] = v;
+      }
     }
     const auto cnt = (CE_GPTR(const u32))(p.grid + (size_t)E.e * CE_FEAT_STATE_BYTES + 2 * (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS));
     E.next_a = rfl(cnt[0]);
@@ -2466,9 +2470,11 @@ template <int GK> DEVINL void feat_paint(FEnv<GK>& E) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
     pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), E.AS[r] != kAbsent ? CE_CELL_APPLE : CE_CELL_EMPTY);
+  if (G::NWASTE) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-    pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WC[r]), E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER);
+    for (int r = 0; r < 2; ++r)
+      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WC[r]), E.WS[r] != kAbsent ? CE_CELL_WASTE : CE_CELL_RIVER);
+  }
   wave_sync();
 }
 // waste_block: also write the waste stamps (HarvestFeatures has none: only its construct / reset launches initialise them)
