@@ -548,16 +548,23 @@ def run_rank(a):
             rr.close()
         if out is not None:
             out["configs"] = rows
+    def extra(fn, *args, **kw):
+        """the sections beside the headline must never take the line down with them: a failure is reported in place"""
+        try:
+            return fn(*args, **kw)
+        except Exception as exc:  # noqa: BLE001 (reported, not swallowed)
+            return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
     if out is not None and world == 1 and not custom:
         if not a.no_closed_loop:
-            out["closed_loop"] = closed_loop(WORKLOADS["C4"], E, local_rank, a.streams)
+            out["closed_loop"] = extra(closed_loop, WORKLOADS["C4"], E, local_rank, a.streams)
         if not a.no_boundary:
-            out["boundary"] = boundary(WORKLOADS["C4"], E, local_rank)
+            out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+            out["cpu_baseline"] = extra(cpu_baseline, wl, a.cpu_seconds)
             for row in out.get("configs", []):  # BASELINE.md: the CPU path beside every GPU config, same E rule / seeds / actions
-                row["cpu_baseline"] = cpu_baseline(WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
+                row["cpu_baseline"] = extra(cpu_baseline, WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
         print(json.dumps(out), flush=True)
     group.close()
 

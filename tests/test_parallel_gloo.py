@@ -87,3 +87,9 @@ def test_launcher_deadline_is_for_the_whole_job(tmp_path):
     t0 = time.monotonic()
     rc = parallel.spawn_local_ranks(str(script), [], 3, timeout=2.0)
     assert rc == 124 and time.monotonic() - t0 < 15
+
+
+def test_eight_rank_shard_equals_single_rank(tmp_path):
+    """the 8-GPU layout of BASELINE config 3 in miniature: eight ranks over gloo, three envs each, against one rank
+    stepping all twenty-four (global-index seeds and actions: the digests must line up env for env)"""
+    _run(tmp_path, 8, 3)
