@@ -1740,6 +1740,9 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 // agent-steps/s, tools/ab.sh, two rounds interleaved — which in round 1 was itself 3 % faster than 5 waves without spills
 #define CE_CLEANUP_ROLLOUT_WAVES 8
 #endif
+#ifndef CE_CLEANUP_ROLLOUT_WAVES_SMALL
+#define CE_CLEANUP_ROLLOUT_WAVES_SMALL 7  // launches that do not fill the machine: see k_grid_rollout
+#endif
 constexpr int kWavesPerBlock = 1;
 
 template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, WaveLds<KIND>* lds, u32 env_first, u32 env_end) {
@@ -2217,7 +2220,11 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 #ifndef CE_HARVEST_ROLLOUT_WAVES
 #define CE_HARVEST_ROLLOUT_WAVES 6  // 76 VGPRs, no scratch (64 with 8 spilled registers in the loop: 2 % slower)
 #endif
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_ROLLOUT_WAVES : CE_HARVEST_ROLLOUT_WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+// WAVES = the occupancy the register budget is cut for.  The cleanup rollout exists twice: 8 waves / SIMD (64 VGPRs + 21 spilled)
+// for launches that oversubscribe the machine — occupancy is what hides a wave's dependent chain there: +3 % on the headline —
+// and 7 waves (72 + 13 spilled) for small launches, where every wave is resident anyway and the extra spills only cost
+// (cleanup n = 4 x 4 096 envs: 1.41 vs 1.37 G).  launch_grid_rollout picks by the size of the launch.
+template <int KIND, int WAVES> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
@@ -3515,8 +3522,16 @@ void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void*
 void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_rollout<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
-  else hipLaunchKernelGGL(k_grid_rollout<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+  // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues
+  constexpr u32 kSmallLaunch = 2730;
+  if (kind == CE_KIND_CLEANUP) {
+    if (count <= kSmallLaunch)
+      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+    else
+      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+  } else {
+    hipLaunchKernelGGL((k_grid_rollout<CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+  }
 }
 
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
