@@ -3217,7 +3217,10 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
 // Fused multi-step rollout of the feature-vector envs (ce_rollout_fused): list stamps, agents and the CPython `random`
 // stream stay on chip for the steps of a launch (the np.random stream is only touched by resets, straight in HBM)
 #ifndef CE_FEAT_ROLLOUT_WAVES
-#define CE_FEAT_ROLLOUT_WAVES 5  // 90-94 VGPRs, no scratch (see CE_CLEANUP_WAVES)
+// round 3, tools/ab.sh, two rounds interleaved (HarvestFeatures / CleanupFeatures n = 2 x 16 384 envs, G agent-steps/s):
+// 5 waves (96 VGPRs, no scratch) 1.99 / 1.81, 6 waves 2.14 / 1.95, 7 waves (72 VGPRs + 12 / 20 spilled) 2.28 / 2.04, 8 waves 2.24 / 2.01.
+// (Round 2 saw a spilling build of this kernel run at two speeds from process to process and chose 5; not reproduced since.)
+#define CE_FEAT_ROLLOUT_WAVES 7
 #endif
 template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
