@@ -2218,7 +2218,8 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 }
 
 #ifndef CE_HARVEST_ROLLOUT_WAVES
-#define CE_HARVEST_ROLLOUT_WAVES 6  // 76 VGPRs, no scratch (64 with 8 spilled registers in the loop: 2 % slower)
+// round 3 (tools/ab.sh, harvest n = 8 x 16 384 envs): 6 waves (80 VGPRs + 2 spilled) 5.21 G, 7 waves (72 + 3) 5.46 G, 8 waves (64 + 7) 5.38 G
+#define CE_HARVEST_ROLLOUT_WAVES 7
 #endif
 // WAVES = the occupancy the register budget is cut for.  The cleanup rollout exists twice: 8 waves / SIMD (64 VGPRs + 21 spilled)
 // for launches that oversubscribe the machine — occupancy is what hides a wave's dependent chain there: +3 % on the headline —
