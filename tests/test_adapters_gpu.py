@@ -719,3 +719,55 @@ def test_run_rendering_writes_episode_videos(tmp_path):
         im = Image.open(paths[0])
         assert im.n_frames == 12 and im.size == (18 * 20, 25 * 20)
     env.close()
+
+
+def test_versioned_state_rejects_other_layouts(tmp_path):
+    """checkpoints and pickled adapters carry the engine ABI version and every parameter that enters a step: a blob from
+    another layout / another configuration is refused with a clear message instead of an opaque size error or a silently
+    different continuation"""
+    from contracts_amd import _lib
+    from contracts_amd.engine import BatchedEnv
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    a = BatchedEnv("cleanup", 4, 3, contract="cleanup", horizon=30)
+    a.seed(seed0=1)
+    a.reset()
+    st = a.state_dict()
+    assert int(st["_meta"][6]) == _lib.CE_ABI_VERSION and "_meta_f64" in st
+    b = BatchedEnv("cleanup", 4, 3, contract="cleanup", horizon=30)
+    b.load_state_dict(st)  # same configuration: fine
+    old = dict(st)
+    old["_meta"] = st["_meta"][:6]  # what round 2 wrote
+    del old["_meta_f64"]
+    with pytest.raises(ValueError, match="predates the versioned format"):
+        b.load_state_dict(old)
+    other_abi = dict(st)
+    other_abi["_meta"] = st["_meta"].copy()
+    other_abi["_meta"][6] += 1
+    with pytest.raises(ValueError, match="ABI v"):
+        b.load_state_dict(other_abi)
+    c = BatchedEnv("cleanup", 4, 3, contract="cleanup", horizon=30, contract_high=0.1)
+    with pytest.raises(ValueError, match="contract_high"):
+        c.load_state_dict(st)
+    d = BatchedEnv("cleanup", 4, 3, contract="cleanup", horizon=30, null_prob=0.25)
+    with pytest.raises(ValueError, match="null_prob"):
+        d.load_state_dict(st)
+    for e in (a, b, c, d):
+        e.close()
+    # a cached download is read-only: mutating it must raise, not corrupt later downloads
+    a = BatchedEnv("cleanup", 2, 2)
+    a.seed(seed0=3)
+    a.reset()
+    a.prefetch(("agents", "timestep"))
+    with pytest.raises(ValueError):
+        a.download("agents")[0, 0, 0] = 9
+    a.close()
+    # pickled adapter blobs
+    np.random.seed(2)
+    env = CleanupEnv(num_agents=2)
+    env.reset()
+    clone = pickle.loads(pickle.dumps(env))
+    assert clone._pending_abi == _lib.CE_ABI_VERSION
+    clone._pending_abi = _lib.CE_ABI_VERSION + 1
+    with pytest.raises(ValueError, match="re-create the env"):
+        clone.step({"a0": 4, "a1": 4})
+    env.close()

@@ -412,3 +412,35 @@ def test_to_base_env_fallbacks_keep_object_per_env_semantics():
         feat.to_base_env(num_envs=2)
     three.stop()
     one.stop()
+
+
+@pytest.mark.gpu
+def test_try_reset_batching_is_optional_and_metrics_follow_the_tick():
+    """(a) with batch_done_resets=False try_reset(e) resets exactly env e — a done env the caller leaves alone
+    stays done; with the default the first try_reset after a tick resets every done env in one launch; (b) env_metrics()
+    serves the finished episode's rows from the poll that reported the done until the next send_actions, the running
+    episode's afterwards"""
+    from contracts_amd.vector_env import BatchedBaseEnv
+    E, n, H = 4, 2, 6
+    keys = ["a0", "a1"]
+    for batching in (False, True):
+        venv = BatchedBaseEnv("harvest", E, n, seed0=11, horizon=H, batch_done_resets=batching)
+        venv.poll()
+        for t in range(H):
+            venv.send_actions({e: {k: 4 for k in keys} for e in range(E)})
+            obs, rew, dones, infos, _ = venv.poll()
+        assert all(dones[e]["__all__"] for e in range(E))
+        m_done = venv.env_metrics(2)
+        assert "equality" in m_done  # the finished episode's rows
+        venv.try_reset(1)
+        ts = venv.engine.download("timestep")
+        assert ts[1] == 0
+        assert (ts[[0, 2, 3]] == 0).all() if batching else (ts[[0, 2, 3]] == H).all()
+        assert "equality" in venv.env_metrics(2)  # a reset in between does not clear them
+        for e in (0, 2, 3):
+            venv.try_reset(e)
+        venv.send_actions({e: {k: 4 for k in keys} for e in range(E)})
+        assert "equality" not in venv.env_metrics(2)  # stepped again: the running episode (before the next poll, too)
+        venv.poll()
+        assert "equality" not in venv.env_metrics(2)
+        venv.stop()
