@@ -247,3 +247,102 @@ def test_agent_view_mirrors_the_reference_agent_fields():
     assert a.get_char_id() == b"8" and a.get_pos() is a.pos and a.get_orientation() == "DOWN"
     assert a.row_size == a.col_size == 7
     assert list(a.translate_pos_to_egocentric_coord([4, 9])) == [8, 5]
+
+
+def test_to_base_env_maps_the_env_configuration(monkeypatch):
+    """host logic of the RLlib hook, no GPU: `to_base_env(num_envs=E)` builds ONE BatchedBaseEnv whose
+    engine configuration is the env's own — kind, agents, horizon, firing, reward flags, contract id and float32 bounds,
+    null_prob, seed — and falls back to object-per-sub-env semantics where the batched hook does not apply.  The engine
+    is replaced by a recorder (the product path itself has no CPU engine: tests/test_cabi.py::test_no_gpu_fails_loudly)."""
+    import contracts_amd.engine as engine_mod
+    import contracts_amd.vector_env as vector_env
+    from contracts_amd import _lib
+
+    made = []
+
+    class RecordingEngine:
+        def __init__(self, kind, num_envs, num_agents, **kw):
+            self.kind, self.E, self.n, self.kw = kind, num_envs, num_agents, kw
+            self.cfg = engine_mod.make_config(kind, num_envs, num_agents, **kw)
+            self.firing = bool(kw.get("firing", False))
+            self.num_actions = engine_mod.NUM_ACTIONS.get((kind, self.firing))
+            self.seeded = None
+            made.append(self)
+
+        def seed(self, seeds=None, seed0=0, **k):
+            self.seeded = seed0
+
+        def construct(self, *a, **k):
+            pass
+
+        def reset(self, *a, **k):
+            pass
+
+        def set_contract(self, *a):
+            self.contract_set = a
+
+        def set_flags(self, **k):
+            pass
+
+        def upload(self, *a, **k):
+            pass
+
+        def download(self, field, *a, **k):
+            return np.zeros((1, 628 * 2), np.uint32) if field == "rng" else np.zeros((1, 8), np.float64)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(vector_env, "BatchedEnv", RecordingEngine)
+    import contracts_amd.environments.map_env as map_env
+    import contracts_amd.environments.feature_envs as feature_envs
+    import contracts_amd.environments.self_driving_car_accelerate as sdc
+    for mod in (map_env, feature_envs, sdc):
+        monkeypatch.setattr(mod, "BatchedEnv", RecordingEngine)
+    from contracts_amd.contract.contract_list import CleanupContract, SelfdriveContractDistprop
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    from contracts_amd.environments.two_stage_train import SeparateContractSubgameStage
+    from contracts_amd.environments.vector_hook import SubEnvBaseEnv
+
+    base = CleanupEnv(num_agents=4, horizon=77, disable_firing=False, inequity_averse_reward=True, alpha=5.0, beta=0.05,
+                      rng="private")
+    env = SeparateContractSubgameStage(base, CleanupContract(4), 4, True, null_prob=0.25)
+    base.seed(9001)
+    made.clear()
+    venv = env.to_base_env(make_env=None, num_envs=64, remote_envs=False)
+    assert isinstance(venv, vector_env.BatchedBaseEnv) and len(made) == 1
+    eng = made[0]
+    assert (eng.kind, eng.E, eng.n, eng.seeded) == ("cleanup", 64, 4, 9001)
+    c = eng.cfg
+    assert c.horizon == 77 and c.contract == _lib.CONTRACT["cleanup"] and c.null_prob == 0.25
+    assert c.contract_low == 0.0 and c.contract_high == float(np.float32(0.2))  # the Box's float32 bound
+    assert c.flags & _lib.FLAG_FIRING and c.flags & _lib.FLAG_INEQUITY and not c.flags & _lib.FLAG_AUTO_RESET
+    assert (c.alpha, c.beta) == (5.0, 0.05) and venv.contract == "cleanup" and venv.convolutional is True
+
+    plain = HarvestEnv(num_agents=3, horizon=50, rng="private")
+    made.clear()
+    v2 = plain.to_base_env(num_envs=8)
+    assert isinstance(v2, vector_env.BatchedBaseEnv) and made[0].kind == "harvest" and made[0].cfg.contract == 0
+    assert not made[0].cfg.flags & _lib.FLAG_FIRING and made[0].cfg.horizon == 50
+
+    car = SeparateContractSubgameStage(sdc.SelfAcceleratingCarEnv(num_agents=4, collision_on=True, rng="private"),
+                                       SelfdriveContractDistprop(4), 4, False)
+    made.clear()
+    v3 = car.to_base_env(num_envs=16)
+    assert made[0].kind == "selfdrive" and made[0].cfg.flags & _lib.FLAG_COLLISION and made[0].cfg.contract_high == 100.0
+    assert v3.convolutional is False
+
+    # fallbacks: one sub-env, remote sub-envs, feature-vector grid envs -> the adapters themselves, one object per sub-env
+    assert isinstance(plain.to_base_env(num_envs=1), SubEnvBaseEnv)
+    built = []
+
+    def make_env(i):
+        built.append(i)
+        return HarvestEnv(num_agents=3, horizon=50, rng="private")
+
+    remote = plain.to_base_env(make_env=make_env, num_envs=3, remote_envs=True)
+    assert isinstance(remote, SubEnvBaseEnv) and remote.num_envs == 3 and built == [1, 2]
+    feat = CleanupEnv(num_agents=2, image_obs=False, rng="private")
+    with pytest.raises(ValueError):
+        feat.to_base_env(num_envs=2)  # needs make_env to build the other sub-env
