@@ -277,7 +277,11 @@ int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* strea
 /* ce_step restricted to the env slice [env_begin, env_begin + env_count).  `actions` / `active` still
  * point at the FULL [E][n] planes (the slice indexes into them).  Slices are independent: stepping
  * disjoint slices on different HIP streams lets one slice's tail overlap another's head (and, in an RL
- * loop, one slice's policy inference overlap the other slice's env step — double-buffered sampling). */
+ * loop, one slice's policy inference overlap the other slice's env step — double-buffered sampling).
+ * ce_step / ce_step_range are one plain kernel launch on the caller's stream (no host synchronisation, no allocation), so a
+ * caller may capture them into a hipGraph together with its own kernels (bench.py's closed loop does: one graph per slice).
+ * Capture only on a stream that has already issued a step since the last ce_reset: the first step after a reset on another
+ * stream inserts a one-time hipStreamWaitEvent (see ce_reset), which does not belong in a capture. */
 int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count,
                   void* stream);
 
