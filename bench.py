@@ -315,10 +315,10 @@ class Runner:
 def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     """The RL-usable rate: one host iteration per env-step.  The batch is `num_slices` independent env slices, each with
     its own HIP stream; per slice and step, torch computes the actions ON THE DEVICE from the observation the previous
-    step of that slice wrote (the pixel in front of every agent, mixed with a resident noise plane so the action
-    distribution stays the benchmark's uniform one: three elementwise torch kernels), then ce_step_range steps the slice
+    step of that slice wrote (the pixel in front of every agent, accumulated into a resident noise plane so the action
+    distribution stays the benchmark's uniform one: two elementwise torch kernels), then ce_step_range steps the slice
     from that device pointer.  No joins between slices: one slice's policy and kernel tail overlap another's step.
-    Ways to issue a slice's tick: `eager` (four launches from Python), `graph` (the same four launches captured once per
+    Ways to issue a slice's tick: `eager` (three launches from Python), `graph` (the same three launches captured once per
     slice into a hipGraph and replayed: one host call per slice and step) — `value` is the faster of these two, both
     with one host iteration per env-step — and `graph16` (16 consecutive ticks per replay: the loop observation -> policy
     -> step still closes on the device every step, the host only comes by every 16 steps; reported beside, not as
@@ -334,7 +334,6 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     ahead = obs[:, :, 6, 7, 1]        # green channel of the cell in front of the agent: [E, n], stride-only view
     g = torch.Generator(device="cuda").manual_seed(1)
     noise = torch.randint(0, 256, (E, n), dtype=torch.uint8, device="cuda", generator=g)
-    tmp = torch.empty((E, n), dtype=torch.uint8, device="cuda")
     acts = torch.zeros((E, n), dtype=torch.uint8, device="cuda")
     S = max(1, num_slices)
     streams = [torch.cuda.Stream() for _ in range(S)]
@@ -345,12 +344,12 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     torch.cuda.synchronize()
 
     def slice_tick(st, b0, b1):  # every pointer is fixed, so the same calls can be captured into a graph
-        torch.add(ahead[b0:b1], noise[b0:b1], out=tmp[b0:b1])  # uint8 wrap-around: uniform whatever the pixel
-        noise[b0:b1].add_(37)                                   # the plane moves on every step (a bijection mod 256)
+        # noise <- noise + pixel (uint8 wrap-around): stays uniform whatever the pixels were, and moves on every step
+        torch.add(ahead[b0:b1], noise[b0:b1], out=noise[b0:b1])
         if A == 8:
-            torch.bitwise_and(tmp[b0:b1], 7, out=acts[b0:b1])
+            torch.bitwise_and(noise[b0:b1], 7, out=acts[b0:b1])
         else:
-            torch.remainder(tmp[b0:b1], A, out=acts[b0:b1])
+            torch.remainder(noise[b0:b1], A, out=acts[b0:b1])
         env.step_range_device(acts.data_ptr(), b0, b1 - b0, stream=st.cuda_stream)
 
     def eager_tick():
@@ -375,7 +374,7 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
         return {"value": E * n * K / med, "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
                 "timed_seconds": sum(elapsed)}
 
-    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=4 * S, host_iterations_per_step=1)}
+    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=3 * S, host_iterations_per_step=1)}
     for name, ticks in (("graph", 1), ("graph16", 16)):
         try:  # one hipGraph per slice, replayed on the slice's stream
             graphs = []
@@ -399,7 +398,7 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     best = max((m for m in ("eager", "graph") if "value" in modes[m]), key=lambda m: modes[m]["value"])
     out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
                policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
-                      "byte) mod %d — three elementwise kernels per slice and step" % A,
+                      "byte, accumulated) mod %d — two elementwise kernels per slice and step" % A,
                workload=wl["name"])
     env.close()
     return out
