@@ -168,7 +168,7 @@ void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
-void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream);
+void launch_grid_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
 void launch_sd_construct(const SdParams& p, void* stream);
 void launch_sd_reset(const SdParams& p, void* stream);
 void launch_sd_step(const SdParams& p, void* stream);

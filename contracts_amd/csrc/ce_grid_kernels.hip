@@ -2157,7 +2157,11 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 // starts with its addresses in registers instead of two dependent scalar-load round trips (the kernarg segment, then the
 // head of the parameter block), ~300 cycles each under load.  The parameter block `pp` is still read for everything that
 // is not on the way to the first load (output pointers, flags, contract bounds).
-template <int KIND>
+// NFIX: the number of agents as a compile-time constant (0 = the runtime argument).  The step logic is written for any
+// n <= 9, with wave-uniform branches on n in every phase (pair tests, group sizes of the feature scan, loop bounds); the
+// instance for the headline's n = 8 lets the compiler fold them all (everything is inlined into the kernel, so a literal
+// E.n propagates through every phase).
+template <int KIND, int NFIX>
 __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(
     const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
     uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
@@ -2177,7 +2181,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
 #else
   ph.debug = nullptr;
 #endif
-  ph.n = num_agents;
+  ph.n = NFIX ? (u32)NFIX : num_agents;
   const auto acts = (CE_GPTR(const uint8_t))call_actions;
   env_begin(E, ph, lds, env_first, 0xffffffffu);
   const u32 lane = E.lane, n = E.n;
@@ -2225,13 +2229,18 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 // for launches that oversubscribe the machine — occupancy is what hides a wave's dependent chain there: +3 % on the headline —
 // and 7 waves (72 + 13 spilled) for small launches, where every wave is resident anyway and the extra spills only cost
 // (cleanup n = 4 x 4 096 envs: 1.41 vs 1.37 G).  launch_grid_rollout picks by the size of the launch.
-template <int KIND, int WAVES> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+// NFIX as for k_grid_step: the instance for n = 8 folds every branch on the number of agents (and frees the register n lives in).
+template <int KIND, int WAVES, int NFIX> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, *pp, lds, rap->env_first, rap->env_end)) return;
+  if (NFIX) {
+    E.n = (u32)NFIX;
+    E.is_agent = E.lane < E.n;
+  }
   u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))rap->actions + (size_t)E.e * E.n, E.lane) : 4u;
   load_env_state(E, *pp);
   u32 t = rfl((u32)pp->timestep[E.e]);
@@ -2247,7 +2256,7 @@ template <int KIND, int WAVES> __global__ __launch_bounds__(64 * kWavesPerBlock,
     // per step and cost 40 spilled registers: 2.4 G instead of 3.3 G).  The static cell tables (AP / WS) do stay
     // resident: re-fetching them per step cost 4 %
     asm volatile("" : "+v"(E.lane));
-    E.n = opaque_u32(E.n);
+    E.n = NFIX ? (u32)NFIX : opaque_u32(E.n);
     E.e = opaque_u32(E.e);
     E.is_agent = E.lane < E.n;
     const u32 lane = E.lane;
@@ -3515,27 +3524,36 @@ void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void*
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
   // the state pointers travel as kernel arguments (preloaded into SGPRs at wave launch), see k_grid_step
-  if (kind == CE_KIND_CLEANUP)
-    hipLaunchKernelGGL(k_grid_step<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
-                       (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
-  else
-    hipLaunchKernelGGL(k_grid_step<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
-                       (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+#define CE_STEP_LAUNCH(K_, N_)                                                                                          \
+  hipLaunchKernelGGL((k_grid_step<K_, N_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+                     (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
+  if (kind == CE_KIND_CLEANUP) {
+    if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 8);
+    else CE_STEP_LAUNCH(CE_KIND_CLEANUP, 0);
+  } else {
+    if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_HARVEST, 8);
+    else CE_STEP_LAUNCH(CE_KIND_HARVEST, 0);
+  }
+#undef CE_STEP_LAUNCH
 }
 
-void launch_grid_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+void launch_grid_rollout(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
   // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues
   constexpr u32 kSmallLaunch = 2730;
+#define CE_ROLLOUT_LAUNCH(K_, W_, N_) \
+  hipLaunchKernelGGL((k_grid_rollout<K_, W_, N_>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra)
   if (kind == CE_KIND_CLEANUP) {
-    if (count <= kSmallLaunch)
-      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
-    else
-      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+    // (the n = 8 instance of the cleanup rollout measured the same as the generic one — 4.35 G both, 35 spilled registers
+    // instead of 24 — so only the generic one is built; harvest's gains 8 %: 5.44 -> 5.89 G)
+    if (count <= kSmallLaunch) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 0);
+    else CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES, 0);
   } else {
-    hipLaunchKernelGGL((k_grid_rollout<CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+    if (num_agents == 8) CE_ROLLOUT_LAUNCH(CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES, 8);
+    else CE_ROLLOUT_LAUNCH(CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES, 0);
   }
+#undef CE_ROLLOUT_LAUNCH
 }
 
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
