@@ -662,7 +662,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       order_after_reset(h, stream);
       if (is_grid(h->cfg)) launch_grid_rollout((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);
-      else launch_feat_rollout((int)h->cfg.kind, h->d_gparams, ra, stream);
+      else launch_feat_rollout((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       if (h->timing_armed) h->timed_launches++;
     }
     plane = (uint32_t)(((uint64_t)plane + cnt) % ra.num_planes);

@@ -157,7 +157,7 @@ struct SdParams {
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
-void launch_feat_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream);
+void launch_feat_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
 int upload_grid_tables(int kind, const GridTables& t, const uint32_t* rgb16);
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, uint32_t env_first, uint32_t env_count, void* stream);
 void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, uint32_t* error_flags, uint32_t env_first, uint32_t env_count, void* stream);

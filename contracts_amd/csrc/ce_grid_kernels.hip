@@ -3206,12 +3206,17 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
   }
 }
 
-template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+// NFIX: the number of agents as a compile-time constant (0 = p.n), as for k_grid_step; the instance is for n = 2 (BASELINE config 0)
+template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
                                                                    const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ FeatLds<GK> lds;
   FEnv<GK> E;
   if (!feat_begin(E, p, &lds, env_first, env_end)) return;
+  if (NFIX) {
+    E.n = (u32)NFIX;
+    E.is_agent = E.lane < E.n;
+  }
   const u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + (size_t)E.e * E.n, E.lane) : 4u;
   if (ballot(E.is_agent && ACT > (GK == CE_KIND_HARVEST ? 7u : 8u)) != 0) {  // validated before anything is loaded or written
     if (E.lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
@@ -3232,12 +3237,16 @@ template <int GK> __global__ __launch_bounds__(64, 8) void k_feat_step(const Gri
 // (Round 2 saw a spilling build of this kernel run at two speeds from process to process and chose 5; not reproduced since.)
 #define CE_FEAT_ROLLOUT_WAVES 7
 #endif
-template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+template <int GK, int NFIX> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k_feat_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   __shared__ FeatLds<GK> lds;
   FEnv<GK> E;
   if (!feat_begin(E, *pp, &lds, rap->env_first, rap->env_end)) return;
+  if (NFIX) {
+    E.n = (u32)NFIX;
+    E.is_agent = E.lane < E.n;
+  }
   u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))rap->actions + (size_t)E.e * E.n, E.lane) : 4u;
   feat_load(E, *pp, true);
   u32 t = rfl((u32)pp->timestep[E.e]);
@@ -3249,7 +3258,7 @@ template <int GK> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAVES) void k
     const GridParams& p = opaque_block(pp);
     const RolloutArgs& ra = opaque_block(rap);
     asm volatile("" : "+v"(E.lane));
-    E.n = opaque_u32(E.n);
+    E.n = NFIX ? (u32)NFIX : opaque_u32(E.n);
     E.e = opaque_u32(E.e);
     E.is_agent = E.lane < E.n;
     const u32 sn = s + 1 < num_steps ? s + 1 : s;
@@ -3577,11 +3586,31 @@ void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error
   } while (0)
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_construct); }
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_reset); }
-void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_step); }
-void launch_feat_rollout(int kind, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) {
+  const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
+#define CE_FEAT_STEP_LAUNCH(K_, N_) \
+  hipLaunchKernelGGL((k_feat_step<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, p.actions, p.mask, first, first + count)
+  if (kind == CE_KIND_HARVEST_FEATURES) {
+    if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 2);
+    else CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 0);
+  } else {
+    if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_CLEANUP, 2);
+    else CE_FEAT_STEP_LAUNCH(CE_KIND_CLEANUP, 0);
+  }
+#undef CE_FEAT_STEP_LAUNCH
+}
+void launch_feat_rollout(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
-  if (kind == CE_KIND_HARVEST_FEATURES) hipLaunchKernelGGL(k_feat_rollout<CE_KIND_HARVEST>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra);
-  else hipLaunchKernelGGL(k_feat_rollout<CE_KIND_CLEANUP>, dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra);
+#define CE_FEAT_ROLLOUT_LAUNCH(K_, N_) \
+  hipLaunchKernelGGL((k_feat_rollout<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra)
+  if (kind == CE_KIND_HARVEST_FEATURES) {
+    if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 2);
+    else CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 0);
+  } else {
+    if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, 2);
+    else CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, 0);
+  }
+#undef CE_FEAT_ROLLOUT_LAUNCH
 }
 
 void launch_synth_actions_u8(uint8_t* out, u64 key, u64 env_base, u32 E, u32 n, u32 t0, u32 T, u32 num_actions,
