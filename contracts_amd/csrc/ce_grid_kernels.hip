@@ -3538,6 +3538,7 @@ void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void*
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
   if (kind == CE_KIND_CLEANUP) {
     if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 8);
+    else if (p.n == 4) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 4);  // BASELINE config 1
     else CE_STEP_LAUNCH(CE_KIND_CLEANUP, 0);
   } else {
     if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_HARVEST, 8);
@@ -3556,7 +3557,8 @@ void launch_grid_rollout(int kind, u32 num_agents, const GridParams* dp, const R
   if (kind == CE_KIND_CLEANUP) {
     // (the n = 8 instance of the cleanup rollout measured the same as the generic one — 4.35 G both, 35 spilled registers
     // instead of 24 — so only the generic one is built; harvest's gains 8 %: 5.44 -> 5.89 G)
-    if (count <= kSmallLaunch) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 0);
+    if (count <= kSmallLaunch && num_agents == 4) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 4);
+    else if (count <= kSmallLaunch) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 0);
     else CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES, 0);
   } else {
     if (num_agents == 8) CE_ROLLOUT_LAUNCH(CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES, 8);
