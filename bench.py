@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--config-cpu-seconds", type=float, default=2.5, help="CPU baseline sample per config row")
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-boundary", action="store_true")
+    ap.add_argument("--no-counter-rng", action="store_true", help="skip the counter-RNG rows beside the MT19937 ones")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N self-launch: deadline of the whole job, s")
     return ap.parse_args()
 
@@ -200,7 +201,7 @@ class Runner:
         kind, n = wl["kind"], wl["n"]
         base, _ = group.shard(E)  # rank g owns global envs [g*E, (g+1)*E); seeds / actions are keyed by the global index
         self.env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
-                              env_index_base=base)
+                              env_index_base=base, rng=wl.get("rng", "mt19937"))
         self.env.seed(seed0=SEED0)
         self.env.reset()
         dt = torch.float32 if kind == "selfdrive" else torch.uint8
@@ -404,6 +405,32 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     return out
 
 
+def counter_rng(group, wl, a, device_index, big_E=262144):
+    """The engine's counter-RNG mode (CE_FLAG_RNG_COUNTER: Philox4x32-10 blocks, 16 bytes of generator state per env — NOT
+    the reference's stream, so never the headline) beside the MT19937 mode, same protocol as the config rows: at the
+    headline's batch, and at a batch far beyond the Infinity Cache where the MT19937 state round trip is real HBM traffic."""
+    out = {"rng": "philox4x32-10 counter stream, 512-word generations, a fresh generation per env-step",
+           "note": "same step logic and draw order; differs from the reference's np.random stream by construction "
+                   "(parity: engine == oracle restatement of this stream, tests/test_counter_rng_gpu.py)"}
+    for label, E, modes in (("headline_batch", wl["E"], ("counter",)), ("large_batch", big_E, ("mt19937", "counter"))):
+        row = {"envs_per_gpu": E, "agents": wl["n"]}
+        for mode in modes:
+            fused_T = a.fused_steps if label == "headline_batch" else 0
+            r = Runner(group, dict(wl, rng=mode), E, a.config_steps, min(a.warmup, 20), a.streams, device_index, fused_T)
+            m = r.measure("per_step", min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
+            cell = {"value": m["value"], "ms_per_step": m["ms_per_step"], "steps": m["steps"], "repeats": m["repeats"],
+                    "roofline_frac": r.roofline(m, KERNEL[wl["kind"]][0], "-")["frac"]}
+            if fused_T:
+                f = r.measure("fused", T=fused_T, min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
+                cell["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps": f["steps"],
+                                 "steps_per_launch": f["steps_per_launch"],
+                                 "roofline_frac": r.roofline(f, KERNEL[wl["kind"]][1], "-")["frac"]}
+            row[mode] = cell
+            r.close()
+        out[label] = row
+    return out
+
+
 def boundary(wl, E, device_index):
     """The RLlib vector hook at the headline batch (contracts_amd.vector_env.BatchedBaseEnv), as a sampler on
     the host would drive it — PCIe- and Python-inclusive, never `value`:
@@ -559,6 +586,8 @@ def run_rank(a):
             out["closed_loop"] = extra(closed_loop, WORKLOADS["C4"], E, local_rank, a.streams)
         if not a.no_boundary:
             out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
+        if not a.no_counter_rng:
+            out["counter_rng"] = extra(counter_rng, group, WORKLOADS["C4"], a, local_rank)
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = extra(cpu_baseline, wl, a.cpu_seconds)

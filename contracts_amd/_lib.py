@@ -16,6 +16,7 @@ FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_
 CONTRACT = {None: 0, "none": 0, "cleanup": 1, "harvest_local": 2, "selfdrive_distprop": 3}
 FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FLAG_EXTERNAL_THETA = 1, 2, 4, 8, 16, 32
 FLAG_BEAM_TRACE = 64
+FLAG_RNG_COUNTER = 128
 BEAM_NONE, BEAM_FIRE, BEAM_CLEAN = 0, 1, 2
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4
 ERRORS = {-22: "CE_EINVAL", -12: "CE_ENOMEM", -19: "CE_ENODEV", -5: "CE_EIO", -34: "CE_ERANGE"}

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcontracts_engine.so")
-SOURCES = ["ce_api.hip", "ce_grid_kernels.hip", "ce_selfdrive_kernels.hip"]
+SOURCES = ["ce_api.hip", "ce_grid_kernels.hip", "ce_grid_kernels_ctr.hip", "ce_selfdrive_kernels.hip"]
 HEADERS = ["ce_device.h", "ce_grid_probe.inc", os.path.join("..", "..", "include", "contracts_engine.h")]
 # -ffp-contract=off: float64 reward/transfer arithmetic must round exactly like the reference's
 # separate multiply and add; no fast-math anywhere.
@@ -50,14 +50,17 @@ def build(force=False, verbose=False):
         lib, suffix, force = LIB.replace(".so", "_%s.so" % variant), "_" + variant, True
     if not force and not needs_build():
         return LIB
-    objs = []
-    for src in SOURCES:
+    objs, procs = [], []
+    for src in SOURCES:  # the translation units compile side by side
         obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
         cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    failed = [cmd for cmd, proc in procs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))

@@ -173,6 +173,7 @@ static int sync_device_params(ce_engine* h);
 
 static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.kind == CE_KIND_HARVEST; }
 static bool is_feat(const ce_config& c) { return c.kind == CE_KIND_HARVEST_FEATURES || c.kind == CE_KIND_CLEANUP_FEATURES; }
+static bool counter_rng(const ce_config& c) { return (c.flags & CE_FLAG_RNG_COUNTER) != 0; }  // grid kinds only (ce_create)
 static bool u8_actions(const ce_config& c) { return is_grid(c) || is_feat(c); }  // one byte per agent (selfdrive: float32)
 
 static int contract_ok(uint32_t kind, uint32_t contract) {
@@ -193,6 +194,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (is_feat(*cfg) && (cfg->flags & (CE_FLAG_COLLECTIVE_REWARD | CE_FLAG_INEQUITY_AVERSE | CE_FLAG_FIRING_ENABLED))) return CE_EINVAL;
   if ((cfg->flags & CE_FLAG_INEQUITY_AVERSE) && cfg->num_agents < 2) return CE_EINVAL;  // map_env.py:294 assertion
   if ((cfg->flags & CE_FLAG_BEAM_TRACE) && !is_grid(*cfg)) return CE_EINVAL;
+  if ((cfg->flags & CE_FLAG_RNG_COUNTER) && !is_grid(*cfg)) return CE_EINVAL;  // the other kinds draw from CPython's `random` too
 
   ce_engine* h = new (std::nothrow) ce_engine();
   if (!h) return CE_ENOMEM;
@@ -249,12 +251,12 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     b.obs_agent_stride = kObsAgentStride;
     b.obs_env_stride = (uint32_t)(n * kObsAgentStride);
     b.num_features = (uint32_t)(cl ? 12 + n : 10 + 2 * n);
-    b.rng_words = CE_RNG_WORDS_GRID;
+    b.rng_words = counter_rng(*cfg) ? CE_RNG_WORDS_COUNTER : CE_RNG_WORDS_GRID;
     A(grid, E * kGridStateBytes);
     A(agents, E * n * 4);
     A(spawn_perm, E * 20);
     A(waste_perm, E * 119 + 8);
-    A(rng, E * CE_RNG_WORDS_GRID);
+    A(rng, E * b.rng_words);
     A(obs, E * b.obs_env_stride + 16);
     A(features, E * n * b.num_features);
     A(beam_map, E * b.grid_h * b.grid_w);
@@ -289,6 +291,10 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
                                 rgb(99, 99, 255),   rgb(250, 204, 255), rgb(238, 223, 16),  0};
       if (upload_grid_tables(CE_KIND_CLEANUP, t0, lut) ||
           upload_grid_tables(CE_KIND_HARVEST, t1, lut))
+        rc = fail(h, CE_ENODEV, "constant table upload failed");
+      // (the counter-mode kernels are a translation unit of their own, with their own copies of the tables)
+      if (rc == CE_OK && counter_rng(*cfg) &&
+          (upload_grid_tables_ctr(CE_KIND_CLEANUP, t0, lut) || upload_grid_tables_ctr(CE_KIND_HARVEST, t1, lut)))
         rc = fail(h, CE_ENODEV, "constant table upload failed");
     }
   }
@@ -507,11 +513,13 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
   if ((mode & (CE_SEED_RESEED | CE_SEED_CONSTRUCT)) == 0) return fail(h, CE_EINVAL, "ce_seed: empty mode");
   const bool reseed = mode & CE_SEED_RESEED, replay_constructor = mode & CE_SEED_CONSTRUCT;
   if (is_grid(h->cfg)) {
-    if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_GRID, 0, h->d_seeds, dmask, E, 0, nullptr);
+    const bool ctr = counter_rng(h->cfg);
+    if (reseed && ctr) launch_seed_ctr(h->buf.rng, h->d_seeds, dmask, E, nullptr);
+    if (reseed && !ctr) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_GRID, 0, h->d_seeds, dmask, E, 0, nullptr);
     if (replay_constructor) {
       GridParams p = grid_params(h);
       p.mask = dmask;
-      launch_grid_construct((int)h->cfg.kind, p, h->d_gparams, nullptr);
+      (ctr ? launch_grid_construct_ctr : launch_grid_construct)((int)h->cfg.kind, p, h->d_gparams, nullptr);
     }
   } else if (is_feat(h->cfg)) {
     if (reseed) launch_mt_seed(h->buf.rng, CE_RNG_WORDS_SELFDRIVE, 0, h->d_seeds, dmask, E, 0, nullptr);
@@ -544,7 +552,7 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.mask = dmask;
-    launch_grid_reset((int)h->cfg.kind, p, h->d_gparams, stream);
+    (counter_rng(h->cfg) ? launch_grid_reset_ctr : launch_grid_reset)((int)h->cfg.kind, p, h->d_gparams, stream);
   } else if (is_feat(h->cfg)) {
     GridParams p = grid_params(h);
     p.mask = dmask;
@@ -573,7 +581,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
     p.actions = (const uint8_t*)actions;
     p.env_first = env_begin;
     p.env_count = env_count;
-    launch_grid_step((int)h->cfg.kind, p, h->d_gparams, stream);
+    (counter_rng(h->cfg) ? launch_grid_step_ctr : launch_grid_step)((int)h->cfg.kind, p, h->d_gparams, stream);
   } else if (is_feat(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
@@ -660,7 +668,8 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       ra.env_end = (uint32_t)(E * (sl + 1) / num_slices);
       void* stream = streams ? streams[sl] : nullptr;
       order_after_reset(h, stream);
-      if (is_grid(h->cfg)) launch_grid_rollout((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
+      if (is_grid(h->cfg))
+        (counter_rng(h->cfg) ? launch_grid_rollout_ctr : launch_grid_rollout)((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);
       else launch_feat_rollout((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       if (h->timing_armed) h->timed_launches++;
@@ -917,10 +926,12 @@ extern "C" int ce_selftest(int device, uint32_t* failed_mask) {
   if (hipMalloc((void**)&d, 16) != hipSuccess) return CE_ENOMEM;
   (void)hipMemset(d, 0xff, 16);
   launch_selftest(d, nullptr);
-  uint32_t r = 0xffffffffu;
-  hipError_t e = hipMemcpy(&r, d, 4, hipMemcpyDeviceToHost);
+  launch_selftest_ctr(d + 1, nullptr);  // bits 4, 5: Philox4x32-10 known answers, the counter-mode LDS fill
+  uint32_t both[2] = {0xffffffffu, 0xffffffffu};
+  hipError_t e = hipMemcpy(both, d, 8, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return CE_ENODEV;
+  const uint32_t r = both[0] | both[1];
   if (failed_mask) *failed_mask = r;
   return r == 0 ? CE_OK : CE_EIO;
 }

@@ -169,6 +169,16 @@ void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, 
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
+// the same kernels over the counter-RNG stream (CE_FLAG_RNG_COUNTER; ce_grid_kernels_ctr.hip), with their own constant tables
+inline namespace ctr {
+int upload_grid_tables_ctr(int kind, const GridTables& t, const uint32_t* rgb16);
+void launch_seed_ctr(uint32_t* rng, const uint64_t* seeds_dev, const uint8_t* mask_dev, uint32_t E, void* stream);
+void launch_grid_construct_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_reset_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_step_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_rollout_ctr(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
+int launch_selftest_ctr(uint32_t* out_dev, void* stream);
+}  // namespace ctr
 void launch_sd_construct(const SdParams& p, void* stream);
 void launch_sd_reset(const SdParams& p, void* stream);
 void launch_sd_step(const SdParams& p, void* stream);

@@ -47,10 +47,26 @@ constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = f
 #endif
 
 namespace ce {
+// This file is compiled twice.  The second translation unit (ce_grid_kernels_ctr.hip: -DCE_RNG_COUNTER) holds the grid kernels of
+// the counter-RNG mode (CE_FLAG_RNG_COUNTER, contracts_engine.h): same step logic, the env's random stream comes from
+// Philox4x32-10 blocks instead of the numpy MT19937 state.  Its kernels, constant tables and launchers live in an inline
+// namespace so the two sets of symbols never meet; the feature-vector kernels and the helpers at the end of the file are
+// built in the first unit only.
+#ifdef CE_RNG_COUNTER
+inline namespace ctr {
+#define CE_LAUNCHER(name) name##_ctr
+constexpr bool kCounterRng = true;
+#else
+#define CE_LAUNCHER(name) name
+constexpr bool kCounterRng = false;
+#endif
 
 typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int32_t i32;
+// words of one generation of the env's stream in LDS, and of an env's row of the `rng` buffer
+constexpr u32 kGen = kCounterRng ? (u32)CE_RNG_COUNTER_GEN : (u32)kMtN;
+constexpr u32 kRngRow = kCounterRng ? (u32)CE_RNG_WORDS_COUNTER : (u32)kRngStride;
 
 #define DEVINL __device__ __forceinline__
 
@@ -162,15 +178,82 @@ DEVINL void mt_twist(u32* mt, u32 lane) {
   if (!diag::ablate_twist) mt_twist_lds((lds_u32*)mt, lane);
 }
 
+// Counter mode (CE_FLAG_RNG_COUNTER, contracts_engine.h): Philox4x32-10 (Salmon et al., SC'11; Random123), ten rounds of
+//   (c0, c1, c2, c3) <- (hi(M1 c2) ^ c1 ^ k0, lo(M1 c2), hi(M0 c0) ^ c3 ^ k1, lo(M0 c0)),  k0 += W0, k1 += W1.
+// The 64-bit products are one v_mad_u64_u32 each; the key schedule is wave-uniform (scalar adds).
+DEVINL void philox4x32_10(u32 k0, u32 k1, u32& c0, u32& c1, u32& c2, u32& c3) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+    const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (u32)p1;
+    c3 = (u32)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// Generation `gen` of an env's stream into LDS: 128 blocks of four words, two per lane, each one 16-byte store.
+DEVINL void ctr_fill_body(lds_u32* mt, u32 lane, u32 k0, u32 k1, u32 gen) {
+  static_assert(CE_RNG_COUNTER_GEN == 512, "two blocks per lane");
+  lds_u32x4* Q = (lds_u32x4*)mt;
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    u32 c0 = lane + 64u * r, c1 = gen, c2 = 0, c3 = 0;
+    philox4x32_10(k0, k1, c0, c1, c2, c3);
+    u32x4_t c;
+    c.x = c0;
+    c.y = c1;
+    c.z = c2;
+    c.w = c3;
+    Q[lane + 64u * r] = c;
+  }
+  wave_sync();
+}
+// ... as a called function for the places that run a generation dry in mid-operation (resets; rare)
+__device__ __noinline__ void ctr_fill_lds(lds_u32* mt, u32 lane, u32 k0, u32 k1, u32 gen) {
+  // arguments of a called function arrive in VGPRs; these three are wave-uniform, and the ten round keys derived from
+  // them belong in SGPRs (as VGPRs they were twenty registers held through the whole function)
+  ctr_fill_body(mt, lane, rfl(k0), rfl(k1), rfl(gen));
+}
+
 struct Rng {
-  u32* mt;     // LDS, 624 words
+  u32* mt;     // LDS, kGen words
   u32 pos;     // words consumed from the current generation (uniform)
   u32 cache;   // lane k: tempered word cbase + k
   u32 cbase;   // uniform
   u32 ccount;  // uniform; 0 = cache invalid
   u64 cvalid;  // lanes < ccount
   u32 twists;  // generations advanced since the state was loaded (uniform): 0 = the key words in HBM are still current
+  u32 k0, k1, gen0;  // counter mode: the env's key and the generation its `rng` row named at load (uniform)
 };
+// the stream has run dry: next generation into LDS (callers reset pos)
+DEVINL void rng_advance(Rng& r, u32 lane) {
+  r.twists += 1;
+  if (kCounterRng) ctr_fill_lds((lds_u32*)r.mt, lane, r.k0, r.k1, r.gen0 + r.twists);
+  else mt_twist(r.mt, lane);
+}
+// Counter mode: every operation on an env (construct, reset, a step that is taken) opens a fresh generation and leaves nothing
+// behind in it, so no state but the generation number travels between launches and a fused rollout draws what single steps
+// draw.  The per-step kernel opens it while its state loads are in flight (load_env_state, inlined fill: a called function
+// would wait for them first); a rollout's later steps open theirs at step entry.
+DEVINL void rng_begin_op(Rng& r, u32 lane, bool inline_fill = false) {
+  if (kCounterRng && r.pos >= kGen) {
+    r.twists += 1;
+    if (inline_fill) ctr_fill_body((lds_u32*)r.mt, lane, r.k0, r.k1, r.gen0 + r.twists);
+    else ctr_fill_lds((lds_u32*)r.mt, lane, r.k0, r.k1, r.gen0 + r.twists);
+    r.pos = 0;
+    r.ccount = 0;
+  }
+}
+DEVINL void rng_end_of_op(Rng& r) {
+  if (kCounterRng) {
+    r.pos = kGen;
+    r.ccount = 0;
+  }
+}
 
 // The stream position / cache window are wave-uniform by construction, but after inlined helpers with several
 // exits merge, the compiler's divergence analysis can lose that and turn every loop over the stream into an
@@ -184,17 +267,16 @@ DEVINL void rng_assert_uniform(Rng& r) {
 
 // make the per-lane cache cover stream words [pos, pos + ccount)
 DEVINL void rng_refill(Rng& r, u32 lane) {
-  if (r.pos >= (u32)kMtN) {
-    mt_twist(r.mt, lane);
-    r.twists += 1;
+  if (r.pos >= kGen) {
+    rng_advance(r, lane);
     r.pos = 0;
   }
   r.cbase = r.pos;
-  const u32 left = (u32)kMtN - r.pos;
+  const u32 left = kGen - r.pos;
   r.ccount = left < 64u ? left : 64u;
   r.cvalid = left < 64u ? ((1ull << left) - 1ull) : ~0ull;
   const u32 idx = r.pos + lane;
-  r.cache = mt_temper(r.mt[idx < (u32)kMtN ? idx : (u32)kMtN - 1]);
+  r.cache = mt_temper(r.mt[idx < kGen ? idx : kGen - 1]);
 }
 
 DEVINL u32 rng_next(Rng& r, u32 lane) {
@@ -214,12 +296,11 @@ DEVINL void rng_bulk(Rng& r, u32* U, uint8_t* S, u32 count, u32 keep, bool want_
   rng_assert_uniform(r);
   u32 done = 0;
   while (done < count) {
-    if (r.pos >= (u32)kMtN) {
-      mt_twist(r.mt, lane);
-      r.twists += 1;
+    if (r.pos >= kGen) {
+      rng_advance(r, lane);
       r.pos = 0;
     }
-    u32 chunk = (u32)kMtN - r.pos;
+    u32 chunk = kGen - r.pos;
     if (chunk > count - done) chunk = count - done;
     for (u32 k = lane; k < chunk; k += 64) {
       const u32 w = mt_temper(r.mt[r.pos + k]);
@@ -589,7 +670,7 @@ DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
 // per-wave LDS
 // ----------------------------------------------------------------------------------------
 template <int KIND> struct alignas(16) WaveLds {
-  u32 mt[kMtN];
+  u32 mt[kGen];
   u32 U[Geo<KIND>::UWORDS];
   uint8_t S[Geo<KIND>::SBYTES];
   uint8_t pmap[Geo<KIND>::PQUADS * 16];  // PCELLS bytes used; padded to whole 16-byte quads for the image copy
@@ -687,23 +768,41 @@ template <int KIND> DEVINL void load_static(Env<KIND>& E) {
   if (E.lane < 16) E.L->rgb[E.lane] = c_rgb[E.lane];
 }
 
+// counter mode: the env's `rng` row is (key0, key1, generation, pad) — one scalar load; the stream starts "dry", the first
+// draw of the operation fills LDS with generation + 1
+DEVINL void load_rng_counter(Rng& r, const GridParams& p, u32 e) {
+  const auto row = (CE_GPTR(const u32))(p.rng + (size_t)e * kRngRow);
+  r.k0 = rfl(row[0]);
+  r.k1 = rfl(row[1]);
+  r.gen0 = rfl(row[2]);
+  r.pos = kGen;
+}
 template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
-  const uint4* src = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
-  uint4* dst = (uint4*)E.L->mt;
-  for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
   E.rng.mt = E.L->mt;
-  E.rng.pos = rfl(p.rng[(size_t)E.e * kRngStride + kMtN]);
+  if (kCounterRng) {
+    load_rng_counter(E.rng, p, E.e);
+  } else {
+    const uint4* src = (const uint4*)(p.rng + (size_t)E.e * kRngRow);
+    uint4* dst = (uint4*)E.L->mt;
+    for (u32 k = E.lane; k < kMtN / 4; k += 64) dst[k] = src[k];
+    E.rng.pos = rfl(p.rng[(size_t)E.e * kRngRow + kMtN]);
+  }
   E.rng.cbase = 0;
   E.rng.ccount = 0;
   E.rng.cvalid = 0;
   E.rng.cache = 0;
   E.rng.twists = 0;
   wave_sync();
+  rng_begin_op(E.rng, E.lane);
 }
 template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   wave_sync();
+  if (kCounterRng) {  // only the generation number moves
+    if (E.lane == 0) p.rng[(size_t)E.e * kRngRow + 2] = E.rng.gen0 + E.rng.twists;
+    return;
+  }
   if (rfl(E.rng.twists) != 0 && !diag::ablate_twist) {  // the key words only change at a twist; otherwise just the position moves
-    uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngStride);
+    uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngRow);
     const uint4* src = (const uint4*)E.L->mt;
     const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
     const uint4 r0 = src[E.lane], r1 = src[E.lane + 64], r2 = src[q2];
@@ -711,7 +810,7 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
     dst[E.lane + 64] = r1;
     dst[q2] = r2;
   }
-  if (E.lane == 0) p.rng[(size_t)E.e * kRngStride + kMtN] = E.rng.pos;
+  if (E.lane == 0) p.rng[(size_t)E.e * kRngRow + kMtN] = E.rng.pos;
 }
 
 template <int KIND> DEVINL void zero_pmap(Env<KIND>& E) {
@@ -824,11 +923,17 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   // Every load and LDS store below is unconditional: a lane past the end of a list repeats the last element (clamped
   // index, same value to the same address).  A divergent `if` around a single load costs a compare, an exec save /
   // restore pair and a branch — scalar-unit work, which is what this kernel has least of.
-  const uint4* rsrc = (const uint4*)(p.rng + (size_t)E.e * kRngStride);
+  const uint4* rsrc = (const uint4*)(p.rng + (size_t)E.e * kRngRow);
   constexpr u32 kLastQuad = (u32)kMtN / 4 - 1;
   const u32 q2 = min(lane + 128u, kLastQuad);
-  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
-  const u32 rpos = p.rng[(size_t)E.e * kRngStride + kMtN];
+  uint4 r0 = {}, r1 = {}, r2 = {};
+  u32 rpos = kGen;
+  if (kCounterRng) {
+    load_rng_counter(E.rng, p, E.e);
+  } else {
+    r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
+    rpos = p.rng[(size_t)E.e * kRngRow + kMtN];
+  }
   // map: the constant base image, codes pre-scaled (L2-resident, shared by every env), as two rounds of 16-byte copies
   // + this env's 8 presence dwords (one scalar load)
   const uint4* gsrc = (const uint4*)T.base_pmap4;
@@ -864,6 +969,11 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
     E.WS[r] = idx < (u32)G::NWASTE ? v : 0;
   }
   const u32 rgbv = c_rgb[lane & 15];
+  if (kCounterRng) {  // the step's generation, computed under the loads above
+    E.rng.mt = E.L->mt;
+    E.rng.twists = 0;
+    rng_begin_op(E.rng, lane, true);
+  }
   // ---- LDS image ----
   uint4* pm128 = (uint4*)E.L->pmap;
   pm128[lane] = gw0;
@@ -871,17 +981,19 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
   wave_sync();
   paint_presence(E, gbits);
   E.L->rgb[lane & 15] = rgbv;
-  uint4* mt4 = (uint4*)E.L->mt;
-  mt4[lane] = r0;
-  mt4[lane + 64] = r1;
-  mt4[q2] = r2;
+  if (!kCounterRng) {
+    uint4* mt4 = (uint4*)E.L->mt;
+    mt4[lane] = r0;
+    mt4[lane + 64] = r1;
+    mt4[q2] = r2;
+  }
   E.rng.mt = E.L->mt;
-  E.rng.pos = rfl(rpos);
+  E.rng.pos = kCounterRng ? 0u : rfl(rpos);
   E.rng.cbase = 0;
   E.rng.ccount = 0;
   E.rng.cvalid = 0;
   E.rng.cache = 0;
-  E.rng.twists = 0;
+  if (!kCounterRng) E.rng.twists = 0;
   E.P = pad_of<KIND>(aw & 0xff, (aw >> 8) & 0xff);
   E.O = (aw >> 16) & 3;
   E.RW = 0;
@@ -1098,15 +1210,14 @@ struct StreamWindow {
 };
 template <int RANDW> DEVINL StreamWindow window_open(Rng& r, u32 lane) {
   rng_assert_uniform(r);
-  if (r.pos >= (u32)kMtN) {
-    mt_twist(r.mt, lane);
-    r.twists += 1;
+  if (r.pos >= kGen) {
+    rng_advance(r, lane);
     r.pos = 0;
   }
   StreamWindow w;
   w.mt = r.mt;
   w.pos = r.pos;
-  const u32 left = (u32)kMtN - r.pos;
+  const u32 left = kGen - r.pos;
   w.alen = left < (u32)RANDW ? left : (u32)RANDW;
   return w;
 }
@@ -1223,8 +1334,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
   }
   if (W.alen < (u32)G::RANDW) {  // the window runs into the next generation
-    mt_twist(W.mt, lane);
-    E.rng.twists += 1;
+    rng_advance(E.rng, lane);
     if (scan) {
 #pragma unroll
       for (int r = 0; r < AR; ++r) {
@@ -1874,6 +1984,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     return;
   }
   uint8_t* pm = E.L->pmap;
+  if (FUSED) rng_begin_op(E.rng, lane);  // counter mode: steps after a launch's first one
 
   // ---------------- MapEnv.step ----------------
   t += 1;
@@ -2128,6 +2239,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   }
 
   CE_STAMP(7);
+  rng_end_of_op(E.rng);
   // ---------------- state out ----------------
   if (FUSED) {  // the env state stays in registers / LDS for the next step of this launch
     if (lane == 0) out.done()[E.e] = done ? 1 : 0;
@@ -2292,6 +2404,7 @@ template <int KIND, int WAVES, int NFIX> __global__ __launch_bounds__(64 * kWave
   }
 }
 
+#ifndef CE_RNG_COUNTER  // the rest of the kernels is built in the first translation unit only (see the top of the file)
 // ========================================================================================
 // Feature-vector envs: HarvestFeatures (harvest_features.py:60-336) and CleanupFeatures
 // (cleanup_features.py:48-309), BASELINE config 0 / SURVEY §8f.1.  Same maps and static tables as the two grid
@@ -3491,20 +3604,71 @@ __global__ void k_selftest(u32* out) {
   if (lane == 0) out[0] = fail;
 }
 
+#else  // CE_RNG_COUNTER
+// ----------------------------------------------------------------------------------------
+// counter mode: seeding = writing the key; self-test = the Random123 known-answer vectors of Philox4x32-10
+// ----------------------------------------------------------------------------------------
+__global__ void k_ctr_seed(u32* rng, const u64* seeds, const uint8_t* mask, u32 E) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  if (mask && mask[e] == 0) return;
+  u32* row = rng + (size_t)e * kRngRow;
+  row[0] = (u32)seeds[e];
+  row[1] = (u32)(seeds[e] >> 32);
+  row[2] = 0;  // generation 0 counts as used up: the first draw opens generation 1
+  row[3] = 0;
+}
+__global__ void k_ctr_selftest(u32* out) {
+  __shared__ u32 gen[CE_RNG_COUNTER_GEN];
+  const u32 lane = lane_id();
+  // Random123 kat_vectors, philox4x32 10 rounds: counter / key / expected
+  const u32 kat[3][10] = {
+      {0, 0, 0, 0, 0, 0, 0x6627e8d5u, 0xe169c58du, 0xbc57ac4cu, 0x9b00dbd8u},
+      {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x408f276du, 0x41c83b0eu, 0xa20bc7c6u, 0x6d5451fdu},
+      {0x243f6a88u, 0x85a308d3u, 0x13198a2eu, 0x03707344u, 0xa4093822u, 0x299f31d0u, 0xd16cfe09u, 0x94fdccebu, 0x5001e420u, 0x24126ea1u}};
+  u32 fail = 0;
+  for (int v = 0; v < 3; ++v) {
+    u32 c0 = kat[v][0], c1 = kat[v][1], c2 = kat[v][2], c3 = kat[v][3];
+    philox4x32_10(kat[v][4], kat[v][5], c0, c1, c2, c3);
+    if (c0 != kat[v][6] || c1 != kat[v][7] || c2 != kat[v][8] || c3 != kat[v][9]) fail |= 16u;
+  }
+  // the LDS fill against per-block evaluation: word 4 q + j of generation g = block (q, g, 0, 0) word j
+  ctr_fill_lds((lds_u32*)gen, lane, 0xa4093822u, 0x299f31d0u, 7u);
+  for (u32 q = lane; q < CE_RNG_COUNTER_GEN / 4; q += 64) {
+    u32 c0 = q, c1 = 7u, c2 = 0, c3 = 0;
+    philox4x32_10(0xa4093822u, 0x299f31d0u, c0, c1, c2, c3);
+    if (gen[4 * q] != c0 || gen[4 * q + 1] != c1 || gen[4 * q + 2] != c2 || gen[4 * q + 3] != c3) fail |= 32u;
+  }
+  fail = ballot(fail & 16u) ? (fail | 16u) : fail;
+  fail = ballot(fail & 32u) ? (fail | 32u) : fail;
+  if (lane == 0) out[0] = fail;
+}
+#endif  // CE_RNG_COUNTER
+
 // ----------------------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------------------
-int upload_grid_tables(int kind, const GridTables& t, const u32* rgb16) {
+int CE_LAUNCHER(upload_grid_tables)(int kind, const GridTables& t, const u32* rgb16) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(GridTables), sizeof(GridTables) * kind) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_rgb), rgb16, sizeof(u32) * 16) != hipSuccess) return -1;
   return 0;
 }
 
+#ifndef CE_RNG_COUNTER
 void launch_mt_seed(u32* rng, u32 stride_words, u32 block_offset_words, const u64* seeds_dev, const uint8_t* mask_dev,
                     u32 E, int python_seeding, void* stream) {
   hipLaunchKernelGGL(k_mt_seed, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, rng, stride_words,
                      block_offset_words, seeds_dev, mask_dev, E, python_seeding);
 }
+#else
+void launch_seed_ctr(u32* rng, const u64* seeds_dev, const uint8_t* mask_dev, u32 E, void* stream) {
+  hipLaunchKernelGGL(k_ctr_seed, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, rng, seeds_dev, mask_dev, E);
+}
+int launch_selftest_ctr(u32* out_dev, void* stream) {
+  hipLaunchKernelGGL(k_ctr_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev);
+  return 0;
+}
+#endif
 
 // CE_EXTRA_LDS (bytes of unused dynamic LDS per workgroup) is an occupancy-sweep knob for experiments
 static unsigned extra_lds() {
@@ -3527,9 +3691,9 @@ static unsigned extra_lds() {
                          p.actions, p.mask, first, first + count);                                    \
   } while (0)
 
-void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
-void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
-void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream) {
+void CE_LAUNCHER(launch_grid_construct)(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_construct); }
+void CE_LAUNCHER(launch_grid_reset)(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_GRID(k_grid_reset); }
+void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridParams* dp, void* stream) {
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
   // the state pointers travel as kernel arguments (preloaded into SGPRs at wave launch), see k_grid_step
@@ -3547,7 +3711,7 @@ void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void*
 #undef CE_STEP_LAUNCH
 }
 
-void launch_grid_rollout(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+void CE_LAUNCHER(launch_grid_rollout)(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
   // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues
@@ -3567,6 +3731,7 @@ void launch_grid_rollout(int kind, u32 num_agents, const GridParams* dp, const R
 #undef CE_ROLLOUT_LAUNCH
 }
 
+#ifndef CE_RNG_COUNTER
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
   if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
   else hipLaunchKernelGGL(k_grid_expand<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
@@ -3625,5 +3790,9 @@ int launch_selftest(u32* out_dev, void* stream) {
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev);
   return 0;
 }
+#endif  // !CE_RNG_COUNTER
 
+#ifdef CE_RNG_COUNTER
+}  // inline namespace ctr
+#endif
 }  // namespace ce

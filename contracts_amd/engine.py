@@ -34,7 +34,11 @@ _FIELD_DTYPES = {
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
-                beam_trace=False, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8):
+                beam_trace=False, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8, rng="mt19937"):
+    """rng: "mt19937" = the reference's numpy stream (every parity claim is about this mode); "counter" = the engine's own
+    Philox4x32-10 stream (CE_FLAG_RNG_COUNTER, grid kinds only): 16 bytes of generator state per env, no np.random.seed trace"""
+    if rng not in ("mt19937", "counter"):
+        raise ValueError("rng must be 'mt19937' or 'counter', got %r" % (rng,))
     cfg = CeConfig()
     cfg.abi_version = _lib.CE_ABI_VERSION
     cfg.kind = _lib.KIND[kind]
@@ -43,7 +47,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.flags = (_lib.FLAG_FIRING * bool(firing) | _lib.FLAG_AUTO_RESET * bool(auto_reset)
                  | _lib.FLAG_COLLECTIVE * bool(collective) | _lib.FLAG_INEQUITY * bool(inequity)
                  | _lib.FLAG_COLLISION * bool(collision_on) | _lib.FLAG_EXTERNAL_THETA * bool(external_theta)
-                 | _lib.FLAG_BEAM_TRACE * bool(beam_trace))
+                 | _lib.FLAG_BEAM_TRACE * bool(beam_trace) | _lib.FLAG_RNG_COUNTER * (rng == "counter"))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))

@@ -71,6 +71,23 @@ enum ce_contract {
 #define CE_FLAG_BEAM_TRACE 0x40u       /* grid kinds: every step also writes `beam_map`, the cells the step's FIRE / CLEAN beams
                                          covered (MapEnv.beam_pos, map_env.py:231,813) — what render() / full_map_to_colors()
                                          overlay on the map (map_env.py:371-373); off by default, rollouts do not need it */
+#define CE_FLAG_RNG_COUNTER 0x80u      /* grid kinds, fixed at ce_create: the env's random stream is a counter-based generator
+                                         (Philox4x32-10) instead of numpy's legacy MT19937.  NOT the reference's stream: a
+                                         rollout in this mode is a valid sample of the same process (every draw site of
+                                         map_env.py:546,685,821,831, cleanup_new.py:326,339, harvest_new.py:294 and
+                                         two_stage_train.py:163-166 consumes the stream in the reference's order, through
+                                         the same shuffle / rand(k) / randint / uniform arithmetic), but it reproduces no
+                                         np.random.seed trace.  What it buys: 16 bytes of generator state per env in HBM
+                                         instead of 2 512, and no state round trip per step.  Definition (oracle.c restates
+                                         it; tests pin both to the Random123 known-answer vectors):
+                                           key      = (seed, 0)                       the env's 32-bit seed
+                                           block    (g, q) = philox4x32_10(counter = (q, g, 0, 0), key)      four words
+                                           generation g    = blocks q = 0 .. 127      CE_RNG_COUNTER_GEN = 512 words
+                                           stream word     = MT19937's tempering applied to the block word (a bijection;
+                                                             it keeps every consumer of the stream common to both modes)
+                                         and every operation on an env (construct, reset, step) starts a fresh generation:
+                                         the words a step leaves unread are dropped, a step that needs more than 512
+                                         runs on into generation g + 1.  `rng` row: key0, key1, g = last generation used, pad */
 
 typedef struct ce_config {
   uint32_t abi_version;    /* CE_ABI_VERSION                                               */
@@ -106,7 +123,7 @@ typedef struct ce_buffers {
   uint32_t num_int_metrics;      /* see CE_MI_* / CE_MIA_*                                  */
   uint32_t num_f64_metrics;      /* see CE_MF_*                                            */
   uint32_t obs_env_stride;       /* bytes between consecutive envs in `obs` (n * obs_agent_stride) */
-  uint32_t rng_words;            /* CE_RNG_WORDS_GRID / CE_RNG_WORDS_SELFDRIVE             */
+  uint32_t rng_words;            /* CE_RNG_WORDS_GRID / CE_RNG_WORDS_SELFDRIVE / CE_RNG_WORDS_COUNTER */
   uint32_t grid_env_stride;      /* bytes between consecutive envs in `grid`                  */
   uint32_t grid_row_stride;      /* bytes between consecutive map rows inside an env's `grid` slice: the map
                                     is stored with the 7-cell view border on every side (32 cleanup, 52 harvest) */
@@ -220,6 +237,8 @@ typedef struct ce_buffers {
 #define CE_FEAT_ABSENT 0xffffu
 #define CE_RNG_WORDS_GRID 628u       /* key[624], pos, 3 pad words (16-byte aligned rows)   */
 #define CE_RNG_WORDS_SELFDRIVE 1256u /* numpy MT block then Python `random` MT block        */
+#define CE_RNG_WORDS_COUNTER 4u      /* CE_FLAG_RNG_COUNTER: key0, key1, generation, pad    */
+#define CE_RNG_COUNTER_GEN 512u      /* stream words per generation in that mode            */
 
 #define CE_FAULT_BAD_ACTION 0x1u     /* action id outside the family's table (Agent.py:161,198)
                                         — the reference raises KeyError                     */

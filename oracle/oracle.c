@@ -45,6 +45,10 @@
 typedef struct {
   uint32_t key[624];
   uint32_t pos;
+  /* counter mode (CE_FLAG_RNG_COUNTER, contracts_engine.h — the engine's own stream, not the reference's): key[0..511] holds
+   * generation `gen` of Philox4x32-10 blocks under (k0, k1); everything downstream of mt_next is shared with MT19937 */
+  int ctr;
+  uint32_t k0, k1, gen;
 } mt_t;
 
 /* numpy: RandomState.seed(int) -> mt19937_seed == init_genrand */
@@ -84,7 +88,45 @@ static void mt_init_by_array(mt_t* m, const uint32_t* init_key, int key_length) 
   m->pos = 624;
 }
 
+/* Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123
+ * philox.h): ten rounds of (c0,c1,c2,c3) <- (hi(M1*c2)^c1^k0, lo(M1*c2), hi(M0*c0)^c3^k1, lo(M0*c0)), key += (W0, W1) */
+static void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+static uint32_t rng_gen_words(const mt_t* m) { return m->ctr ? CE_RNG_COUNTER_GEN : 624u; }
+/* counter mode: the next generation = blocks (q, gen, 0, 0), q = 0 .. 127 */
+static void ctr_next_generation(mt_t* m) {
+  m->gen += 1;
+  for (uint32_t q = 0; q < CE_RNG_COUNTER_GEN / 4; q++) {
+    uint32_t c[4] = {q, m->gen, 0, 0};
+    philox4x32_10(m->k0, m->k1, c);
+    memcpy(m->key + 4 * q, c, 16);
+  }
+  m->pos = 0;
+}
+/* ... every operation on an env (construct, reset, a step that is taken) opens a fresh generation and ends by dropping
+ * what is left of it */
+static void rng_begin_op(mt_t* m) {
+  if (m->ctr && m->pos >= CE_RNG_COUNTER_GEN) ctr_next_generation(m);
+}
+static void rng_end_of_op(mt_t* m) {
+  if (m->ctr) m->pos = CE_RNG_COUNTER_GEN;
+}
+
 static void mt_twist(mt_t* m) {
+  if (m->ctr) {
+    ctr_next_generation(m);
+    return;
+  }
   uint32_t* k = m->key;
   int i;
   uint32_t y;
@@ -102,7 +144,7 @@ static void mt_twist(mt_t* m) {
 }
 
 static uint32_t mt_next(mt_t* m) {
-  if (m->pos >= 624) mt_twist(m);
+  if (m->pos >= rng_gen_words(m)) mt_twist(m);
   uint32_t y = m->key[m->pos++];
   y ^= (y >> 11);
   y ^= (y << 7) & 0x9d2c5680u;
@@ -817,9 +859,10 @@ static void latch_zero_metrics(orc_t* o, int ei) {
   memset(o->b.f64_metrics + (size_t)ei * CE_MF_COUNT(n), 0, sizeof(double) * CE_MF_COUNT(n));
 }
 
-static void export_state(orc_t* o, int ei) {
+static void export_state(orc_t* o, int ei) { /* the last thing construct / reset / step do to an env */
   env_t* e = &o->envs[ei];
   int n = o->n;
+  rng_end_of_op(&e->np_rng);
   if (o->kind != CE_KIND_SELFDRIVE) {
     memcpy(o->b.grid + (size_t)ei * o->cells, e->grid, o->cells);
     for (int a = 0; a < n; a++) {
@@ -846,6 +889,14 @@ static void export_state(orc_t* o, int ei) {
     s[5 * n + 2] = o->b.f64_metrics[(size_t)ei * CE_MF_COUNT(n) + CE_MF_TRANSFERS];
   }
   o->b.theta[ei] = e->theta;
+  if (e->np_rng.ctr) { /* key0, key1, generation, pad */
+    uint32_t* rw = o->b.rng + (size_t)ei * CE_RNG_WORDS_COUNTER;
+    rw[0] = e->np_rng.k0;
+    rw[1] = e->np_rng.k1;
+    rw[2] = e->np_rng.gen;
+    rw[3] = 0;
+    return;
+  }
   uint32_t* rw = o->b.rng + (size_t)ei * (o->kind == CE_KIND_SELFDRIVE ? CE_RNG_WORDS_SELFDRIVE : CE_RNG_WORDS_GRID);
   memcpy(rw, e->np_rng.key, 624 * 4);
   rw[624] = e->np_rng.pos;
@@ -857,12 +908,20 @@ static void export_state(orc_t* o, int ei) {
 
 static void grid_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
   env_t* e = &o->envs[ei];
-  if (mode & CE_SEED_RESEED) {
+  if ((mode & CE_SEED_RESEED) && (o->cfg.flags & CE_FLAG_RNG_COUNTER)) {
+    memset(&e->np_rng, 0, sizeof(e->np_rng));
+    e->np_rng.ctr = 1;
+    e->np_rng.k0 = (uint32_t)seed;
+    e->np_rng.k1 = (uint32_t)(seed >> 32);
+    e->np_rng.gen = 0; /* counts as used up: the first draw opens generation 1 */
+    e->np_rng.pos = CE_RNG_COUNTER_GEN;
+  } else if (mode & CE_SEED_RESEED) {
     mt_init_genrand(&e->np_rng, (uint32_t)seed);
     uint32_t k32 = (uint32_t)seed;
     mt_init_by_array(&e->py_rng, &k32, 1);
   }
   if (!(mode & CE_SEED_CONSTRUCT)) return;
+  rng_begin_op(&e->np_rng);
   /* MapEnv.__init__: spawn_points = the P cells in row-major order, then setup_agents() */
   int base_len = o->kind == CE_KIND_CLEANUP ? 10 : 20;
   for (int i = 0; i < 20; i++) e->spawn_perm[i] = (uint8_t)i;
@@ -975,6 +1034,7 @@ static void grid_step(orc_t* o, int ei, const uint8_t* act) {
       o->b.error_flags[ei] |= CE_FAULT_BAD_ACTION;
       return;
     }
+  rng_begin_op(&e->np_rng);
   int64_t* mi = o->b.int_metrics + (size_t)ei * CE_MI_COUNT(n);
   double* mf = o->b.f64_metrics + (size_t)ei * CE_MF_COUNT(n);
   /* reference current_apple_points == apples on the grid when the step is entered */
@@ -1812,6 +1872,7 @@ int orc_create(const ce_config* cfg, orc_t** out) {
   if (cfg->kind > CE_KIND_CLEANUP_FEATURES || cfg->num_envs == 0) return CE_EINVAL;
   int maxn = cfg->kind == CE_KIND_SELFDRIVE ? 10 : 9;
   if (cfg->num_agents < 1 || (int)cfg->num_agents > maxn) return CE_EINVAL;
+  if ((cfg->flags & CE_FLAG_RNG_COUNTER) && cfg->kind != CE_KIND_CLEANUP && cfg->kind != CE_KIND_HARVEST) return CE_EINVAL;
   orc_t* o = (orc_t*)calloc(1, sizeof(orc_t));
   if (!o) return CE_ENOMEM;
   o->cfg = *cfg;
@@ -1843,7 +1904,7 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     o->b.obs_agent_stride = WIN * WIN * 3;
     o->b.obs_row_stride = WIN * 3;
     o->b.obs_env_stride = (uint32_t)((n * WIN * WIN * 3 + 3) / 4 * 4);
-    o->b.rng_words = CE_RNG_WORDS_GRID;
+    o->b.rng_words = (cfg->flags & CE_FLAG_RNG_COUNTER) ? CE_RNG_WORDS_COUNTER : CE_RNG_WORDS_GRID;
     o->b.grid_env_stride = (uint32_t)o->cells;
     o->b.grid_row_stride = (uint32_t)o->W;
     o->b.grid_origin = 0;
@@ -1921,8 +1982,10 @@ int orc_reset(orc_t* o, const uint8_t* mask) {
       feat_reset(o, (int)ei);
     else if (o->kind == CE_KIND_SELFDRIVE)
       sd_reset(o, (int)ei);
-    else
+    else {
+      rng_begin_op(&o->envs[ei].np_rng);
       grid_reset(o, (int)ei);
+    }
   }
   return CE_OK;
 }
@@ -1981,6 +2044,15 @@ int orc_import_state(orc_t* o, uint32_t ei) {
     e->sd_ncross = (int)s[4 * n + 1];
   }
   e->theta = o->b.theta[ei];
+  if (o->cfg.flags & CE_FLAG_RNG_COUNTER) {
+    const uint32_t* row = o->b.rng + (size_t)ei * CE_RNG_WORDS_COUNTER;
+    e->np_rng.ctr = 1;
+    e->np_rng.k0 = row[0];
+    e->np_rng.k1 = row[1];
+    e->np_rng.gen = row[2];
+    e->np_rng.pos = CE_RNG_COUNTER_GEN;
+    return CE_OK;
+  }
   const uint32_t* rw = o->b.rng + (size_t)ei * (o->kind == CE_KIND_SELFDRIVE ? CE_RNG_WORDS_SELFDRIVE : CE_RNG_WORDS_GRID);
   memcpy(e->np_rng.key, rw, 624 * 4);
   e->np_rng.pos = rw[624];
@@ -1992,6 +2064,20 @@ int orc_import_state(orc_t* o, uint32_t ei) {
 }
 
 /* raw generator access for the RNG known-answer tests */
+void orc_philox4x32_10(const uint32_t key[2], const uint32_t counter[4], uint32_t out[4]) {
+  memcpy(out, counter, 16);
+  philox4x32_10(key[0], key[1], out);
+}
+/* the first `count` words of an env's counter-mode stream as the draw sites see them (generation 1 onwards, tempered) */
+void orc_counter_stream(uint64_t seed, uint32_t* out, int count) {
+  mt_t m;
+  memset(&m, 0, sizeof(m));
+  m.ctr = 1;
+  m.k0 = (uint32_t)seed;
+  m.k1 = (uint32_t)(seed >> 32);
+  m.pos = CE_RNG_COUNTER_GEN;
+  for (int i = 0; i < count; i++) out[i] = mt_next(&m);
+}
 void orc_rng_words(uint32_t seed, int python_seeding, uint32_t* out, int count) {
   mt_t m;
   if (python_seeding)

@@ -62,7 +62,7 @@ CONTRACT_SPACE = {
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
-                beam_trace=False):
+                beam_trace=False, rng="mt19937"):
     cfg = CeConfig()
     cfg.abi_version = 2
     cfg.kind = KIND[kind]
@@ -72,7 +72,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
     cfg.contract = CONTRACT[contract]
     cfg.flags = (FLAG_FIRING * bool(firing) | FLAG_AUTO_RESET * bool(auto_reset) | FLAG_COLLECTIVE * bool(collective)
                  | FLAG_INEQUITY * bool(inequity) | FLAG_COLLISION * bool(collision_on) | FLAG_EXTERNAL_THETA * bool(external_theta)
-                 | 64 * bool(beam_trace))
+                 | 64 * bool(beam_trace) | 128 * (rng == "counter"))
     cfg.device = device
     cfg.env_index_base = env_index_base
     lo, hi = CONTRACT_SPACE.get(contract, (0.0, 0.0))
@@ -110,6 +110,8 @@ def lib():
         L.orc_rng_shuffle.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int]
         L.orc_rng_double.argtypes = [C.c_uint32, C.c_int, C.c_int]
         L.orc_rng_double.restype = C.c_double
+        L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_counter_stream.argtypes = [C.c_uint64, C.c_void_p, C.c_int]
         for f in ("orc_create", "orc_destroy", "orc_seed", "orc_reset", "orc_step", "orc_get_buffers", "orc_import_state"):
             getattr(L, f).restype = C.c_int
         _lib = L

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
 tail -1 $OUT/kt_bench_line.json | cut -c1-200
 python3 $R/tools/kernel_trace_by_config.py $OUT/kt $OUT/kernel_stats_by_config.csv
 cd $R

@@ -3,7 +3,8 @@
 
     CONTRACTS_AMD_LIB=lib.so python tools/rate.py C4 C2:fused C1 cleanup_features,2,16384 ...
 
-RATE_PREROLL=N adds N untimed steps first.  A spec is a BASELINE config key (C1..C5, bench.py's WORKLOADS) or kind,agents,envs, optionally :fused.  Protocol: 300-step
+RATE_PREROLL=N adds N untimed steps first.  A spec is a BASELINE config key (C1..C5, bench.py's WORKLOADS) or kind,agents,envs, optionally :fused and / or
+@counter (the counter-RNG mode).  Protocol: 300-step
 pre-roll, then the median of 5 repeats of 300 steps (fused: 304 = 19 launches of 16), three env slices on three streams."""
 import os
 import statistics
@@ -22,6 +23,9 @@ CONTRACT = {"cleanup": "cleanup", "harvest": "harvest_local", "selfdrive": "self
 tag = os.path.basename(os.environ.get("CONTRACTS_AMD_LIB", "default")).replace("libcontracts_engine", "").replace(".so", "") or "HEAD"
 for spec in sys.argv[1:]:
     name, _, mode = spec.partition(":")
+    mode, _, rng = mode.partition("@")  # C4@counter, C4:fused@counter: the counter-RNG mode (grid kinds)
+    if "@" in name:
+        name, _, rng = name.partition("@")
     if name in bench.WORKLOADS:
         w = bench.WORKLOADS[name]
         kind, n, E = w["kind"], w["n"], w["E"]
@@ -32,7 +36,7 @@ for spec in sys.argv[1:]:
     K, T, PRE, S = (304, 16, 300, 3) if fused else (300, 0, 300, 3)
     LONG = int(os.environ.get("RATE_PREROLL", "0"))  # extra untimed steps first (replaying the pre-roll planes): steady states
 
-    env = BatchedEnv(kind, E, n, contract=CONTRACT[kind], horizon=1000, auto_reset=True)
+    env = BatchedEnv(kind, E, n, contract=CONTRACT[kind], horizon=1000, auto_reset=True, rng=rng or "mt19937")
     env.seed(seed0=73907)
     env.reset()
     dt = torch.float32 if kind == "selfdrive" else torch.uint8

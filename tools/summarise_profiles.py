@@ -37,7 +37,7 @@ line = [ln for ln in open(os.path.join(src, "kt_bench_line.json")).read().splitl
 json.dump(json.loads(line), open("profiles/%s_bench_line.json" % tag, "w"), indent=1)
 
 out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 20 "
-       "--no-cpu-baseline --no-closed-loop --no-boundary --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
+       "--no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
        "a 300-step pre-roll run with the other mode's kernel), summed over the dispatches of the kernel and divided by envs x steps",
        "kernels": {}}
 traffic = {}
