@@ -328,7 +328,8 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
     from contracts_amd.engine import BatchedEnv
     kind, n = wl["kind"], wl["n"]
     A = 8 if kind == "cleanup" else 7
-    env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index)
+    env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
+                     rng=wl.get("rng", "mt19937"))
     env.seed(seed0=SEED0)
     env.reset()
     obs = env.torch_tensors()["obs"]  # uint8 [E, n, 15, 15, 3], strided view of the engine's pitched buffer
@@ -428,6 +429,9 @@ def counter_rng(group, wl, a, device_index, big_E=262144):
             row[mode] = cell
             r.close()
         out[label] = row
+    cl = closed_loop(dict(wl, rng="counter"), wl["E"], device_index, a.streams)  # the per-step path is the closed loop's
+    out["closed_loop"] = {"value": cl["value"], "ms_per_step": cl["ms_per_step"], "issue": cl["issue"],
+                          "by_issue": {m: v.get("value", v.get("error")) for m, v in cl["modes"].items()}}
     return out
 
 

@@ -12,6 +12,8 @@ state afterwards, so `np.random.seed(s); env = CleanupEnv(...); env.reset(); env
 very same stream, interleaved correctly with any other user of `np.random` in the process.
 `rng="private"` keeps a per-env stream inside the engine (what the batched API uses).
 """
+import os
+
 import numpy as np
 
 from .. import spaces
@@ -126,7 +128,7 @@ class GridEnvAdapter(VectorHookMixin, _Base):
 
     def __init__(self, ascii_map=None, num_agents=1, disable_firing=True, image_obs=True, return_agent_actions=False,
                  use_collective_reward=False, inequity_averse_reward=False, alpha=0.0, beta=0.0, horizon=1000,
-                 one_hot_id=False, rng="global", device=0, **kwargs):
+                 one_hot_id=False, rng="global", device=0, vector_rng=None, **kwargs):
         if ascii_map is not None and [str(r) for r in ascii_map] != static_map(self.KIND):
             # the reference's constructors pass their module's map explicitly (cleanup_new.py:62, harvest_new.py:51):
             # that layout is accepted; any other one would need tables and per-map draw counts the kernels fix at
@@ -147,6 +149,11 @@ class GridEnvAdapter(VectorHookMixin, _Base):
         self.view_len = self.map_padding = VIEW
         self._rng_mode = rng
         self._device = device
+        # stream of the batched hook this env's to_base_env() builds (vector_hook.py): "mt19937" = the reference's, "counter" =
+        # the engine's Philox stream (faster, no np.random.seed trace); the single env itself always runs the reference's
+        self.vector_rng = vector_rng or os.environ.get("CONTRACTS_AMD_VECTOR_RNG", "mt19937")
+        if self.vector_rng not in ("mt19937", "counter"):
+            raise ValueError("vector_rng must be 'mt19937' or 'counter', got %r" % (self.vector_rng,))
         self._engine = None
         self._contract = (None, None, None, 0.0)
         self._keys = ["a%d" % i for i in range(num_agents)]

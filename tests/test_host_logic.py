@@ -325,6 +325,19 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     v2 = plain.to_base_env(num_envs=8)
     assert isinstance(v2, vector_env.BatchedBaseEnv) and made[0].kind == "harvest" and made[0].cfg.contract == 0
     assert not made[0].cfg.flags & _lib.FLAG_FIRING and made[0].cfg.horizon == 50
+    assert not made[0].cfg.flags & _lib.FLAG_RNG_COUNTER  # the reference's stream unless the env asks otherwise
+
+    # opt-in to the engine's counter stream for the batched hook: per env (vector_rng=) or per process (environment variable)
+    made.clear()
+    HarvestEnv(num_agents=3, horizon=50, rng="private", vector_rng="counter").to_base_env(num_envs=8)
+    assert made[-1].E == 8 and made[-1].cfg.flags & _lib.FLAG_RNG_COUNTER
+    monkeypatch.setenv("CONTRACTS_AMD_VECTOR_RNG", "counter")
+    made.clear()
+    CleanupEnv(num_agents=4, rng="private").to_base_env(num_envs=8)
+    assert made[-1].E == 8 and made[-1].cfg.flags & _lib.FLAG_RNG_COUNTER
+    monkeypatch.delenv("CONTRACTS_AMD_VECTOR_RNG")
+    with pytest.raises(ValueError):
+        HarvestEnv(num_agents=3, rng="private", vector_rng="xorshift")
 
     car = SeparateContractSubgameStage(sdc.SelfAcceleratingCarEnv(num_agents=4, collision_on=True, rng="private"),
                                        SelfdriveContractDistprop(4), 4, False)

@@ -5,14 +5,15 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n,contract,horizon", [("cleanup", 4, "cleanup", 25), ("harvest", 3, None, 30),
-                                                     ("harvest_features", 2, "harvest_local", 20)])
-def test_base_env_protocol_matches_oracle(kind, n, contract, horizon):
+@pytest.mark.parametrize("kind,n,contract,horizon,rng", [
+    ("cleanup", 4, "cleanup", 25, "mt19937"), ("harvest", 3, None, 30, "mt19937"), ("harvest_features", 2, "harvest_local", 20, "mt19937"),
+    ("cleanup", 4, "cleanup", 25, "counter"), ("harvest", 5, "harvest_local", 30, "counter")])  # the engine's own stream: vs its oracle twin
+def test_base_env_protocol_matches_oracle(kind, n, contract, horizon, rng):
     from contracts_amd.vector_env import BatchedBaseEnv
     from oracle.pyoracle import Oracle
     E, T = 6, 70
-    venv = BatchedBaseEnv(kind, E, n, contract=contract, seed0=500, horizon=horizon)
-    orc = Oracle(kind, E, n, contract=contract, horizon=horizon)
+    venv = BatchedBaseEnv(kind, E, n, contract=contract, seed0=500, horizon=horizon, rng=rng)
+    orc = Oracle(kind, E, n, contract=contract, horizon=horizon, rng=rng)
     orc.seed(seed0=500)
     orc.reset()
     keys = ["a%d" % i for i in range(n)]
