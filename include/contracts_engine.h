@@ -386,7 +386,8 @@ int ce_timing_begin(ce_handle h, void* stream);
 int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches);
 
 /* Device self-test of the wave primitives the kernels rely on (DPP reduction, parallel MT
- * twist, cross-lane list swap).  failed_mask: bit i set = check i failed.  0 on success. */
+ * twist, cross-lane list swap; bits 4, 5: Philox4x32-10 against the Random123 known-answer vectors and the counter-mode LDS
+ * fill against per-block evaluation).  failed_mask: bit i set = check i failed.  0 on success. */
 int ce_selftest(int device, uint32_t* failed_mask);
 
 /* 64-bit counter hash behind ce_synth_actions (selfdrive: action = ((hash>>40) / 2^24) * 0.2f - 0.1f) */

@@ -2,7 +2,7 @@
 """Workload for PMC passes (tools/pmc_run.sh): steps one handle either with per-step launches or fused rollouts.
 
     python3 tools/pmc_driver.py --mode step|fused [--kind cleanup] [--agents 8] [--envs 16384] [--steps 64] [--T 64]
-                                [--preroll 300] [--streams 3]
+                                [--preroll 300] [--streams 3] [--rng counter]
 The pre-roll runs with the other mode's kernel (so the profiled kernel only sees the measured, steady-state steps).
 """
 import argparse
@@ -23,12 +23,13 @@ def main():
     ap.add_argument("--T", type=int, default=64)
     ap.add_argument("--preroll", type=int, default=300)
     ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--rng", default="mt19937", help="mt19937 | counter (grid kinds)")
     a = ap.parse_args()
     import torch
     from contracts_amd.engine import BatchedEnv
     contract = {"cleanup": "cleanup", "harvest": "harvest_local", "selfdrive": "selfdrive_distprop",
                 "harvest_features": "harvest_local", "cleanup_features": "cleanup"}[a.kind]
-    env = BatchedEnv(a.kind, a.envs, a.agents, contract=contract, horizon=1000, auto_reset=True)
+    env = BatchedEnv(a.kind, a.envs, a.agents, contract=contract, horizon=1000, auto_reset=True, rng=a.rng)
     env.seed(seed0=73907)
     env.reset()
     dt = torch.float32 if a.kind == "selfdrive" else torch.uint8
