@@ -1850,8 +1850,14 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
 // agent-steps/s, tools/ab.sh, two rounds interleaved — which in round 1 was itself 3 % faster than 5 waves without spills
 #define CE_CLEANUP_ROLLOUT_WAVES 8
 #endif
+// launches that do not fill the machine (launch_grid_rollout): every wave is resident anyway, so the register budget is cut
+// for the occupancy the launch can reach and no further — C2 (three launches of 1 365 envs): 7 waves 1.59 G, 6: 1.69, 5: 1.75,
+// 4: 1.76; launches of 2 730 envs: 6 waves 2.81 / 3.94 G (n = 4 / 8), 5: 2.83 / 3.79, 4: 2.6 / 3.45
+#ifndef CE_CLEANUP_ROLLOUT_WAVES_MID
+#define CE_CLEANUP_ROLLOUT_WAVES_MID 6
+#endif
 #ifndef CE_CLEANUP_ROLLOUT_WAVES_SMALL
-#define CE_CLEANUP_ROLLOUT_WAVES_SMALL 7  // launches that do not fill the machine: see k_grid_rollout
+#define CE_CLEANUP_ROLLOUT_WAVES_SMALL 4
 #endif
 constexpr int kWavesPerBlock = 1;
 
@@ -2337,10 +2343,10 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 // round 3 (tools/ab.sh, harvest n = 8 x 16 384 envs): 6 waves (80 VGPRs + 2 spilled) 5.21 G, 7 waves (72 + 3) 5.46 G, 8 waves (64 + 7) 5.38 G
 #define CE_HARVEST_ROLLOUT_WAVES 7
 #endif
-// WAVES = the occupancy the register budget is cut for.  The cleanup rollout exists twice: 8 waves / SIMD (64 VGPRs + 21 spilled)
-// for launches that oversubscribe the machine — occupancy is what hides a wave's dependent chain there: +3 % on the headline —
-// and 7 waves (72 + 13 spilled) for small launches, where every wave is resident anyway and the extra spills only cost
-// (cleanup n = 4 x 4 096 envs: 1.41 vs 1.37 G).  launch_grid_rollout picks by the size of the launch.
+// WAVES = the occupancy the register budget is cut for.  The cleanup rollout exists three times: 8 waves / SIMD (64 VGPRs + 21
+// spilled) for launches that oversubscribe the machine — occupancy is what hides a wave's dependent chain there: +3 % on the
+// headline — and 6 / 4 waves (80 / 128 VGPRs, few / no spills) for launches that leave at most that many waves per SIMD, where
+// every wave is resident anyway and spills only cost.  launch_grid_rollout picks by the size of the launch.
 // NFIX as for k_grid_step: the instance for n = 8 folds every branch on the number of agents (and frees the register n lives in).
 template <int KIND, int WAVES, int NFIX> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
@@ -3714,15 +3720,17 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
 void CE_LAUNCHER(launch_grid_rollout)(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-  // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues
-  constexpr u32 kSmallLaunch = 2730;
+  // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues; one of
+  // a sixth leaves four waves per SIMD
+  constexpr u32 kMidLaunch = 2730, kSmallLaunch = 1366;
 #define CE_ROLLOUT_LAUNCH(K_, W_, N_) \
   hipLaunchKernelGGL((k_grid_rollout<K_, W_, N_>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra)
   if (kind == CE_KIND_CLEANUP) {
     // (the n = 8 instance of the cleanup rollout measured the same as the generic one — 4.35 G both, 35 spilled registers
     // instead of 24 — so only the generic one is built; harvest's gains 8 %: 5.44 -> 5.89 G)
-    if (count <= kSmallLaunch && num_agents == 4) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 4);
+    if (count <= kSmallLaunch && num_agents == 4) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 4);  // BASELINE config 1
     else if (count <= kSmallLaunch) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_SMALL, 0);
+    else if (count <= kMidLaunch) CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES_MID, 0);
     else CE_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES, 0);
   } else {
     if (num_agents == 8) CE_ROLLOUT_LAUNCH(CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES, 8);

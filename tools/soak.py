@@ -1,6 +1,7 @@
 """Randomised soak: engine vs CPU oracle over random configurations (family, n, flags, horizon, policy mix),
 every persistent and output field compared after every step — or, for half of the configurations, after every fused
-multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed]"""
+multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed] [counter]
+(`counter`: the grid kinds run in the counter-RNG mode, engine and oracle alike)"""
 import sys
 import time
 import numpy as np
@@ -10,12 +11,13 @@ from oracle.pyoracle import Oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+COUNTER = len(sys.argv) > 3 and sys.argv[3] == "counter"
 FIELDS = ["grid", "agents", "spawn_perm", "rng", "timestep", "theta", "obs", "base_reward", "reward", "done", "info", "features",
           "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics"]
 t_end = time.time() + budget
 runs = steps_total = 0
 while time.time() < t_end:
-    kind = rs.choice(["cleanup", "harvest", "cleanup", "harvest", "cleanup_features", "harvest_features"])
+    kind = rs.choice(["cleanup", "harvest"] if COUNTER else ["cleanup", "harvest", "cleanup", "harvest", "cleanup_features", "harvest_features"])
     feat = kind.endswith("_features")
     n = int(rs.randint(2 if feat else 1, 10))
     firing = bool(rs.randint(2)) and not feat
@@ -26,6 +28,8 @@ while time.time() < t_end:
     E = int(rs.choice([65, 128, 300]))
     kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, collective=collective, inequity=inequity,
               alpha=float(rs.rand() * 5), beta=float(rs.rand()))
+    if COUNTER:
+        kw["rng"] = "counter"
     trace = (not feat) and rs.rand() < 0.5
     if trace:
         kw["beam_trace"] = True
@@ -63,7 +67,7 @@ while time.time() < t_end:
             t += 1
         for f in fields:
             x, y = (env.download(f, raw=True) if feat and f == "grid" else env.download(f)), getattr(orc, f)
-            if f == "rng":
+            if f == "rng" and not COUNTER:
                 x, y = x.reshape(E, -1, 628)[:, :, :625], y.reshape(E, -1, 628)[:, :, :625]
             same = np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
             if not same:
