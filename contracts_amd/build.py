@@ -5,10 +5,13 @@
 Output: contracts_amd/csrc/libcontracts_engine.so (git-ignored; travels to the GPU box with
 the gpurun snapshot).  hipcc cross-compiles gfx950 code objects without a GPU.
 """
+import hashlib
+import json
 import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -30,12 +33,34 @@ def hipcc():
     return exe
 
 
+INFO = os.path.join(CSRC, "build_info.json")  # record of the last default build (git-ignored, like the library)
+
+
+def _sha16(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def fingerprint():
+    """what the library is a function of: every source and header by content, and the flags"""
+    files = {s: _sha16(os.path.join(CSRC, s)) for s in SOURCES + HEADERS}
+    return {"files": files, "flags": FLAGS}
+
+
+def last_build():
+    try:
+        with open(INFO) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """content-based: the library is current iff it is the file the record describes and the record's fingerprint is today's"""
+    rec = last_build()
+    if not os.path.exists(LIB) or rec is None:
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return rec.get("fingerprint") != fingerprint() or rec.get("lib_sha16") != _sha16(LIB)
 
 
 def build(force=False, verbose=False):
@@ -48,8 +73,11 @@ def build(force=False, verbose=False):
     if variant:
         flags += os.environ.get("CE_VARIANT_FLAGS", "").split()
         lib, suffix, force = LIB.replace(".so", "_%s.so" % variant), "_" + variant, True
+    if os.environ.get("CE_FORCE_BUILD") == "1":
+        force = True
     if not force and not needs_build():
         return LIB
+    t0 = time.time()
     objs, procs = [], []
     for src in SOURCES:  # the translation units compile side by side
         obj = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
@@ -65,6 +93,12 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if lib == LIB:
+        ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+        with open(INFO, "w") as f:
+            json.dump({"fingerprint": fingerprint(), "lib_sha16": _sha16(LIB), "compile_seconds": round(time.time() - t0, 1),
+                       "hipcc": ver[0] if ver else "", "translation_units": SOURCES, "offload_arch": "gfx950",
+                       "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}, f, indent=1)
     return lib
 
 
