@@ -101,3 +101,15 @@ def test_synth_action_host_is_deterministic_and_uniform():
     assert a == b and min(a) == 0 and max(a) == 7
     hist = np.bincount(a, minlength=8) / len(a)
     assert np.all(np.abs(hist - 0.125) < 0.03)
+
+
+def test_library_is_the_build_of_these_sources():
+    """the in-tree library is checked against the build record by content, not by file times: every source and header hashed,
+    the flags, and the library file itself (contracts_amd/build.py); a stale or foreign .so would make needs_build() true"""
+    from contracts_amd import build as b
+    rec = b.last_build()
+    assert rec is not None, "no build record: run `python -m contracts_amd.build`"
+    assert rec["fingerprint"] == b.fingerprint(), "sources changed since the library was built"
+    assert rec["lib_sha16"] == b._sha16(b.LIB)
+    assert set(rec["translation_units"]) == {"ce_api.hip", "ce_grid_kernels.hip", "ce_grid_kernels_ctr.hip", "ce_selfdrive_kernels.hip"}
+    assert not b.needs_build()
