@@ -87,5 +87,13 @@ def test_bench_default_line_has_every_config():
     assert cl["value"] > 0 and cl["host_iterations_per_step"] == 1 and cl["timed_seconds"] >= 0.5 and "eager" in cl["modes"]
     bd = row["boundary"]
     assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > 0
+    # the counter-RNG rows sit beside the line, never in it: the headline's rng is the reference's
+    assert row["config"]["rng"] == "mt19937-numpy-compat"
+    cr = row["counter_rng"]
+    assert "error" not in cr, cr
+    assert cr["headline_batch"]["counter"]["value"] > 0 and cr["headline_batch"]["counter"]["fused"]["steps_per_launch"] == 16
+    big = cr["large_batch"]
+    assert big["envs_per_gpu"] == 262144 and big["counter"]["value"] > big["mt19937"]["value"] > 0  # 16 B vs 2.5 KB of state per env
+    assert cr["closed_loop"]["value"] > 0
     rf = row["roofline"]
     assert abs(rf["frac"] * 8000e9 * row["ms_per_step"] * 1e-3 - 7235 * 16384) < 0.01 * 7235 * 16384
