@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-boundary", action="store_true")
     ap.add_argument("--no-counter-rng", action="store_true", help="skip the counter-RNG rows beside the MT19937 ones")
+    ap.add_argument("--rng", default="mt19937", choices=["mt19937", "counter"],
+                    help="stream of the HEADLINE rows: mt19937 = the reference's (default: the only mode BASELINE's metric is about); "
+                         "counter = the engine's own Philox stream, grid kinds only — the line then says so in config.rng")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N self-launch: deadline of the whole job, s")
     return ap.parse_args()
 
@@ -520,6 +523,10 @@ def run_rank(a):
                                             name="%s %d agents + contract (custom)" % (kind, n))
     E = a.envs_per_gpu or wl["E"]
     K, W = a.steps, a.warmup
+    if a.rng == "counter":
+        if wl["kind"] not in ("cleanup", "harvest"):
+            raise SystemExit("bench.py: --rng counter belongs to the grid kinds")
+        wl["rng"] = "counter"
 
     do_fused = bool(a.fused_steps) and wl["kind"] in FUSED_KINDS
     r = Runner(group, wl, E, K, W, a.streams, local_rank, a.fused_steps if do_fused else 0)
@@ -531,7 +538,8 @@ def run_rank(a):
     out = None
     if rank == 0:
         kstep, kfused = KERNEL[wl["kind"]]
-        roof = r.roofline(head, kstep, "per_step") if wl["algo"] else None
+        sfx = "_counter" if wl.get("rng") == "counter" else ""
+        roof = r.roofline(head, kstep, "per_step" + sfx) if wl["algo"] else None
         if roof is not None:
             ceil = stream_ceiling()
             roof["measured_copy_GBs"], roof["measured_fill_GBs"] = ceil["copy"], ceil["fill"]
@@ -541,13 +549,14 @@ def run_rank(a):
             "vs_baseline": None, "dtype": DTYPE[wl["kind"]], "data": "synthetic",
             "repeats": head["repeats"], "value_min": head["value_min"], "value_max": head["value_max"],
             "config": {"workload": wl["name"], "mode": "per_step: one launch per env-step and env slice", "envs_per_gpu": E,
-                       "envs_per_launch": E // r.S, "agents": wl["n"], "global_envs": world * E, "rng": "mt19937-numpy-compat",
+                       "envs_per_launch": E // r.S, "agents": wl["n"], "global_envs": world * E,
+                       "rng": "mt19937-numpy-compat" if a.rng == "mt19937" else "philox4x32-10 counter stream (NOT the reference's)",
                        "parallelism": "env-shard x%d, no collectives" % world, "streams_per_gpu": r.S,
                        "preroll_steps": PREROLL, "timed_seconds": head["timed_seconds"], "sanity": stats},
             "roofline": roof,
         }
         if fused is not None:
-            fr = r.roofline(fused, kfused, "fused") if wl["algo"] else None
+            fr = r.roofline(fused, kfused, "fused" + sfx) if wl["algo"] else None
             out["fused"] = dict(fused, roofline=fr, note="ce_rollout_fused: %d steps per launch, env state resident on chip, every "
                                 "step's obs / rewards / infos / features / done written to a %d-plane trajectory ring; whole launches "
                                 "only (%d timed steps per repeat); results bit-identical to per_step (tests/test_fused_rollout_gpu.py)"
@@ -557,6 +566,7 @@ def run_rank(a):
     # the other BASELINE configs, same protocol: repeats of --config-steps steps (independent of --steps) until
     # --config-seconds of timed wall per mode (single-GPU workloads: rank 0's GPU only would idle the others, so every
     # rank runs its shard of them too and the line reports the whole-job value)
+    custom = custom or a.rng != "mt19937"  # (a line on the engine's own stream carries the headline rows only)
     if not a.no_configs and not custom:
         rows = []
         for key in ("C2", "C3", "C5", "C1"):

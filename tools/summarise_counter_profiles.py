@@ -23,5 +23,11 @@ for k, algo in ALGO.items():
 rows = [r for r in csv.DictReader(open(out + "/kernel_stats.csv")) if "k_grid_step" in r["Name"]]
 res["kernel_trace"] = [{"name": r["Name"], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in rows]
 json.dump(res, open("profiles/%s_counter_rng.json" % tag, "w"), indent=1)
+# bench.py --rng counter looks its `roofline.traffic` up here
+tj = json.load(open("profiles/traffic.json"))
+for key, k in (("per_step_counter", "counter_c4_step"), ("fused_counter", "counter_c4_fused")):
+    tj[key] = {"kind": "cleanup", "agents": 8, "hbm_bytes_per_env_step": res["kernels"][k]["hbm_bytes_per_env_step"],
+               "source": "profiles/%s_counter_rng.json (%s; FETCH_SIZE doubled per the gfx950 correction)" % (tag, k)}
+json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: (v.get("hbm_bytes_per_env_step"), v["per_env_step"].get("SQ_INSTS_VALU"), v["per_env_step"].get("SQ_INSTS_SALU")) for k, v in res["kernels"].items()}))
 print(res["kernel_trace"])

@@ -64,5 +64,9 @@ for key in ALGO:
         row["wait_inst_any_share"] = per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]
     out["kernels"][key] = row
 json.dump(out, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
+try:  # the counter-RNG rows belong to tools/summarise_counter_profiles.py: kept
+    traffic.update({k: v for k, v in json.load(open("profiles/traffic.json")).items() if k.endswith("_counter")})
+except (OSError, ValueError):
+    pass
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v.get("hbm", {}).get("hbm_bytes_per_env_step") for k, v in out["kernels"].items()}))
