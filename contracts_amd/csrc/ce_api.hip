@@ -503,8 +503,9 @@ extern "C" int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const
     for (uint32_t i = 0; i < E; ++i) tmp[i] = seed0 + h->cfg.env_index_base + i;
     seeds = tmp.data();
   }
-  for (uint32_t i = 0; i < E; ++i)
-    if ((!mask || mask[i]) && seeds[i] > 0xffffffffull) return fail(h, CE_EINVAL, "seed must fit 32 bits (np.random.seed range)");
+  if (!counter_rng(h->cfg))  // (the counter stream's key is the whole 64-bit seed)
+    for (uint32_t i = 0; i < E; ++i)
+      if ((!mask || mask[i]) && seeds[i] > 0xffffffffull) return fail(h, CE_EINVAL, "seed must fit 32 bits (np.random.seed range)");
   hipError_t e = hipMemcpy(h->d_seeds, seeds, sizeof(uint64_t) * E, hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "seed upload", e);
   const uint8_t* dmask;

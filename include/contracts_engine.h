@@ -80,7 +80,7 @@ enum ce_contract {
                                          np.random.seed trace.  What it buys: 16 bytes of generator state per env in HBM
                                          instead of 2 512, and no state round trip per step.  Definition (oracle.c restates
                                          it; tests pin both to the Random123 known-answer vectors):
-                                           key      = (seed, 0)                       the env's 32-bit seed
+                                           key      = (seed & 0xffffffff, seed >> 32)   the env's seed (ce_seed takes 64 bits here)
                                            block    (g, q) = philox4x32_10(counter = (q, g, 0, 0), key)      four words
                                            generation g    = blocks q = 0 .. 127      CE_RNG_COUNTER_GEN = 512 words
                                            stream word     = MT19937's tempering applied to the block word (a bijection;

@@ -120,6 +120,20 @@ def test_counter_mode_differs_from_the_reference_stream_but_not_in_distribution(
         assert abs(a.mean() - b.mean()) < 4 * se, (a.mean(), b.mean(), se)
 
 
+def test_counter_stream_key_is_the_whole_64_bit_seed():
+    L = po.lib()
+    seed = (5 << 32) | 77
+    out = np.zeros(8, np.uint32)
+    L.orc_counter_stream(C.c_uint64(seed), out.ctypes.data, 8)
+    ctrs = np.zeros((2, 4), np.uint64)
+    ctrs[:, 0] = [0, 1]
+    ctrs[:, 1] = 1
+    assert np.array_equal(out, temper(philox_np((77, 5), ctrs).reshape(-1)))
+    o = po.Oracle("harvest", 2, 3, rng="counter")
+    o.seed(np.array([seed, seed + 1], np.uint64))
+    assert o.rng[:, :2].tolist() == [[77, 5], [78, 5]]
+
+
 def test_counter_mode_belongs_to_the_grid_kinds():
     for kind, n in (("selfdrive", 4), ("harvest_features", 2), ("cleanup_features", 2)):
         with pytest.raises(RuntimeError):

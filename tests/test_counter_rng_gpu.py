@@ -142,6 +142,33 @@ def test_counter_state_roundtrip_and_mode_is_part_of_the_state():
         e.close()
 
 
+def test_counter_seeds_are_64_bit_keys():
+    """ce_seed takes whole 64-bit seeds in counter mode (key = (low, high) words); the MT19937 mode keeps np.random.seed's range"""
+    from contracts_amd import _lib
+    from contracts_amd.engine import BatchedEnv
+    from oracle.pyoracle import Oracle
+    E, n = 16, 3
+    seeds = (np.arange(E, dtype=np.uint64) << np.uint64(33)) + np.uint64(0x1234567)
+    kw = dict(contract="harvest_local", horizon=9, auto_reset=True, rng="counter")
+    env, orc = BatchedEnv("harvest", E, n, **kw), Oracle("harvest", E, n, **kw)
+    env.seed(seeds)
+    orc.seed(seeds)
+    env.reset()
+    orc.reset()
+    assert np.array_equal(env.download("rng")[:, 1], (seeds >> np.uint64(32)).astype(np.uint32))
+    rs = np.random.RandomState(2)
+    for t in range(30):
+        a = rs.randint(0, 8, size=(E, n)).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        _compare(env, orc, FIELDS_GRID, "step %d" % t)
+    mt = BatchedEnv("harvest", E, n, contract="harvest_local")
+    with pytest.raises(_lib.EngineError):
+        mt.seed(seeds)
+    env.close()
+    mt.close()
+
+
 def test_counter_mode_belongs_to_the_grid_kinds():
     from contracts_amd import _lib
     from contracts_amd.engine import BatchedEnv
