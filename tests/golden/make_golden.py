@@ -11,6 +11,7 @@ each episode (pins the persistent spawn/waste shuffles across resets).
 
 Usage:  python tests/golden/make_golden.py            # writes all fixtures
 """
+import contextlib
 import hashlib
 import os
 import random
@@ -42,9 +43,12 @@ def obs_u8(img):
     return u
 
 
-def mt_fingerprint():
+def _mt_fingerprint():
     st = np.random.get_state()
     return np.array([st[2], int(hashlib.sha256(st[1].tobytes()).hexdigest()[:8], 16)], np.int64)
+
+
+mt_fingerprint = _mt_fingerprint
 
 
 def perm_of(points, static_points):
@@ -57,19 +61,36 @@ def perm_of(points, static_points):
 
 
 def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True, action_p=None,
-                   act_seed=None, store_obs_steps=None, extra_env_kwargs=None):
+                   act_seed=None, store_obs_steps=None, extra_env_kwargs=None, stream=None):
+    """`stream`: a counter_stream.CounterWords the caller has routed np.random to (make_counter_golden.py) — the constructor,
+    every reset() and every step() are then one operation each on that stream, and the per-step generator record is the
+    stream's (key0, key1, generation) row instead of the MT19937 fingerprint"""
+    global mt_fingerprint
+    op = stream.op if stream is not None else contextlib.nullcontext
+    if stream is not None:
+        mt_fingerprint = stream.state_row
+    try:
+        return _run_grid_trace(R, kind, n, seed, T, episodes, firing, contract, action_p, act_seed, store_obs_steps,
+                               extra_env_kwargs, op, stream is not None)
+    finally:
+        mt_fingerprint = _mt_fingerprint
+
+
+def _run_grid_trace(R, kind, n, seed, T, episodes, firing, contract, action_p, act_seed, store_obs_steps, extra_env_kwargs,
+                    op, counter):
     np.random.seed(seed)
     random.seed(seed)
     kw = dict(num_agents=n, disable_firing=not firing)
     kw.update(extra_env_kwargs or {})
-    if kind == "cleanup":
-        env = R.CleanupEnv(**kw)
-        con = R.contract_list.CleanupContract(n)
-        n_act = 9 if firing else 8
-    else:
-        env = R.HarvestEnv(**kw)
-        con = R.contract_list.HarvestFeaturemodLocalContract(n)
-        n_act = 8 if firing else 7
+    with op():
+        if kind == "cleanup":
+            env = R.CleanupEnv(**kw)
+            con = R.contract_list.CleanupContract(n)
+            n_act = 9 if firing else 8
+        else:
+            env = R.HarvestEnv(**kw)
+            con = R.contract_list.HarvestFeaturemodLocalContract(n)
+            n_act = 8 if firing else 7
     horizon = env.horizon
     static_spawn = sorted({tuple(p) for p in env.spawn_points})
     top = R.SeparateContractSubgameStage(env, con, n, True) if contract else env
@@ -92,7 +113,8 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
 
     step_idx = 0
     for ep in range(episodes):
-        o = top.reset()
+        with op():
+            o = top.reset()
         rec["ep_start"].append(step_idx)
         rec["reset_grid"].append(grid_codes(env))
         rec["reset_agents"].append(np.array([[a.pos[0], a.pos[1], ORIENT2INT[a.orientation]] for a in env.agents.values()], np.uint8))
@@ -109,7 +131,8 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
             else:
                 a = ars.choice(n_act, size=n, p=action_p)
             acts = {k: int(a[i]) for i, k in enumerate(keys)}
-            o, r, d, info = top.step(acts)
+            with op():
+                o, r, d, info = top.step(acts)
             base = env.total_reward_dict
             rec["actions"].append(a.astype(np.uint8))
             rec["grid"].append(grid_codes(env))
@@ -143,10 +166,11 @@ def run_grid_trace(R, kind, n, seed, T, episodes=1, firing=False, contract=True,
         rec["spawn_perm"].append(np.array(sp, np.int16))
 
     ek = extra_env_kwargs or {}
-    out = {"kind": kind, "n": n, "seed": seed, "firing": int(firing), "contract": int(contract), "horizon": horizon,
+    out = {"rng_mode": "counter"} if counter else {}
+    out.update({"kind": kind, "n": n, "seed": seed, "firing": int(firing), "contract": int(contract), "horizon": horizon,
            "collective": int(bool(ek.get("use_collective_reward"))), "inequity": int(bool(ek.get("inequity_averse_reward"))),
            "alpha": float(ek.get("alpha", 0.0)), "beta": float(ek.get("beta", 0.0)), "image_obs": int(ek.get("image_obs", True)),
-           "static_spawn": np.array(static_spawn, np.int16)}
+           "static_spawn": np.array(static_spawn, np.int16)})
     for k, v in rec.items():
         if isinstance(v, list):
             out[k] = np.array(v) if len(v) else np.zeros((0,), np.uint8)

@@ -72,9 +72,21 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
         sp = get("spawn_perm")[env]
         return [int(p) % len(static_spawn) if kind == "cleanup" else int(p) for p in sp]
 
+    counter = "rng_mode" in g and str(g["rng_mode"]) == "counter"  # p_* fixtures: the reference run over the counter stream
+
+    def rng_record():
+        """what the fixture recorded after every operation: MT19937 position + key fingerprint, or — counter mode — the
+        (key0, key1, generation) row"""
+        rng = get("rng")[env]
+        if counter:
+            return tuple(int(x) for x in rng[:3])
+        return (int(rng[624]), int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16))
+
     seeds = np.full((E,), seed, np.uint64)
     impl.seed(seeds)
     sync()
+    if counter:
+        assert rng_record() == tuple(int(x) for x in g["ctor_mt"]), "generator state after the constructor"
     assert np.array_equal(get("agents")[env][:, :3], g["ctor_agents"]), "constructor agents"
     assert spawn_cells() == list(g["ctor_spawn_perm"]), "constructor spawn list"
     ep_start = list(g["ep_start"]) + [len(g["actions"])]
@@ -88,9 +100,7 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
             assert np.array_equal(get("obs")[env], g["reset_obs"][ep]), "reset obs ep%d" % ep
         if not image_obs:  # feature-vector mode: the reset observation is the feature vector
             assert np.array_equal(get("features")[env].astype(np.float64), g["reset_features"][ep]), "reset features"
-        rng = get("rng")[env]
-        fp = int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16)
-        assert (int(rng[624]), fp) == tuple(int(x) for x in g["reset_mt"][ep]), "MT state after reset ep%d" % ep
+        assert rng_record() == tuple(int(x) for x in g["reset_mt"][ep]), "generator state after reset ep%d" % ep
         assert get("theta")[env] == g["theta"][ep], "theta ep%d" % ep
         for t in range(ep_start[ep], ep_start[ep + 1]):
             acts = np.broadcast_to(g["actions"][t], (E, n))
@@ -114,9 +124,7 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
                     assert np.array_equal(ob, g["obs"][t]), "obs " + tag
                 sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(ob).tobytes()).digest(), np.uint8)
                 assert np.array_equal(sha, g["obs_sha"][t]), "obs sha " + tag
-            rng = get("rng")[env]
-            fp = int(hashlib.sha256(rng[:624].tobytes()).hexdigest()[:8], 16)
-            assert (int(rng[624]), fp) == tuple(int(x) for x in g["mt"][t]), "MT state " + tag
+            assert rng_record() == tuple(int(x) for x in g["mt"][t]), "generator state " + tag
             if kind == "cleanup":
                 assert np.array_equal(get("waste_perm")[env], g["waste_perm"][t]), "waste perm " + tag
         # metrics at the end of the recorded episode

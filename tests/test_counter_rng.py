@@ -138,3 +138,89 @@ def test_counter_mode_belongs_to_the_grid_kinds():
     for kind, n in (("selfdrive", 4), ("harvest_features", 2), ("cleanup_features", 2)):
         with pytest.raises(RuntimeError):
             po.Oracle(kind, 2, n, rng="counter")
+
+
+# ---- the harness that runs the REFERENCE over this stream (tests/golden/counter_stream.py, make_counter_golden.py) ----
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import counter_stream as cs  # noqa: E402
+
+
+def _mt19937_words(seed, count):
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)  # what np.random.seed(int) / RandomState(int) do
+    return bg.random_raw(count)
+
+
+@pytest.mark.parametrize("seed", [0, 7, 73907])
+def test_legacy_draws_are_numpys_legacy_algorithms(seed):
+    """LegacyDraws — what the p_* fixtures' generator routes the reference's np.random calls to — fed the raw MT19937 words
+    returns exactly what np.random.RandomState returns, call for call, on the argument shapes of the reference's draw sites
+    (map_env.py:546,685,821,831, cleanup_new.py:326,339, harvest_new.py:294, two_stage_train.py:163-164)"""
+    rs = np.random.RandomState(seed)
+    mine = cs.LegacyDraws(cs.WordList(_mt19937_words(seed, 40000)))
+    lo32, hi32 = np.array([0.0], np.float32), np.array([0.2], np.float32)  # contract_low / contract_high as gym casts them
+    for rnd in range(12):
+        for length in (0, 1, 2, 3, 5, 8, 9, 20, 119):
+            a, b = [[i, 2 * i] for i in range(length)], [[i, 2 * i] for i in range(length)]
+            rs.shuffle(a)
+            mine.shuffle(b)
+            assert a == b
+        movers = list(zip(["a%d" % i for i in range(7)], [[i, i + 1] for i in range(7)]))
+        m2 = list(movers)
+        rs.shuffle(movers)
+        mine.shuffle(m2)
+        assert movers == m2
+        arr, arr2 = np.arange(24).reshape(12, 2), np.arange(24).reshape(12, 2)
+        rs.shuffle(arr)
+        mine.shuffle(arr2)
+        assert np.array_equal(arr, arr2)
+        for k in (222, 155, 1):
+            assert np.array_equal(rs.rand(k), mine.rand(k))
+        assert rs.rand() == mine.rand()
+        assert [rs.randint(4) for _ in range(9)] == [mine.randint(4) for _ in range(9)]
+        assert np.array_equal(rs.randint(0, 7, size=5), mine.randint(0, 7, size=5))
+        u, v = rs.uniform(low=lo32, high=hi32), mine.uniform(low=lo32, high=hi32)
+        assert u.dtype == v.dtype and u.shape == v.shape and np.array_equal(u, v)
+        assert rs.uniform(-0.5, 2.25) == mine.uniform(-0.5, 2.25)
+        assert np.array_equal(rs.random_sample(3), mine.random_sample(3))
+    assert rs.randint(0, 2 ** 32, dtype=np.uint32) == mine.words.next32()  # both sides consumed the same number of words
+
+
+def test_counter_words_is_the_documented_stream():
+    """CounterWords (the Python side of the p_* fixtures) == the published Philox vectors, and == the oracle's stream"""
+    for ctr, key, want in KAT:
+        assert tuple(int(x) for x in cs.philox4x32_10(key, [ctr])[0]) == want
+    L = po.lib()
+    for seed in (0, 73907, (7 << 32) | 123456789):
+        w = cs.CounterWords(seed)
+        mine = [w.next32() for _ in range(512 * 2 + 9)]
+        out = np.zeros(len(mine), np.uint32)
+        L.orc_counter_stream(C.c_uint64(seed), out.ctypes.data, len(mine))
+        assert mine == [int(x) for x in out]
+        assert (w.k0, w.k1, w.gen) == (seed & 0xffffffff, seed >> 32, 3)
+    w = cs.CounterWords(5)
+    with w.op():
+        first = w.next32()
+    with w.op():  # an operation drops what the previous one left unread
+        assert w.gen == 2 and w.next32() == int(cs.temper(cs.philox4x32_10((5, 0), [(0, 2, 0, 0)]))[0, 0]) != first
+
+
+def test_patched_routes_every_global_draw_or_refuses():
+    w = cs.CounterWords(11)
+    before = np.random.get_state()[1].copy()
+    with cs.patched(w):
+        np.random.seed(12)
+        assert (w.k0, w.gen) == (12, 0)
+        with w.op():
+            x = [1, 2, 3, 4, 5]
+            np.random.shuffle(x)
+            np.random.rand(3), np.random.randint(4), np.random.uniform(0, 1)
+        assert w.consumed >= 4 + 6 + 1 + 2
+        with pytest.raises(AssertionError):
+            np.random.choice(3)
+        with pytest.raises(AssertionError):
+            np.random.random()
+    assert np.array_equal(np.random.get_state()[1], before)  # restored, and the global MT19937 was never touched

@@ -38,6 +38,20 @@ def test_golden_grid(name):
     env.close()
 
 
+@pytest.mark.parametrize("name", gc.fixtures("p"))
+def test_golden_grid_counter_rng(name):
+    """p_* fixtures: the reference itself, run with its np.random draw sites routed to the counter stream
+    (tests/golden/make_counter_golden.py) — the HIP engine in rng="counter" mode against them, every field of every step plus
+    the (key0, key1, generation) row after each construct / reset / step"""
+    g = gc.load(name)
+    assert str(g["rng_mode"]) == "counter"
+    kind, n, kw = gc.grid_kwargs(g)
+    env = _engine(kind, 3, n, rng="counter", **kw)
+    gc.replay_grid(g, env, env=2)
+    env.check_faults()
+    env.close()
+
+
 @pytest.mark.parametrize("name", gc.fixtures("g5_selfdrive"))
 def test_golden_selfdrive(name):
     g = gc.load(name)

@@ -13,6 +13,17 @@ def test_oracle_grid_golden(name):
     gc.replay_grid(g, Oracle(kind, 2, n, **kw), env=1)
 
 
+@pytest.mark.parametrize("name", gc.fixtures("p"))
+def test_oracle_counter_rng_golden(name):
+    """p_* fixtures: the REFERENCE run with np.random routed to the counter stream (tests/golden/make_counter_golden.py) — the
+    oracle in rng="counter" mode reproduces every field of every step, and the (key0, key1, generation) row after every
+    construct / reset / step"""
+    g = gc.load(name)
+    assert str(g["rng_mode"]) == "counter"
+    kind, n, kw = gc.grid_kwargs(g)
+    gc.replay_grid(g, Oracle(kind, 2, n, rng="counter", **kw), env=1)
+
+
 @pytest.mark.parametrize("name", gc.fixtures("g5_selfdrive"))
 def test_oracle_selfdrive_golden(name):
     g = gc.load(name)
