@@ -59,6 +59,9 @@ WORKLOADS = {
     "C1": dict(kind="harvest_features", n=2, E=16384, contract="harvest_local", algo=887,
                name="harvest (HarvestFeatures) 2 agents + HarvestFeaturemodLocalContract, batched to 16384 envs"),
 }
+# BASELINE.md "CPU reference measured by the survey": the Python reference, agent-steps/s of one process, per (kind, agents)
+PYTHON_REFERENCE_PER_CORE = {("cleanup", 8): 4259, ("cleanup", 4): 4203, ("harvest", 8): 1567, ("selfdrive", 4): 29578,
+                             ("harvest_features", 2): 1846}
 DTYPE = {"cleanup": "u8", "harvest": "u8", "harvest_features": "u8", "cleanup_features": "u8", "selfdrive": "f64"}
 FUSED_KINDS = ("cleanup", "harvest", "selfdrive", "harvest_features", "cleanup_features")
 
@@ -163,8 +166,9 @@ def cpu_baseline(wl, target_s, single_thread_s=4.0):
         v_one, steps1, dt1 = run(1, 256, min(single_thread_s, target_s))
         out["single_thread_value"] = v_one
         out["sample"] += " (+ envs 0..255 x %d steps on 1 thread, %.1f s)" % (steps1, dt1)
-    if kind == "cleanup" and n == 8:
-        out["python_reference_per_core"] = 4259  # the reference itself, measured by the survey
+    ref = PYTHON_REFERENCE_PER_CORE.get((kind, n))
+    if ref is not None:
+        out["python_reference_per_core"] = ref  # the reference itself (1 process), measured by the survey
     return out
 
 
@@ -249,7 +253,7 @@ class Runner:
                 self.traj = self.env.alloc_trajectory(T)  # every per-step output kept, ring of T planes
         if W:
             self._issue(mode, PREROLL, W, T)
-        elapsed, ev_ms = [], []
+        elapsed, ev_ms, self.rank_spread = [], [], []
         while len(elapsed) < min_repeats or (sum(elapsed) < min_seconds and len(elapsed) < max_repeats):
             self._fence()
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in self.streams]
@@ -264,6 +268,8 @@ class Runner:
             t1 = time.perf_counter()
             self._fence()
             elapsed.append(self.group.max(t1 - t0))  # MAX over ranks
+            if self.group.world > 1:  # the fastest rank's clock beside the slowest's: what the MAX hides
+                self.rank_spread.append((self.group.min(t1 - t0), elapsed[-1]))
             ev_ms.append(max(a.elapsed_time(b) for a, b in zip(ev0, ev1)))
         self.env.check_faults()
         med = statistics.median(elapsed)
@@ -275,6 +281,9 @@ class Runner:
                # HIP events on the launch streams (slowest stream per repeat, median repeat): the device-side time of
                # the same K steps, without the host's launch / synchronize overhead
                "event_ms_per_step": statistics.median(ev_ms) / K, "streams": self.S, "launches_per_step": launches_per_step}
+        if self.rank_spread:  # per-rank clocks of the same repeats: fastest and slowest rank (median repeat each)
+            res["ms_per_step_rank_min"] = statistics.median(lo for lo, _ in self.rank_spread) / K * 1e3
+            res["ms_per_step_rank_max"] = statistics.median(hi for _, hi in self.rank_spread) / K * 1e3
         if mode == "fused":
             res["steps_per_launch"] = T
             res["trajectory_planes"] = self.traj.P
@@ -297,6 +306,9 @@ class Runner:
             traffic = None
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": kernel,
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE (PMC): requests served by the 256 MB Infinity Cache count like HBM "
+                        "accesses, and this batch largely lives there — an upper bound of the HBM bytes; counter_rng.large_batch "
+                        "(262144 envs) is the beyond-cache figure",
                 "algorithmic_bytes_per_env_step": algo,
                 "algorithmic_bytes_per_launch": int(round(algo * envs_per_launch * steps_per_launch)),
                 "envs_per_launch": envs_per_launch, "steps_per_launch": steps_per_launch,
@@ -535,6 +547,13 @@ def run_rank(a):
     if do_fused:
         fused = r.measure("fused", T=a.fused_steps, min_repeats=a.repeats, min_seconds=a.min_seconds, max_repeats=100000)
     stats = r.sanity()
+    # proof of the job's width that does not rest on --gpus: every rank adds 1 over the process group (an all-reduce SUM
+    # over RCCL under nccl); per-rank clocks of the timed repeats as min / max over ranks
+    ranks = {"ranks_seen": int(round(group.sum(1.0))), "world_size": world,
+             "backend": backend if world > 1 else "none (single process)",
+             "device": torch.cuda.get_device_properties(local_rank).name, "envs_per_rank": E,
+             "ms_per_step_rank_min": head.get("ms_per_step_rank_min", head["ms_per_step"]),
+             "ms_per_step_rank_max": head.get("ms_per_step_rank_max", head["ms_per_step"])}
     out = None
     if rank == 0:
         kstep, kfused = KERNEL[wl["kind"]]
@@ -555,6 +574,7 @@ def run_rank(a):
                        "preroll_steps": PREROLL, "timed_seconds": head["timed_seconds"], "sanity": stats},
             "roofline": roof,
         }
+        out["ranks"] = ranks
         if fused is not None:
             fr = r.roofline(fused, kfused, "fused" + sfx) if wl["algo"] else None
             out["fused"] = dict(fused, roofline=fr, note="ce_rollout_fused: %d steps per launch, env state resident on chip, every "

@@ -31,6 +31,19 @@ class Contract:
         return (self.engine_contract, float(self.contract_space.low[0]), float(self.contract_space.high[0]),
                 float(null_prob))
 
+    def fused_epilogue(self):
+        """name of the step kernel's epilogue that computes THIS object's transfers, or None = host protocol
+        (`compute_transfer` called every step, as the reference does).  A subclass of a shipped contract that overrides
+        `compute_transfer` no longer is what the epilogue computes, so it falls back to the host protocol instead of having
+        its override silently ignored."""
+        name = self.engine_contract
+        if name is None:
+            return None
+        for cls in type(self).__mro__:
+            if "engine_contract" in cls.__dict__:  # the class that declared the epilogue owns the arithmetic it stands for
+                return name if type(self).compute_transfer is cls.__dict__.get("compute_transfer") else None
+        return None
+
     def compute_transfer(self, obs, acts, params, infos=None):
         raise NotImplementedError
 

@@ -455,20 +455,24 @@ static void begin_call(ce_engine* h) {
   (void)hipGetLastError();
 }
 
-// make `stream` wait for the last ce_reset if that ran on a different stream and this one has not waited for it yet
-static void order_after_reset(ce_engine* h, void* stream) {
-  if (h->reset_gen == 0 || stream == h->reset_stream) return;
+// make `stream` wait for the last ce_reset if that ran on a different stream and this one has not waited for it yet.
+// A stream only counts as ordered once the wait was accepted: if it is refused (e.g. `stream` is being captured and the
+// reset's event was recorded outside the capture) nothing is remembered and the caller reports the error.
+static hipError_t order_after_reset(ce_engine* h, void* stream) {
+  if (h->reset_gen == 0 || stream == h->reset_stream) return hipSuccess;
   for (auto& it : h->reset_seen) {
     if (it.first == stream) {
-      if (it.second == h->reset_gen) return;
-      it.second = h->reset_gen;
-      (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
-      return;
+      if (it.second == h->reset_gen) return hipSuccess;
+      const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
+      if (e == hipSuccess) it.second = h->reset_gen;
+      return e;
     }
   }
+  const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
+  if (e != hipSuccess) return e;
   if (h->reset_seen.size() >= 64) h->reset_seen.clear();
   h->reset_seen.emplace_back(stream, h->reset_gen);
-  (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_reset, 0);
+  return hipSuccess;
 }
 
 static int check_launch(ce_engine* h, const char* what) {
@@ -576,7 +580,8 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
   if (!h || !actions) return CE_EINVAL;
   if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
   begin_call(h);
-  order_after_reset(h, stream);
+  if (hipError_t e = order_after_reset(h, stream); e != hipSuccess)
+    return fail(h, CE_ENODEV, "step: the stream could not be ordered after the last ce_reset (a capture begun before the reset finished?)", e);
   if (is_grid(h->cfg)) {
     GridParams p = grid_params(h);
     p.actions = (const uint8_t*)actions;
@@ -668,7 +673,8 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       ra.env_first = (uint32_t)(E * sl / num_slices);
       ra.env_end = (uint32_t)(E * (sl + 1) / num_slices);
       void* stream = streams ? streams[sl] : nullptr;
-      order_after_reset(h, stream);
+      if (hipError_t e = order_after_reset(h, stream); e != hipSuccess)
+        return fail(h, CE_ENODEV, "fused rollout: the stream could not be ordered after the last ce_reset", e);
       if (is_grid(h->cfg))
         (counter_rng(h->cfg) ? launch_grid_rollout_ctr : launch_grid_rollout)((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);

@@ -293,7 +293,9 @@ class BatchedEnv:
         self._pref = None
 
     def download(self, field, env_begin=0, env_count=None, raw=False):
-        """host copy of a field; grid/obs are returned as [E,H,W] / [E,n,15,15,3] unless raw"""
+        """host copy of a field; grid/obs are returned as [E,H,W] / [E,n,15,15,3] unless raw.  After `prefetch()` a
+        whole-batch request is served from the prefetched snapshot, which is shared and READ-ONLY: copy it before editing in
+        place (e.g. `rng = env.download("rng").copy()` ahead of an `upload`)."""
         cnt = self.E - env_begin if env_count is None else env_count
         if self._pref is not None and field in self._pref and env_begin == 0 and cnt == self.E:
             out = self._pref[field]

@@ -42,7 +42,9 @@ class SeparateContractEnv(VectorHookMixin, _Base):
         # one of the three contracts of contract_list.py: transfer + redistribution run as the step kernel's epilogue.
         # Anything else (a user's Contract subclass) keeps the reference's host protocol: the engine steps the base
         # env, `contract.compute_transfer` is called with the reference's arguments and the wrapper redistributes.
-        self._host_contract = getattr(contract, "engine_contract", None) is None
+        # — and so does a subclass of a shipped contract that overrides compute_transfer (Contract.fused_epilogue).
+        fused = contract.fused_epilogue() if hasattr(contract, "fused_epilogue") else getattr(contract, "engine_contract", None)
+        self._host_contract = fused is None
         if not self._host_contract:
             base_env._contract = contract.engine_spec(null_prob)
             if base_env._engine is not None:

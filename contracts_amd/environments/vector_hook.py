@@ -9,8 +9,8 @@ RLlib's own implementation wraps `num_envs` Python env objects and steps them on
 `num_envs > 1`, the hook returns ONE `BatchedBaseEnv` over one engine handle with `num_envs` replicas configured like the
 env it was called on (kind, agents, horizon, firing / reward flags, contract and its bounds): a sampler tick is one kernel
 launch, with `runner.py` / `ray_config_utils.py` unchanged.  The replicas run private RNG streams seeded
-`seed0 + index` (`seed0` = the value last passed to `env.seed()`, else one draw from the process-global `np.random`, so
-seeded scripts stay reproducible).
+`seed0 + index` (`seed0` = the value last passed to `env.seed()`, else the next draw of a COPY of the process-global
+`np.random`: seeded scripts stay reproducible and the global stream does not move).
 
 Configurations the batched hook does not serve — a single sub-env, remote sub-envs, grid envs in feature-vector or
 one-hot mode, a user-defined host contract, the negotiate / combined / solver stages — get `SubEnvBaseEnv`, which keeps
@@ -84,9 +84,14 @@ def _engine_config(base):
 
 
 def vector_seed0(env):
+    """seed of replica 0 (replica i gets seed0 + i): the value last passed to `env.seed()`, else what the process-global
+    np.random WOULD draw next — taken from a copy of its state, so that seeded scripts stay reproducible while the global
+    stream, which the rng="global" adapters mirror for reference parity, does not move"""
     s = getattr(env, "_vector_seed0", None)
     if s is None:
-        s = int(np.random.randint(0, 2 ** 31 - 1))
+        twin = np.random.RandomState()
+        twin.set_state(np.random.get_state())
+        s = int(twin.randint(0, 2 ** 31 - 1))
     return int(s)
 
 
@@ -119,6 +124,10 @@ def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_ba
     kw.update(contract_kw)
     if seed0 is None:
         seed0 = vector_seed0(base)
+    if kw.get("rng", "mt19937") != "counter" and int(seed0) + num_envs - 1 > 0xffffffff:
+        # np.random.seed() takes 32 bits: replica i is seeded seed0 + i, and none of them may leave that range
+        raise ValueError("to_base_env: seed %d + %d sub-envs runs past 2**32 - 1 (np.random.seed's range); seed the env lower "
+                         "or use vector_rng='counter' (64-bit seeds)" % (seed0, num_envs))
     return BatchedBaseEnv(kind, num_envs, base.num_agents, seed0=seed0, convolutional=convolutional,
                           device=getattr(base, "_device", 0), **kw)
 

@@ -161,6 +161,9 @@ class Group:
         """MAX over ranks of a python float (the benchmark's elapsed time)"""
         return self._reduce(value, "MAX")
 
+    def min(self, value):
+        return self._reduce(value, "MIN")
+
     def sum(self, value):
         return self._reduce(value, "SUM")
 

@@ -23,6 +23,10 @@ def _check(out, world=2, envs=2048):
     assert row["config"]["global_envs"] == world * envs and row["config"]["parallelism"].startswith("env-shard x%d" % world)
     assert row["repeats"] >= 3 and row["value_min"] <= row["value"] <= row["value_max"]
     assert "cpu_baseline" not in row
+    # the job's width as the ranks themselves counted it (an all-reduce SUM of 1), and the per-rank clocks behind the MAX
+    rk = row["ranks"]
+    assert rk["ranks_seen"] == world == rk["world_size"] and rk["envs_per_rank"] == envs
+    assert 0 < rk["ms_per_step_rank_min"] <= rk["ms_per_step_rank_max"] and abs(rk["ms_per_step_rank_max"] - row["ms_per_step"]) < 1e-9
     # the roofline figure follows from the wall clock of the line itself
     rf = row["roofline"]
     assert abs(rf["frac"] * rf["peak"] * 1e9 * row["ms_per_step"] * 1e-3 - 7235 * envs) < 0.01 * 7235 * envs
@@ -80,6 +84,10 @@ def test_bench_default_line_has_every_config():
         assert c["fused"]["steps"] % c["fused"]["steps_per_launch"] == 0
         assert abs(c["fused"]["launches_per_step"] * c["fused"]["steps_per_launch"] - 3) < 1e-9
     assert row["cpu_baseline"]["kind"] == "port" and row["cpu_baseline"]["value"] > 0
+    # BASELINE.md's Python-reference constant beside every CPU baseline
+    assert row["cpu_baseline"]["python_reference_per_core"] == 4259
+    assert [c["cpu_baseline"]["python_reference_per_core"] for c in row["configs"]] == [4203, 1567, 29578, 1846]
+    assert row["ranks"]["ranks_seen"] == 1 and "Infinity Cache" in row["roofline"]["note"]
     # --steps 20 with 16-step fused launches: 32 timed steps, two launches per slice
     assert row["fused"]["steps"] == 32 and row["fused"]["steps_per_launch"] == 16
     assert abs(row["fused"]["launches_per_step"] - 3 / 16.0) < 1e-9

@@ -359,3 +359,40 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     feat = CleanupEnv(num_agents=2, image_obs=False, rng="private")
     with pytest.raises(ValueError):
         feat.to_base_env(num_envs=2)  # needs make_env to build the other sub-env
+
+    # an unseeded env: replica 0's seed is what the global np.random would draw next, but the global stream does not move
+    np.random.seed(4242)
+    before = np.random.get_state()[1].copy(), np.random.get_state()[2]
+    fresh = HarvestEnv(num_agents=3, horizon=50, rng="private")
+    made.clear()
+    fresh.to_base_env(num_envs=4)
+    after = np.random.get_state()
+    assert np.array_equal(after[1], before[0]) and after[2] == before[1]
+    assert made[-1].seeded == int(np.random.RandomState(4242).randint(0, 2 ** 31 - 1))
+    # np.random.seed's range: seed0 + index must stay within 32 bits on the reference's stream; the counter stream takes 64
+    big = HarvestEnv(num_agents=3, horizon=50, rng="private")
+    big.seed(0xffffffff - 2)
+    with pytest.raises(ValueError, match="2\\*\\*32"):
+        big.to_base_env(num_envs=8)
+    bigc = HarvestEnv(num_agents=3, horizon=50, rng="private", vector_rng="counter")
+    bigc.seed(0xffffffff - 2)
+    made.clear()
+    bigc.to_base_env(num_envs=8)
+    assert made[-1].seeded == 0xffffffff - 2
+
+    # a subclass of a shipped contract that overrides compute_transfer is no longer what the fused epilogue computes: the
+    # wrapper falls back to the reference's host protocol (compute_transfer called every step) instead of ignoring the override
+    class DoubleCleanup(CleanupContract):
+        def compute_transfer(self, obs, acts, rews, params, infos=None):
+            return {k: 2 * v for k, v in super().compute_transfer(obs, acts, rews, params, infos).items()}
+
+    class RenamedCleanup(CleanupContract):  # no override: still the epilogue
+        pass
+
+    assert CleanupContract(4).fused_epilogue() == "cleanup" and RenamedCleanup(4).fused_epilogue() == "cleanup"
+    assert DoubleCleanup(4).fused_epilogue() is None
+    b2 = CleanupEnv(num_agents=4, rng="private")
+    assert SeparateContractSubgameStage(b2, DoubleCleanup(4), 4, True)._host_contract is True
+    assert SeparateContractSubgameStage(CleanupEnv(num_agents=4, rng="private"), RenamedCleanup(4), 4, True)._host_contract is False
+    assert isinstance(SeparateContractSubgameStage(b2, DoubleCleanup(4), 4, True).to_base_env(make_env=lambda i: b2, num_envs=2),
+                      SubEnvBaseEnv)
