@@ -1,7 +1,9 @@
 """The counter-RNG mode (CE_FLAG_RNG_COUNTER, include/contracts_engine.h) on the CPU side: the oracle's Philox4x32-10 against
 the published known-answer vectors and an independent numpy restatement, the stream definition (generations of 512 words,
-a fresh generation per operation), and the mode's scope.  The mode is the engine's own stream — no reference fixture exists for
-it; what pins it is the generator's published vectors plus oracle == engine on every field (tests/test_counter_rng_gpu.py)."""
+a fresh generation per operation), the mode's scope — and the harness that pins the mode to the REFERENCE: the reference's own
+code run with its np.random draw sites routed to this stream (tests/golden/counter_stream.py, make_counter_golden.py -> p_*
+fixtures, replayed by tests/test_oracle_golden.py on the CPU and tests/test_gpu_parity.py::test_golden_grid_counter_rng on the
+GPU).  Here: that harness's draw algorithms equal numpy's RandomState call for call, and its word stream is the documented one."""
 import ctypes as C
 
 import numpy as np
