@@ -369,10 +369,16 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
             torch.remainder(noise[b0:b1], A, out=acts[b0:b1])
         env.step_range_device(acts.data_ptr(), b0, b1 - b0, stream=st.cuda_stream)
 
-    def eager_tick():
+    def slice_tick_policy(st, b0, b1):
+        # the same policy with the action selection fused into the step kernel's action load (ce_step_policy,
+        # CE_POLICY_BYTES_MOD: action = policy byte mod |A|): ONE policy kernel + one step launch per slice and tick
+        torch.add(ahead[b0:b1], noise[b0:b1], out=noise[b0:b1])
+        env.step_policy_device(noise.data_ptr(), "bytes", b0, b1 - b0, stream=st.cuda_stream)
+
+    def eager_tick(tick_fn=slice_tick):
         for st, (b0, b1) in zip(streams, bounds):
             with torch.cuda.stream(st):
-                slice_tick(st, b0, b1)
+                tick_fn(st, b0, b1)
 
     def timed(tick, K=480, per_tick=1):
         for _ in range(48 // per_tick):
@@ -391,15 +397,18 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
         return {"value": E * n * K / med, "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
                 "timed_seconds": sum(elapsed)}
 
-    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=3 * S, host_iterations_per_step=1)}
-    for name, ticks in (("graph", 1), ("graph16", 16)):
+    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=3 * S, host_iterations_per_step=1, launches_per_slice_and_step=3),
+             "policy_eager": dict(timed(lambda: eager_tick(slice_tick_policy)), host_calls_per_step=2 * S, host_iterations_per_step=1,
+                                  launches_per_slice_and_step=2)}
+    for name, ticks, tick_fn in (("graph", 1, slice_tick), ("graph16", 16, slice_tick), ("policy_graph", 1, slice_tick_policy),
+                                 ("policy_graph16", 16, slice_tick_policy)):
         try:  # one hipGraph per slice, replayed on the slice's stream
             graphs = []
             for st, (b0, b1) in zip(streams, bounds):
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=st):
                     for _ in range(ticks):
-                        slice_tick(st, b0, b1)
+                        tick_fn(st, b0, b1)
                 graphs.append(gr)
             torch.cuda.synchronize()
 
@@ -409,13 +418,15 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
                         gr.replay()
 
             modes[name] = dict(timed(graph_tick, per_tick=ticks), host_calls_per_step=S / float(ticks),
-                               host_iterations_per_step=1.0 / ticks, device_policy_evaluations_per_step=1)
+                               host_iterations_per_step=1.0 / ticks, device_policy_evaluations_per_step=1,
+                               launches_per_slice_and_step=2 if tick_fn is slice_tick_policy else 3)
         except Exception as exc:  # capture support differs between ROCm builds: the eager figure stands
             modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    best = max((m for m in ("eager", "graph") if "value" in modes[m]), key=lambda m: modes[m]["value"])
+    best = max((m for m in ("eager", "graph", "policy_eager", "policy_graph") if "value" in modes[m]), key=lambda m: modes[m]["value"])
     out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
                policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
-                      "byte, accumulated) mod %d — two elementwise kernels per slice and step" % A,
+                      "byte, accumulated) mod %d — eager / graph: two elementwise kernels + the step per slice and tick; policy_*: "
+                      "one elementwise kernel + ce_step_policy (the modulo happens in the step kernel's action load)" % A,
                workload=wl["name"])
     env.close()
     return out
@@ -477,12 +488,15 @@ def boundary(wl, E, device_index):
     dt = time.perf_counter() - t0
     out["tensor_path"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                           "what": "send_actions_array (host action plane over PCIe) + poll_tensors (zero-copy device views)"}
-    # dict protocol
+    # dict protocol: the policy side's per-env action dictionaries exist before the tick starts (RLlib's sampler builds them
+    # from its policy's output; building them in this loop would time Python's dict constructor, not the hook)
     keys = ["a%d" % i for i in range(n)]
+    t0 = time.perf_counter()
+    action_dicts = [{e: dict(zip(keys, row)) for e, row in enumerate(planes[k].tolist())} for k in range(8)]
+    ms_build = (time.perf_counter() - t0) / 8 * 1e3
 
     def dict_tick(t):
-        a = planes[t % 8].tolist()
-        venv.send_actions({e: dict(zip(keys, a[e])) for e in range(E)})
+        venv.send_actions(action_dicts[t % 8])
         obs, rew, dones, infos, _ = venv.poll()
         k = 0
         for e in obs:  # a sampler touches every env's dictionaries
@@ -490,15 +504,30 @@ def boundary(wl, E, device_index):
             k += len(o)
         return k
 
-    dict_tick(0)
+    for t in range(3):  # the first two ticks build the two dictionary generations
+        dict_tick(t)
     t0, steps = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 1.0 or steps < 2:
-        dict_tick(steps + 1)
+    while time.perf_counter() - t0 < 1.0 or steps < 4:
+        dict_tick(steps + 3)
         steps += 1
     dt = time.perf_counter() - t0
     out["dict_protocol"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "env_steps_per_s": E * steps / dt,
-                            "ms_per_step": dt / steps * 1e3, "steps": steps,
-                            "what": "send_actions + poll with every env's obs (float64 image) / reward / done / info dictionaries materialised"}
+                            "ms_per_step": dt / steps * 1e3, "steps": steps, "host_threads": venv._host_threads(),
+                            "ms_building_action_dicts_not_timed": ms_build,
+                            "what": "send_actions(pre-built {env: {agent: action}}) + poll with every env's obs (float64 image views) / "
+                                    "reward / done / info dictionaries in hand and walked; recycled dictionary trees over page-locked "
+                                    "snapshots (vector_env.py), observations converted to float64 on the host threads every tick"}
+    # the same protocol with every dictionary rebuilt per tick (recycle_dicts=False: round 3's path), a few ticks
+    venv.stop()
+    venv = BatchedBaseEnv(kind, E, n, contract=wl["contract"], seed0=SEED0, horizon=1000, device=device_index, recycle_dicts=False)
+    venv.poll()
+    dict_tick(0)
+    t0 = time.perf_counter()
+    dict_tick(1)
+    dict_tick(2)
+    dt = (time.perf_counter() - t0) / 2
+    out["dict_protocol_rebuilt"] = {"value": E * n / dt, "unit": "agent-steps/s", "ms_per_step": dt * 1e3,
+                                    "what": "recycle_dicts=False: lazily built per-env dictionaries, every one looked up"}
     venv.stop()
     return out
 

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONTRACTS_AMD_LIB") or os.path.join(HERE, "csrc", "libcontracts_engine.so")
 
-CE_ABI_VERSION = 2
+CE_ABI_VERSION = 3
 KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "cleanup_features": 4}
 FEAT_KINDS = ("harvest_features", "cleanup_features")
 FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_* of the header
@@ -18,6 +18,7 @@ FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FL
 FLAG_BEAM_TRACE = 64
 FLAG_RNG_COUNTER = 128
 BEAM_NONE, BEAM_FIRE, BEAM_CLEAN = 0, 1, 2
+POLICY_BYTES_MOD, POLICY_ARGMAX_F32 = 1, 2
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4
 ERRORS = {-22: "CE_EINVAL", -12: "CE_ENOMEM", -19: "CE_ENODEV", -5: "CE_EIO", -34: "CE_ERANGE"}
 
@@ -49,7 +50,7 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P),
+        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P), ("actions_taken", _P),
     ]
 
 
@@ -74,6 +75,7 @@ EXPORTS = {
     "ce_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "ce_step_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_rollout_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeTraj), C.c_uint32, C.c_void_p]),
     "ce_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -85,6 +87,12 @@ EXPORTS = {
     "ce_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
     "ce_download_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeFieldReq), C.c_uint32]),
     "ce_upload": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ce_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ce_host_free": (C.c_int, [C.c_void_p]),
+    "ce_download_async": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ce_step_host_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "ce_obs_u8_to_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "ce_i16_to_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "ce_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ce_timing_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "ce_selftest": (C.c_int, [C.c_int, C.POINTER(C.c_uint32)]),

@@ -33,6 +33,27 @@ def hipcc():
     return exe
 
 
+# CPython helper of the vector hook's dict protocol (host-side marshalling loops, plain C, system compiler)
+PYDICT_SRC = "ce_pydict.c"
+
+
+def pydict_path():
+    import sysconfig
+    return os.path.join(HERE, "_ce_pydict" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pydict(verbose=False):
+    import sysconfig
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for contracts_amd/csrc/ce_pydict.c")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I", sysconfig.get_paths()["include"], os.path.join(CSRC, PYDICT_SRC), "-o", pydict_path()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return pydict_path()
+
+
 INFO = os.path.join(CSRC, "build_info.json")  # record of the last default build (git-ignored, like the library)
 
 
@@ -43,7 +64,7 @@ def _sha16(path):
 
 def fingerprint():
     """what the library is a function of: every source and header by content, and the flags"""
-    files = {s: _sha16(os.path.join(CSRC, s)) for s in SOURCES + HEADERS}
+    files = {s: _sha16(os.path.join(CSRC, s)) for s in SOURCES + HEADERS + [PYDICT_SRC]}
     return {"files": files, "flags": FLAGS}
 
 
@@ -58,7 +79,7 @@ def last_build():
 def needs_build():
     """content-based: the library is current iff it is the file the record describes and the record's fingerprint is today's"""
     rec = last_build()
-    if not os.path.exists(LIB) or rec is None:
+    if not os.path.exists(LIB) or rec is None or not os.path.exists(pydict_path()):
         return True
     return rec.get("fingerprint") != fingerprint() or rec.get("lib_sha16") != _sha16(LIB)
 
@@ -94,6 +115,7 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     if lib == LIB:
+        build_pydict(verbose)
         ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
         with open(INFO, "w") as f:
             json.dump({"fingerprint": fingerprint(), "lib_sha16": _sha16(LIB), "compile_seconds": round(time.time() - t0, 1),

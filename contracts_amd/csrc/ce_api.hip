@@ -4,12 +4,15 @@
 // state besides the per-process constant tables (idempotent uploads).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define CE_PLAIN_PARAM_POINTERS 1  // host side: ordinary pointers in the parameter blocks
@@ -260,6 +263,7 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     A(obs, E * b.obs_env_stride + 16);
     A(features, E * n * b.num_features);
     A(beam_map, E * b.grid_h * b.grid_w);
+    A(actions_taken, E * n);
   } else if (is_feat(*cfg)) {
     const bool cl = cfg->kind == CE_KIND_CLEANUP_FEATURES;
     b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
@@ -389,6 +393,7 @@ static GridParams grid_params(ce_engine* h) {
   p.error_flags = b.error_flags;
   p.debug = h->d_debug;
   p.beam_map = b.beam_map;
+  p.actions_taken = b.actions_taken;
   p.E = h->cfg.num_envs;
   p.n = h->cfg.num_agents;
   p.horizon = h->cfg.horizon;
@@ -606,6 +611,23 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
   return check_launch(h, "step kernel");
 }
 
+extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream) {
+  if (!h || !policy_out) return CE_EINVAL;
+  if (!is_grid(h->cfg)) return fail(h, CE_EINVAL, "ce_step_policy belongs to the grid kinds");
+  if (mode != CE_POLICY_BYTES_MOD && mode != CE_POLICY_ARGMAX_F32) return fail(h, CE_EINVAL, "unknown CE_POLICY_* mode");
+  if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
+  begin_call(h);
+  if (hipError_t e = order_after_reset(h, stream); e != hipSuccess)
+    return fail(h, CE_ENODEV, "step: the stream could not be ordered after the last ce_reset (a capture begun before the reset finished?)", e);
+  GridParams p = grid_params(h);
+  p.actions = (const uint8_t*)policy_out;
+  p.env_first = env_begin;
+  p.env_count = env_count;
+  (counter_rng(h->cfg) ? launch_grid_step_policy_ctr : launch_grid_step_policy)((int)h->cfg.kind, (int)mode, p, h->d_gparams, stream);
+  if (h->timing_armed) h->timed_launches++;
+  return check_launch(h, "policy step kernel");
+}
+
 extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
   if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   const uint32_t E = h->cfg.num_envs;
@@ -788,6 +810,7 @@ static bool find_field(ce_engine* h, const char* name, FieldDesc* out) {
       {"error_flags", b.error_flags, 4},
       {"beam_map", b.beam_map, (size_t)b.grid_h * b.grid_w},
       {"sd_info", b.sd_info, 16},
+      {"actions_taken", b.actions_taken, n},
       {"debug", h->d_debug, 128},
   };
   for (const FieldDesc& f : fields)
@@ -824,6 +847,106 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "download", e);
+  return CE_OK;
+}
+
+// ---- host boundary helpers (the RLlib vector hook's fast path, contracts_amd/vector_env.py) ----
+extern "C" int ce_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return CE_EINVAL;
+  *out = nullptr;
+  void* p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? CE_ENOMEM : CE_ENODEV;
+  }
+  *out = p;
+  return CE_OK;
+}
+
+extern "C" int ce_host_free(void* p) {
+  if (!p) return CE_OK;
+  return hipHostFree(p) == hipSuccess ? CE_OK : CE_EINVAL;
+}
+
+extern "C" int ce_download_async(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes,
+                                 void* stream) {
+  if (!h || !field || !dst) return CE_EINVAL;
+  begin_call(h);
+  FieldDesc f;
+  if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
+  if (is_grid(h->cfg) && std::strcmp(field, "grid") == 0) return fail(h, CE_EINVAL, "ce_download_async: fetch \"grid\" with ce_download");
+  if ((uint64_t)env_begin + env_count > h->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  const hipError_t e = hipMemcpyAsync(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes,
+                                      hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "asynchronous download", e);
+  return CE_OK;
+}
+
+extern "C" int ce_step_host_async(ce_handle h, const void* host_actions, uint32_t env_begin, uint32_t env_count, void* stream) {
+  if (!h || !host_actions) return CE_EINVAL;
+  if (!u8_actions(h->cfg)) return fail(h, CE_EINVAL, "ce_step_host_async takes uint8 action ids (grid / feature kinds)");
+  if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
+  begin_call(h);
+  const size_t n = h->cfg.num_agents;
+  const hipError_t e = hipMemcpyAsync((char*)h->d_stage_actions + (size_t)env_begin * n, (const char*)host_actions + (size_t)env_begin * n,
+                                      (size_t)env_count * n, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "action upload", e);
+  return ce_step_range(h, h->d_stage_actions, nullptr, env_begin, env_count, stream);
+}
+
+// uint8 pitched observation block -> the reference's float64 images (value / 255: cleanup_new.py:258, harvest_new.py:229),
+// dense [envs][n][15][15][3].  A 256-entry table of the same double division numpy performs; rows split over worker threads.
+extern "C" int ce_obs_u8_to_f64(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
+                                uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads) {
+  if (!pitched || !out || obs_row_stride < 45 || threads == 0) return CE_EINVAL;
+  static double lut[256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (int v = 0; v < 256; ++v) lut[v] = (double)v / 255.0;
+  });
+  const size_t views = (size_t)num_envs * num_agents;
+  auto work = [=](size_t v0, size_t v1) {
+    for (size_t v = v0; v < v1; ++v) {
+      const size_t e = v / num_agents, a = v % num_agents;
+      const uint8_t* src = pitched + e * obs_env_stride + a * obs_agent_stride;
+      double* dst = out + v * (size_t)(15 * 45);
+      for (int r = 0; r < 15; ++r) {
+        const uint8_t* s = src + (size_t)r * obs_row_stride;
+        double* d = dst + r * 45;
+        for (int k = 0; k < 45; ++k) d[k] = lut[s[k]];
+      }
+    }
+  };
+  const uint32_t T = (uint32_t)std::min<size_t>(threads, views ? views : 1);
+  if (T <= 1) {
+    work(0, views);
+    return CE_OK;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(T - 1);
+  for (uint32_t t = 1; t < T; ++t) pool.emplace_back(work, views * t / T, views * (t + 1) / T);
+  work(0, views / T);
+  for (auto& th : pool) th.join();
+  return CE_OK;
+}
+
+// int16 feature rows -> float64 (the reference's feature_obs entries are floats), `threads` worker threads
+extern "C" int ce_i16_to_f64(const int16_t* src, double* out, uint64_t count, uint32_t threads) {
+  if (!src || !out || threads == 0) return CE_EINVAL;
+  auto work = [=](uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; ++i) out[i] = (double)src[i];
+  };
+  const uint32_t T = (uint32_t)std::min<uint64_t>(threads, count / 65536 + 1);
+  if (T <= 1) {
+    work(0, count);
+    return CE_OK;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(T - 1);
+  for (uint32_t t = 1; t < T; ++t) pool.emplace_back(work, count * t / T, count * (t + 1) / T);
+  work(0, count / T);
+  for (auto& th : pool) th.join();
   return CE_OK;
 }
 

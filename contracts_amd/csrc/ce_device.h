@@ -100,6 +100,7 @@ struct GridParams {
   CE_GPTR(uint32_t) error_flags;
   CE_GPTR(unsigned long long) debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
   CE_GPTR(uint8_t) beam_map;          // [E][H*W] CE_BEAM_*, written under CE_FLAG_BEAM_TRACE only
+  CE_GPTR(uint8_t) actions_taken;     // [E][n] the action ids a ce_step_policy launch derived from the policy's output
   // inputs
   CE_GPTR(const uint8_t) actions;  // [E][n]
   CE_GPTR(const uint8_t) mask;     // [E] or null (seed/reset)
@@ -168,6 +169,7 @@ void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_
 void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_step_policy(int kind, int policy, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
 // the same kernels over the counter-RNG stream (CE_FLAG_RNG_COUNTER; ce_grid_kernels_ctr.hip), with their own constant tables
 inline namespace ctr {
@@ -176,6 +178,7 @@ void launch_seed_ctr(uint32_t* rng, const uint64_t* seeds_dev, const uint8_t* ma
 void launch_grid_construct_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_reset_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
+void launch_grid_step_policy_ctr(int kind, int policy, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_rollout_ctr(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
 int launch_selftest_ctr(uint32_t* out_dev, void* stream);
 }  // namespace ctr

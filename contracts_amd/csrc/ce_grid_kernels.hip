@@ -2279,7 +2279,32 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 // n <= 9, with wave-uniform branches on n in every phase (pair tests, group sizes of the feature scan, loop bounds); the
 // instance for the headline's n = 8 lets the compiler fold them all (everything is inlined into the kernel, so a literal
 // E.n propagates through every phase).
-template <int KIND, int NFIX>
+// POLICY: what `call_actions` holds (ce_step_policy, contracts_engine.h: CE_POLICY_*).  0 = the action ids themselves (every
+// other entry point); CE_POLICY_BYTES_MOD = one policy byte per agent, action = byte mod |A|; CE_POLICY_ARGMAX_F32 = |A| float
+// scores per agent, action = index of the first maximum (Gumbel-max sampling when the policy adds the noise).  The action a
+// policy step took is written to `actions_taken`.  Separate instances: the plain step kernel sits exactly at its 64 VGPRs.
+template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, size_t ea, u32 lane, bool is_agent, u32 A) {
+  if (POLICY == CE_POLICY_BYTES_MOD) {
+    const u32 b = is_agent ? (u32)GAT((CE_GPTR(const uint8_t))src + ea, lane) : 4u;
+    return A == 8u ? (b & 7u) : A == 7u ? b % 7u : A == 9u ? b % 9u : b % A;
+  }
+  // CE_POLICY_ARGMAX_F32: scores [E][n][A]; strict '>' keeps the first maximum, a NaN never wins
+  const auto sc = (CE_GPTR(const float))src + ea * A;
+  const u32 row = __umul24(is_agent ? lane : 0u, A);
+  float best = GAT(sc, row);
+  u32 arg = 0;
+#pragma unroll
+  for (u32 k = 1; k < 9u; ++k) {
+    const float v = GAT(sc, row + (k < A ? k : 0u));
+    if (k < A && (v > best || best != best)) {
+      best = v;
+      arg = k;
+    }
+  }
+  return is_agent ? arg : 4u;
+}
+
+template <int KIND, int NFIX, int POLICY = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(
     const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
     uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
@@ -2306,7 +2331,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
 
   // the action load is in flight together with the state loads; it is validated before anything is written
-  u32 ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
+  u32 ACT;
+  if (POLICY == 0) {
+    ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
+  } else {
+    const u32 A = (KIND == CE_KIND_CLEANUP ? 8u : 7u) + ((p.flags & CE_FLAG_FIRING_ENABLED) ? 1u : 0u);
+    ACT = policy_action<POLICY>(call_actions, ea, lane, E.is_agent, A);
+    if (E.is_agent) GAT(p.actions_taken + ea, lane) = (uint8_t)ACT;
+  }
   CE_STAMP(0);
   CE_REALSTAMP(14);
   load_env_state(E, ph);
@@ -3714,6 +3746,28 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
     if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_HARVEST, 8);
     else CE_STEP_LAUNCH(CE_KIND_HARVEST, 0);
   }
+#undef CE_STEP_LAUNCH
+}
+
+// ce_step_policy: the same launch with the action taken from the policy's output inside the kernel (p.actions = that output)
+void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams& p, const GridParams* dp, void* stream) {
+  const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
+  dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+#define CE_STEP_LAUNCH(K_, N_, P_)                                                                                      \
+  hipLaunchKernelGGL((k_grid_step<K_, N_, P_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+                     (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
+#define CE_STEP_POLICY(P_)                                         \
+  do {                                                             \
+    if (kind == CE_KIND_CLEANUP) { /* generic n: the n = 8 policy instance spills (10 VGPRs), the generic one does not */ \
+      CE_STEP_LAUNCH(CE_KIND_CLEANUP, 0, P_);                      \
+    } else {                                                       \
+      if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_HARVEST, 8, P_);        \
+      else CE_STEP_LAUNCH(CE_KIND_HARVEST, 0, P_);                 \
+    }                                                              \
+  } while (0)
+  if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY(CE_POLICY_BYTES_MOD);
+  else CE_STEP_POLICY(CE_POLICY_ARGMAX_F32);
+#undef CE_STEP_POLICY
 #undef CE_STEP_LAUNCH
 }
 

@@ -27,7 +27,7 @@ _FIELD_DTYPES = {
     "base_reward": np.int32, "reward": np.float64, "done": np.uint8, "done_agents": np.uint8, "info": np.uint8,
     "features": np.int16, "int_metrics": np.int64, "f64_metrics": np.float64, "final_int_metrics": np.int64,
     "final_f64_metrics": np.float64, "error_flags": np.uint32, "debug": np.uint64,
-    "beam_map": np.uint8, "sd_info": np.float64,
+    "beam_map": np.uint8, "sd_info": np.float64, "actions_taken": np.uint8,
 }
 
 
@@ -216,6 +216,54 @@ class BatchedEnv:
         check(self._L.ce_step_range(self._h, actions_ptr, active_ptr, int(env_begin), int(env_count), stream), self._h,
               "ce_step_range")
 
+    def step_policy_device(self, policy_ptr, mode, env_begin=0, env_count=None, stream=None):
+        """ce_step_policy: step envs [env_begin, env_begin + env_count) with the action selection fused into the step kernel —
+        mode "bytes" (uint8 [E, n], action = byte mod |A|) or "argmax" (float32 [E, n, |A|] scores, first maximum); the
+        ids taken land in `actions_taken`"""
+        self._dirty()
+        m = {"bytes": _lib.POLICY_BYTES_MOD, "argmax": _lib.POLICY_ARGMAX_F32}[mode]
+        cnt = self.E - env_begin if env_count is None else env_count
+        check(self._L.ce_step_policy(self._h, policy_ptr, m, int(env_begin), int(cnt), stream), self._h, "ce_step_policy")
+
+    # ---- host boundary helpers (page-locked staging, asynchronous copies, threaded format conversion) ------------
+    def host_alloc(self, shape, dtype):
+        """page-locked host array (ce_host_alloc): the DMA target of download_async / source of step_host_async; freed
+        when the array is garbage collected"""
+        import weakref
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        check(self._L.ce_host_alloc(max(nbytes, 1), C.byref(p)), self._h, "ce_host_alloc")
+        raw = (C.c_ubyte * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(raw, np.uint8, nbytes).view(dt).reshape(shape)
+        weakref.finalize(raw, self._L.ce_host_free, p.value)  # `arr` keeps `raw` alive through its base chain
+        return arr
+
+    def download_async(self, field, dst, env_begin=0, env_count=None, stream=None):
+        """field slice -> dst (page-locked array) on `stream`, no host synchronization; synchronize(stream) completes it"""
+        cnt = self.E - env_begin if env_count is None else env_count
+        check(self._L.ce_download_async(self._h, field.encode(), int(env_begin), int(cnt), dst.ctypes.data, dst.nbytes, stream),
+              self._h, "ce_download_async(%s)" % field)
+
+    def step_host_async(self, actions, env_begin=0, env_count=None, stream=None):
+        """ce_step_host_async: `actions` is a page-locked uint8 [E, n] plane that stays untouched until the stream has
+        passed the copy"""
+        self._dirty()
+        cnt = self.E - env_begin if env_count is None else env_count
+        check(self._L.ce_step_host_async(self._h, actions.ctypes.data, int(env_begin), int(cnt), stream), self._h,
+              "ce_step_host_async")
+
+    def obs_u8_to_f64(self, pitched, out, threads):
+        """pitched uint8 observation rows (as downloaded raw) -> float64 [envs, n, 15, 15, 3] = value / 255 on `threads`
+        host threads (the GIL is released for the duration)"""
+        b = self.b
+        envs = pitched.size // b.obs_env_stride
+        check(self._L.ce_obs_u8_to_f64(pitched.ctypes.data, out.ctypes.data, envs, self.n, b.obs_env_stride, b.obs_agent_stride,
+                                       b.obs_row_stride, int(threads)), self._h, "ce_obs_u8_to_f64")
+
+    def i16_to_f64(self, src, out, threads):
+        check(self._L.ce_i16_to_f64(src.ctypes.data, out.ctypes.data, src.size, int(threads)), self._h, "ce_i16_to_f64")
+
     def rollout_device(self, actions_ptr, num_steps, stream_handles=None):
         """num_steps consecutive steps from pre-supplied device action planes [T, E, n]; the launch loop runs
         in C.  stream_handles: list of raw HIP stream handles, one env slice per stream (None = null stream)."""
@@ -274,7 +322,7 @@ class BatchedEnv:
             "done_agents": (n,), "info": (n, 2), "features": (n, b.num_features), "int_metrics": (b.num_int_metrics,),
             "f64_metrics": (b.num_f64_metrics,), "final_int_metrics": (b.num_int_metrics,),
             "final_f64_metrics": (b.num_f64_metrics,), "error_flags": (), "debug": (16,),
-            "beam_map": (b.grid_h, b.grid_w), "sd_info": (2,),
+            "beam_map": (b.grid_h, b.grid_w), "sd_info": (2,), "actions_taken": (n,),
         }[field]
 
     def prefetch(self, fields):

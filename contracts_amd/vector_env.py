@@ -16,7 +16,14 @@ Built to stay usable at E = 16 384:
     synchronized horizon (all E envs done in the same tick) costs O(E), not O(E^2).  SIDE EFFECT: a done env the
     caller never asks about is reset as well (RLlib's sampler resets every done sub-env, so it never notices);
     `batch_done_resets=False` resets exactly the env asked for;
-  * `poll_tensors()` / `send_actions_array()` skip Python containers altogether (observations stay in HBM).
+  * `poll_tensors()` / `send_actions_array()` skip Python containers altogether (observations stay in HBM);
+  * grid kinds, `recycle_dicts=True` (the default): the dictionaries of a tick are not rebuilt but RECYCLED.  Two generations
+    of complete dictionary trees ({env: {agent: {"image": ..}}}, rewards, dones, infos) are kept over page-locked snapshot
+    buffers; a tick copies the step's results into the older generation asynchronously (one DMA per field), converts the
+    observations to the reference's float64 on worker threads, and rewrites only the dictionary entries whose values
+    changed (C loops, `csrc/ce_pydict.c`) — ~10 ms per tick at E = 16 384 instead of ~290 ms.  CONTRACT: what `poll()`
+    returned at tick t stays intact through tick t + 1 and is overwritten by tick t + 2 (RLlib copies observations into
+    its sample batches at once; a caller that keeps them longer copies them, or passes `recycle_dicts=False`).
 
 When `ray` is importable the class derives from `ray.rllib.env.BaseEnv`, otherwise it is duck-typed; nothing else in it
 depends on RLlib.  Each sub-env keeps a private RNG stream seeded `seed0 + env_index_base + i` (the batched API's
@@ -138,9 +145,63 @@ class _SubEnvs:
         return (self[e] for e in range(len(self)))
 
 
+def _pydict():
+    """the C loops of the recycled dict protocol (built by contracts_amd.build next to the engine library)"""
+    from . import _ce_pydict
+    return _ce_pydict
+
+
+class _DictGeneration:
+    """one generation of a tick's results on the host: page-locked snapshot buffers, the float64 arrays the dictionaries
+    hand out views of, and the dictionary trees themselves (built once, refreshed in place every second tick)"""
+
+    def __init__(self, venv):
+        eng, E, n, keys = venv.engine, venv.num_envs, venv.num_agents, venv._keys
+        b = eng.b
+        F = b.num_features
+        self.obs_u8 = eng.host_alloc((E, b.obs_env_stride), np.uint8)
+        self.obs_f64 = np.empty((E, n, 15, 15, 3), np.float64)
+        self.float_rewards = venv._float_rewards
+        self.rew = eng.host_alloc((E, n), np.float64 if self.float_rewards else np.int32)
+        self.done = eng.host_alloc((E,), np.uint8)
+        self.info = eng.host_alloc((E, n, 2), np.uint8)
+        self.feat_i16 = eng.host_alloc((E, n, F), np.int16)
+        self.feat_f64 = np.zeros((E, n, F), np.float64)
+        self.err = eng.host_alloc((E,), np.uint32)
+        self.theta = eng.host_alloc((E,), np.float64) if venv.contract else None
+        self.cobs = np.zeros((E, 2), np.float64)    # [theta, 0]: the wrapper's 'contract' observation (two_stage_train.py:104-117)
+        self.cparam = np.zeros((E, 1), np.float64)  # infos[k]['contract_param']
+        # shadows: what the dictionaries currently say
+        self.rew_shadow = np.zeros_like(self.rew)
+        self.done_shadow = np.zeros((E,), np.uint8)
+        self.info_shadow = np.zeros((E, n, 2), np.uint8)
+        second = _SECOND_INFO[venv.kind]
+        contract = bool(venv.contract)
+        zero = 0.0 if self.float_rewards else 0
+        obs_f64, feat_f64, cobs, cparam = self.obs_f64, self.feat_f64, self.cobs, self.cparam
+        self.obs, self.rewards, self.dones, self.infos = {}, {}, {}, {}
+        self.agent_infos = []
+        for e in range(E):
+            img, fe = obs_f64[e], feat_f64[e]
+            if contract:
+                c, cp = cobs[e], cparam[e]
+                self.obs[e] = {k: {"image": img[i], "contract": c} for i, k in enumerate(keys)}
+                inf = {k: {second: 0, "eaten_apples": 0, "feature_obs": fe[i], "contract_param": cp} for i, k in enumerate(keys)}
+            else:
+                self.obs[e] = {k: {"image": img[i]} for i, k in enumerate(keys)}
+                inf = {k: {second: 0, "eaten_apples": 0, "feature_obs": fe[i]} for i, k in enumerate(keys)}
+            self.infos[e] = inf
+            self.agent_infos.extend(inf[k] for k in keys)
+            self.rewards[e] = dict.fromkeys(keys, zero)
+            self.dones[e] = {"__all__": False, "a0": False, "a1": False}  # the reference's dones dict (cleanup_new.py:242)
+        self.reward_list = [self.rewards[e] for e in range(E)]
+        self.done_list = [self.dones[e] for e in range(E)]
+        self.second = second
+
+
 class BatchedBaseEnv(_RLlibBaseEnv):
     def __init__(self, kind, num_envs, num_agents, contract=None, seed0=73907, convolutional=True, batch_done_resets=True,
-                 **engine_kwargs):
+                 recycle_dicts=True, **engine_kwargs):
         self.kind, self.num_envs, self.num_agents = kind, int(num_envs), int(num_agents)
         self.contract = contract
         self.convolutional = convolutional
@@ -157,6 +218,14 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._episode_over = set()                 # envs whose last step ended an episode (metrics: the final rows)
         self._reset_obs = {}                       # env_id -> reset observation (or the lazy map of its reset batch)
         self._acted = None                         # selfdrive: [E, n] which agents acted in the last step
+        # recycled dict protocol (grid kinds): two generations of dictionary trees over page-locked snapshots
+        self._recycle = bool(recycle_dicts) and kind in _GRID
+        self._gens, self._gen = [None, None], 0
+        self._act_planes, self._act_turn = None, 0
+        self._keys_t = tuple(self._keys)
+        self._env_keys = list(range(self.num_envs))
+        self._unchecked_steps = False  # steps issued without a fault check (the fast path checks at poll)
+        self._threads = None
 
     # ---- snapshots: one device -> host copy per field -------------------------------------------------------------
     def _obs_fields(self, env_begin=0, env_count=None):
@@ -239,8 +308,11 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             zero_r = {k: 0.0 for k in self._keys}
             return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: dict(zero_r)),
                     _LazyEnvMap(ids, lambda e: {"__all__": False}), _LazyEnvMap(ids, lambda e: {k: {} for k in self._keys}), {})
+        if self._recycle:
+            return self._poll_recycled()
         ids, self._pending = self._pending, None
         eng = self.engine
+        self._settle_faults()
         snap = self._obs_fields()
         snap["rew"] = eng.download("reward") if self._float_rewards else eng.download("base_reward")
         snap["done"] = eng.download("done")
@@ -278,6 +350,15 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         if len(action_dict) != self.num_envs or any(e not in action_dict for e in range(self.num_envs)):
             raise KeyError("send_actions needs actions for all %d sub-envs in one call" % self.num_envs)
         E, n, keys = self.num_envs, self.num_agents, self._keys
+        if self._recycle and type(action_dict) is dict:
+            # the walk over the E x n action entries in C, into a page-locked plane that the step's stream copies from
+            plane = self._action_plane()
+            _pydict().parse_actions(action_dict, self._env_keys, self._keys_t, plane)
+            self.engine.step_host_async(plane)
+            self._unchecked_steps = True
+            self._episode_over = set()
+            self._pending = self._env_keys
+            return
         if self.kind == "selfdrive":
             a = np.zeros((E, n), np.float32)
             act = np.zeros((E, n), np.uint8)
@@ -295,22 +376,104 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._episode_over = set()  # every env has stepped again: env_metrics() serves the running episode until poll()
         self._pending = list(range(E))
 
+    # ---- recycled dict protocol (see the module docstring) ---------------------------------------------------------
+    def _action_plane(self):
+        """page-locked uint8 [E, n] planes, used in turn: the previous tick's asynchronous upload may still be reading its own"""
+        if self._act_planes is None:
+            self._act_planes = [self.engine.host_alloc((self.num_envs, self.num_agents), np.uint8) for _ in range(3)]
+        self._act_turn = (self._act_turn + 1) % len(self._act_planes)
+        return self._act_planes[self._act_turn]
+
+    def _settle_faults(self):
+        if self._unchecked_steps:
+            self._unchecked_steps = False
+            self.engine.check_faults()
+
+    def _host_threads(self):
+        if self._threads is None:
+            import os
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 2
+            self._threads = max(1, min(16, cores - 1))
+        return self._threads
+
+    def _poll_recycled(self):
+        eng, pd = self.engine, _pydict()
+        self._pending = None
+        g = self._gen = self._gen ^ 1
+        G = self._gens[g]
+        if G is None:
+            G = self._gens[g] = _DictGeneration(self)
+        # small fields first: one asynchronous copy each behind the step on its stream, ONE synchronize for all of them
+        eng.download_async("reward" if G.float_rewards else "base_reward", G.rew)
+        eng.download_async("done", G.done)
+        eng.download_async("info", G.info)
+        eng.download_async("features", G.feat_i16)
+        eng.download_async("error_flags", G.err)
+        if G.theta is not None:
+            eng.download_async("theta", G.theta)
+        eng.synchronize()
+        # the observations (most of the bytes) travel and are converted on worker threads while this thread refreshes the
+        # dictionaries: DMA into the page-locked block, then value / 255 -> float64 across the host cores
+        eng.download_async("obs", G.obs_u8)
+        T = self._host_threads()
+
+        def finish_obs():
+            eng.synchronize()
+            eng.obs_u8_to_f64(G.obs_u8, G.obs_f64, T)
+
+        job = _pool().submit(finish_obs)
+        try:
+            self._unchecked_steps = False
+            if G.err.any():
+                bad = np.nonzero(G.err)[0]
+                raise _lib.EngineError("env faults: %s" % {int(i): int(G.err[i]) for i in bad[:8]})
+            eng.i16_to_f64(G.feat_i16, G.feat_f64, 2)
+            if G.theta is not None:
+                G.cobs[:, 0] = G.theta
+                G.cparam[:, 0] = G.theta
+            if G.float_rewards:
+                pd.refresh_floats(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
+            else:
+                pd.refresh_ints(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
+            pd.refresh_infos(G.agent_infos, "eaten_apples", G.second, G.info, G.info_shadow)
+            pd.refresh_dones(G.done_list, ("__all__", "a0", "a1"), G.done, G.done_shadow)
+            self._done_ids = {int(e) for e in np.nonzero(G.done)[0]}
+            self._episode_over = set(self._done_ids)
+            self._reset_obs = {}
+        finally:
+            job.result()
+        return G.obs, G.rewards, G.dones, G.infos, {}
+
     def send_actions_array(self, actions, active=None):
         """the same tick from a dense [E, n] array (uint8 action ids / float32 accelerations): no per-env containers"""
         if self.kind == "selfdrive":
             self._acted = (1 - self.engine.download("done_agents")) if active is None else np.asarray(active, np.uint8)
             self.engine.step(actions, self._acted)
+            self.engine.check_faults()
         else:
-            self.engine.step(actions)
-        self.engine.check_faults()
+            # staged through a page-locked plane and issued asynchronously: no host synchronization in the tick (a fault —
+            # an action id outside the table — is reported by the next poll() / check_faults())
+            plane = self._action_plane()
+            np.copyto(plane, np.asarray(actions).reshape(plane.shape), casting="unsafe")
+            self.engine.step_host_async(plane)
+            self._unchecked_steps = True
         self._episode_over = set()
-        self._pending = list(range(self.num_envs))
+        self._pending = self._env_keys
 
     def poll_tensors(self):
         """zero-copy torch views of the engine's output buffers (observations stay in HBM) — what a GPU-resident sampler
-        reads instead of poll(); valid until the next send_actions / try_reset"""
+        reads instead of poll(); valid until the next send_actions / try_reset.  Issues no synchronization: work queued on the
+        caller's stream after this (torch ops on the default stream) is ordered behind the step; `check_faults()` on demand"""
         self._pending = None
         return self.engine.torch_tensors()
+
+    def check_faults(self):
+        """raise if any sub-env reported a fault (bad action id, ...) since the last check; synchronizes the device"""
+        self._unchecked_steps = False
+        self.engine.check_faults()
 
     def try_reset(self, env_id=None):
         """reset observation(s) {env_id: obs}.  The first call after a tick resets every env that reported done (plus the

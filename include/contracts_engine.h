@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CE_ABI_VERSION 2
+#define CE_ABI_VERSION 3
 
 /* error codes */
 #define CE_OK 0
@@ -179,6 +179,8 @@ typedef struct ce_buffers {
                             (…accelerate.py:183-189, update_infos :127-149, crash branch :203-204): {ambulance_rank,
                             ambulance_dist_to_front}; every other key carries 0.0 there.  Together with `info`
                             ({just_passed, is_crashed}) this is the whole infos dict of a selfdrive step               */
+  uint8_t* actions_taken; /* grid kinds: [E][n] the action ids the last ce_step_policy launch derived from the policy's output
+                             (ABI 3; untouched by every other entry point)                                             */
 } ce_buffers;
 
 #define CE_BEAM_NONE 0
@@ -304,6 +306,18 @@ int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* strea
 int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count,
                   void* stream);
 
+/* ce_step_range with the action SELECTION fused into the step kernel's action load: `policy_out` is what the caller's policy
+ * kernel left on the device, and a sampler tick is "one policy kernel + one step launch" with no argmax / modulo / cast
+ * kernels in between (bench.py closed_loop; the sampler loop this stands in for: utils/ray_config_utils.py:126-214).
+ *   CE_POLICY_BYTES_MOD   uint8 [E][n]: action = byte mod |A|  (|A| = 8 cleanup / 7 harvest, + 1 with CE_FLAG_FIRING_ENABLED)
+ *   CE_POLICY_ARGMAX_F32  float [E][n][|A|] scores: action = index of the first maximum (NaNs never win) — exact categorical
+ *                         sampling when the policy adds Gumbel noise to its logits, greedy otherwise
+ * The action ids taken are written to ce_buffers.actions_taken (the sampler needs them for its batch).  Grid kinds only
+ * (CE_EINVAL otherwise); slices, streams and graph capture exactly as ce_step_range. */
+#define CE_POLICY_BYTES_MOD 1
+#define CE_POLICY_ARGMAX_F32 2
+int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream);
+
 /* Launch loop in C for pre-supplied actions (benchmarks, random-policy rollouts): `num_steps` consecutive
  * steps over all envs, each issued as `num_slices` ce_step_range launches on streams[0..num_slices-1] (NULL =
  * all on the null stream).  actions: DEVICE pointer to [num_steps][E][n] planes.  Every step is still its own
@@ -362,7 +376,7 @@ int ce_synchronize(ce_handle h, void* stream);
 /* Host copies (stream-synchronous helpers for tests / adapters without torch).
  * field names: "grid","agents","spawn_perm","waste_perm","rng","timestep","theta","sd_state",
  * "obs","obs_f64","base_reward","reward","done","done_agents","info","features",
- * "int_metrics","f64_metrics","final_int_metrics","final_f64_metrics","error_flags","beam_map","sd_info".
+ * "int_metrics","f64_metrics","final_int_metrics","final_f64_metrics","error_flags","beam_map","sd_info","actions_taken".
  * env_begin/env_count select a slice of the env axis; dst/src are host pointers. */
 int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
 int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);
@@ -378,6 +392,26 @@ typedef struct ce_field_req {
 /* (uses a per-handle staging buffer: like every entry point taking a handle, not to be called from two threads on the
  * same handle at once) */
 int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const ce_field_req* reqs, uint32_t count);
+
+/* ---- host boundary helpers: what a host-side sampler (the RLlib vector hook, contracts_amd/vector_env.py) needs to take a
+ * tick's results off the device without a synchronize per field and without pageable staging ----
+ * ce_host_alloc / ce_host_free: page-locked host memory (DMA target of the asynchronous copies below).
+ * ce_download_async: the field's env slice -> dst on `stream`, no host synchronization: ordered after the launches already
+ *   issued on that stream, complete once the caller has synchronized the stream (ce_synchronize).  dst should be page-locked.
+ * ce_step_host_async: ce_step_range with a HOST action plane (uint8 [E][n], page-locked): the slice's bytes are copied on
+ *   `stream` ahead of its step launch and the call returns at once — the plane must stay untouched until the stream has
+ *   passed the copy (double-buffer it).
+ * ce_obs_u8_to_f64: format conversion on the host, `threads` worker threads: the pitched uint8 observation block (as
+ *   downloaded: ce_buffers.obs strides) -> the reference's float64 images value / 255 (cleanup_new.py:258,
+ *   harvest_new.py:229), dense [envs][n][15][15][3]. */
+int ce_host_alloc(uint64_t bytes, void** out);
+int ce_host_free(void* p);
+int ce_download_async(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes,
+                      void* stream);
+int ce_step_host_async(ce_handle h, const void* host_actions, uint32_t env_begin, uint32_t env_count, void* stream);
+int ce_i16_to_f64(const int16_t* src, double* out, uint64_t count, uint32_t threads); /* feature rows -> feature_obs floats */
+int ce_obs_u8_to_f64(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
+                     uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads);
 
 /* Timing of the last N ce_step launches measured with HIP events on the launch stream
  * (bench.py roofline leg).  ce_timing_begin arms recording, ce_timing_end returns the mean

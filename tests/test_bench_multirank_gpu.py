@@ -93,8 +93,10 @@ def test_bench_default_line_has_every_config():
     assert abs(row["fused"]["launches_per_step"] - 3 / 16.0) < 1e-9
     cl = row["closed_loop"]
     assert cl["value"] > 0 and cl["host_iterations_per_step"] == 1 and cl["timed_seconds"] >= 0.5 and "eager" in cl["modes"]
+    assert {"policy_eager", "policy_graph"} <= set(cl["modes"]) and cl["modes"]["policy_eager"]["host_calls_per_step"] == 6
     bd = row["boundary"]
-    assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > 0
+    assert "error" not in bd, bd
+    assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > bd["dict_protocol_rebuilt"]["value"] > 0
     # the counter-RNG rows sit beside the line, never in it: the headline's rng is the reference's
     assert row["config"]["rng"] == "mt19937-numpy-compat"
     cr = row["counter_rng"]

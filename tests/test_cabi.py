@@ -26,7 +26,7 @@ def test_header_functions_exported():
     for name in names:
         assert hasattr(L, name), "library does not export %s" % name
         assert name in _lib.EXPORTS, "ctypes table misses %s" % name
-    assert L.ce_abi_version() == 2
+    assert L.ce_abi_version() == _lib.CE_ABI_VERSION == 3
 
 
 def test_struct_layout_matches_ctypes():
@@ -39,6 +39,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ce_config), offsetof(ce_config, env_index_base),
          offsetof(ce_config, contract_low), offsetof(ce_config, start_vel_ambulance), sizeof(ce_buffers),
          offsetof(ce_buffers, grid), offsetof(ce_buffers, error_flags));
+  printf("%zu ", offsetof(ce_buffers, actions_taken));
   printf("%zu %zu %zu %zu %zu %d\n", offsetof(ce_buffers, sd_info), sizeof(ce_traj), offsetof(ce_traj, obs),
          offsetof(ce_traj, features), offsetof(ce_traj, sd_info), CE_ABI_VERSION);
   return 0;
@@ -52,7 +53,7 @@ int main(void) {
     cfg, buf, traj = _lib.CeConfig, _lib.CeBuffers, _lib.CeTraj
     want = [C.sizeof(cfg), cfg.env_index_base.offset, cfg.contract_low.offset, cfg.start_vel_ambulance.offset,
             C.sizeof(buf), buf.grid.offset, buf.error_flags.offset,
-            buf.sd_info.offset, C.sizeof(traj), traj.obs.offset, traj.features.offset, traj.sd_info.offset, _lib.CE_ABI_VERSION]
+            buf.actions_taken.offset, buf.sd_info.offset, C.sizeof(traj), traj.obs.offset, traj.features.offset, traj.sd_info.offset, _lib.CE_ABI_VERSION]
     assert got == want
 
 

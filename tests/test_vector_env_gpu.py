@@ -120,12 +120,12 @@ def test_base_env_protocol_selfdrive_matches_oracle():
 @pytest.mark.gpu
 def test_vector_hook_scales_to_the_headline_batch():
     """E = 16 384 sub-envs (cleanup n = 8 + contract) through the dict protocol, every env's observation / reward / done /
-    info dictionary materialised each tick, and a synchronized horizon where all E envs are reset through per-env
-    try_reset calls: the host side sustains ~60 k env-steps/s on an idle box and the reset storm must cost O(E) (one masked
-    launch + one copy for the whole batch)."""
+    info dictionary in the caller's hands each tick, and a synchronized horizon where all E envs are reset through per-env
+    try_reset calls: the recycled dictionaries (the default) sustain >= 1 M env-steps/s on an idle box, and the reset storm
+    must cost O(E) (one masked launch + one copy for the whole batch)."""
     import time
     from contracts_amd.vector_env import BatchedBaseEnv
-    E, n, horizon = 16384, 8, 4
+    E, n, horizon = 16384, 8, 6
     venv = BatchedBaseEnv("cleanup", E, n, contract="cleanup", horizon=horizon)
     keys = ["a%d" % i for i in range(n)]
     obs, _, _, _, _ = venv.poll()
@@ -133,7 +133,7 @@ def test_vector_hook_scales_to_the_headline_batch():
     rs = np.random.RandomState(0)
     acts = rs.randint(8, size=(horizon, E, n))
     for t in range(horizon):
-        if t == 1:  # the first tick warms up (worker threads, allocator); the steady state is what is timed
+        if t == 2:  # the first two ticks build the two dictionary generations; the steady state is what is timed
             t0 = time.perf_counter()
         venv.send_actions({e: dict(zip(keys, acts[t, e].tolist())) for e in range(E)})
         obs, rew, dones, infos, _ = venv.poll()
@@ -141,7 +141,7 @@ def test_vector_hook_scales_to_the_headline_batch():
         for e, ob in obs.items():  # what RLlib's sampler does: walk every env of the tick
             touched += ob["a0"]["image"].shape[0] + len(rew[e]) + len(infos[e]) + int(dones[e]["__all__"])
     dt = time.perf_counter() - t0
-    rate = (horizon - 1) * E / dt
+    rate = (horizon - 2) * E / dt
     assert all(dones[e]["__all__"] for e in range(E))  # the synchronized horizon
     launches_before = venv.engine.download("timestep").max()
     t1 = time.perf_counter()
@@ -151,9 +151,9 @@ def test_vector_hook_scales_to_the_headline_batch():
     dt_reset = time.perf_counter() - t1
     assert venv.engine.download("timestep").max() == 0 and launches_before == horizon
     print("vector hook: %.0f env-steps/s through the dict protocol; reset storm of %d envs %.3f s" % (rate, E, dt_reset))
-    assert rate >= 25000, rate  # measured 62 k on an idle box (target 50 k); a correctness gate against O(E^2) host work,
-    # not a benchmark: the margin is for a loaded host
-    assert dt_reset < 8 * (dt / (horizon - 1)), (dt_reset, dt / (horizon - 1))  # O(E): comparable to a tick, not E ticks
+    assert rate >= 150000, rate  # a gate against per-entry Python work creeping back in (the action dictionaries of this loop
+    # are themselves built in Python, ~15 ms per tick), not a benchmark: bench.py's boundary section reports the rate
+    assert dt_reset < 1.0, dt_reset  # O(E): a few hundred lazily built observation dictionaries per 10 ms, not E launches
     # the tensor path: no Python containers at all
     t2 = time.perf_counter()
     for t in range(20):
@@ -445,3 +445,68 @@ def test_try_reset_batching_is_optional_and_metrics_follow_the_tick():
         venv.poll()
         assert "equality" not in venv.env_metrics(2)
         venv.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,contract", [("cleanup", 8, "cleanup"), ("harvest", 3, None), ("cleanup", 2, None)])
+def test_recycled_dict_protocol_equals_the_rebuilt_one(kind, n, contract):
+    """recycle_dicts=True (dictionary trees kept over page-locked snapshots, refreshed in place by the C loops) hands out,
+    tick for tick, what recycle_dicts=False builds from scratch — same keys in the same order, same value types, equal
+    values — and what poll() returned at tick t is still intact at tick t + 1 (the two-generation contract)"""
+    from contracts_amd.vector_env import BatchedBaseEnv
+    E, T, horizon = 70, 45, 13
+    kw = dict(contract=contract, seed0=321, horizon=horizon, firing=True)
+    fast, slow = BatchedBaseEnv(kind, E, n, recycle_dicts=True, **kw), BatchedBaseEnv(kind, E, n, recycle_dicts=False, **kw)
+    keys = ["a%d" % i for i in range(n)]
+    rs = np.random.RandomState(4)
+    na = fast.engine.num_actions
+
+    def same_tree(a, b, path=""):
+        assert type(a) is type(b) or (isinstance(a, (float, np.floating)) and isinstance(b, (float, np.floating))), (path, type(a), type(b))
+        if isinstance(a, dict):
+            assert list(a) == list(b), (path, list(a), list(b))
+            for k in a:
+                same_tree(a[k], b[k], "%s/%s" % (path, k))
+        elif isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), path
+        else:
+            assert a == b, (path, a, b)
+
+    for v in (fast, slow):
+        v.poll()
+    held = None
+    for t in range(T):
+        a = rs.randint(na, size=(E, n))
+        ad = {e: {k: int(a[e, i]) for i, k in enumerate(keys)} for e in range(E)}
+        fast.send_actions(ad)
+        slow.send_actions(ad)
+        fo, fr, fd, fi, _ = fast.poll()
+        so, sr, sd, si, _ = slow.poll()
+        assert type(fo) is dict and sorted(fo) == list(range(E))
+        for e in range(E):
+            same_tree(fo[e], so[e], "obs/%d" % e)
+            same_tree(fr[e], sr[e], "rew/%d" % e)
+            same_tree(fd[e], sd[e], "done/%d" % e)
+            same_tree(fi[e], si[e], "info/%d" % e)
+        if held is not None:  # last tick's dictionaries were not touched by this tick
+            (ho, hr, hd, hi), (co, cr, cd, ci) = held
+            for e in (0, E // 2, E - 1):
+                same_tree(ho[e], co[e], "held obs")
+                same_tree(hr[e], cr[e], "held rew")
+                same_tree(hi[e], ci[e], "held info")
+            assert ho is not fo
+        import copy
+        held = ((fo, fr, fd, fi), tuple(copy.deepcopy({e: m[e] for e in (0, E // 2, E - 1)}) for m in (fo, fr, fd, fi)))
+        done_ids = [e for e in range(E) if fd[e]["__all__"]]
+        assert done_ids == [e for e in range(E) if sd[e]["__all__"]]
+        for e in done_ids:
+            same_tree(fast.try_reset(e)[e], slow.try_reset(e)[e], "reset/%d" % e)
+    # a bad action id surfaces at the poll of the recycled path (the step itself is asynchronous)
+    from contracts_amd._lib import EngineError
+    bad = {e: dict.fromkeys(keys, 0) for e in range(E)}
+    bad[3]["a0"] = 200
+    fast.send_actions(bad)
+    with pytest.raises(EngineError):
+        fast.poll()
+    fast.stop()
+    slow.stop()
