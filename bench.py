@@ -328,7 +328,7 @@ class Runner:
         del self.acts
 
 
-def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
+def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
     """The RL-usable rate: one host iteration per env-step.  The batch is `num_slices` independent env slices, each with
     its own HIP stream; per slice and step, torch computes the actions ON THE DEVICE from the observation the previous
     step of that slice wrote (the pixel in front of every agent, accumulated into a resident noise plane so the action
@@ -397,11 +397,16 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
         return {"value": E * n * K / med, "ms_per_step": med / K * 1e3, "steps": K, "repeats": len(elapsed),
                 "timed_seconds": sum(elapsed)}
 
-    modes = {"eager": dict(timed(eager_tick), host_calls_per_step=3 * S, host_iterations_per_step=1, launches_per_slice_and_step=3),
-             "policy_eager": dict(timed(lambda: eager_tick(slice_tick_policy)), host_calls_per_step=2 * S, host_iterations_per_step=1,
-                                  launches_per_slice_and_step=2)}
+    modes = {}
+    if only is None or "eager" in only:
+        modes["eager"] = dict(timed(eager_tick), host_calls_per_step=3 * S, host_iterations_per_step=1, launches_per_slice_and_step=3)
+    if only is None or "policy_eager" in only:
+        modes["policy_eager"] = dict(timed(lambda: eager_tick(slice_tick_policy)), host_calls_per_step=2 * S,
+                                     host_iterations_per_step=1, launches_per_slice_and_step=2)
     for name, ticks, tick_fn in (("graph", 1, slice_tick), ("graph16", 16, slice_tick), ("policy_graph", 1, slice_tick_policy),
                                  ("policy_graph16", 16, slice_tick_policy)):
+        if only is not None and name not in only:
+            continue
         try:  # one hipGraph per slice, replayed on the slice's stream
             graphs = []
             for st, (b0, b1) in zip(streams, bounds):
@@ -422,7 +427,7 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5):
                                launches_per_slice_and_step=2 if tick_fn is slice_tick_policy else 3)
         except Exception as exc:  # capture support differs between ROCm builds: the eager figure stands
             modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    best = max((m for m in ("eager", "graph", "policy_eager", "policy_graph") if "value" in modes[m]), key=lambda m: modes[m]["value"])
+    best = max((m for m in ("eager", "graph", "policy_eager", "policy_graph") if "value" in modes.get(m, {})), key=lambda m: modes[m]["value"])
     out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
                policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
                       "byte, accumulated) mod %d — eager / graph: two elementwise kernels + the step per slice and tick; policy_*: "
@@ -513,7 +518,7 @@ def boundary(wl, E, device_index):
     dt = time.perf_counter() - t0
     out["dict_protocol"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "env_steps_per_s": E * steps / dt,
                             "ms_per_step": dt / steps * 1e3, "steps": steps, "host_threads": venv._host_threads(),
-                            "ms_building_action_dicts_not_timed": ms_build,
+                            "ms_building_action_dicts_not_timed": ms_build, "last_tick_ms": dict(venv.tick_timing),
                             "what": "send_actions(pre-built {env: {agent: action}}) + poll with every env's obs (float64 image views) / "
                                     "reward / done / info dictionaries in hand and walked; recycled dictionary trees over page-locked "
                                     "snapshots (vector_env.py), observations converted to float64 on the host threads every tick"}
@@ -646,7 +651,21 @@ def run_rank(a):
 
     if out is not None and world == 1 and not custom:
         if not a.no_closed_loop:
-            out["closed_loop"] = extra(closed_loop, WORKLOADS["C4"], E, local_rank, a.streams)
+            out["closed_loop"] = cl = extra(closed_loop, WORKLOADS["C4"], E, local_rank, a.streams)
+            # the same loop cut into 2 / 4 slices (one graph replay per slice and tick: fewer slices = fewer host calls per
+            # tick, more slices = more overlap on the device); `value` stays with the headline's slice count unless one of
+            # these one-host-iteration-per-step rows beats it
+            sweep = {}
+            for S2 in (2, 4):
+                if S2 == a.streams or "error" in cl:
+                    continue
+                r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5, ("policy_graph", "policy_graph16"))
+                sweep[str(S2)] = {m: {k: v[k] for k in ("value", "ms_per_step", "host_calls_per_step") if k in v}
+                                  for m, v in r2.get("modes", {}).items()} if "error" not in r2 else r2
+                if "error" not in r2 and r2["value"] > cl["value"]:
+                    cl.update({k: r2[k] for k in ("value", "ms_per_step", "steps", "repeats", "timed_seconds", "host_calls_per_step",
+                                                  "host_iterations_per_step", "issue", "slices")})
+            cl["slices_sweep"] = sweep
         if not a.no_boundary:
             out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
         if not a.no_counter_rng:

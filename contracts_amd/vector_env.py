@@ -226,6 +226,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._env_keys = list(range(self.num_envs))
         self._unchecked_steps = False  # steps issued without a fault check (the fast path checks at poll)
         self._threads = None
+        self.tick_timing = {}  # where the last recycled tick's host time went (ms), for bench.py's boundary section
 
     # ---- snapshots: one device -> host copy per field -------------------------------------------------------------
     def _obs_fields(self, env_begin=0, env_count=None):
@@ -352,9 +353,12 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         E, n, keys = self.num_envs, self.num_agents, self._keys
         if self._recycle and type(action_dict) is dict:
             # the walk over the E x n action entries in C, into a page-locked plane that the step's stream copies from
+            import time
+            t0 = time.perf_counter()
             plane = self._action_plane()
             _pydict().parse_actions(action_dict, self._env_keys, self._keys_t, plane)
             self.engine.step_host_async(plane)
+            self.tick_timing["send_actions_ms"] = (time.perf_counter() - t0) * 1e3
             self._unchecked_steps = True
             self._episode_over = set()
             self._pending = self._env_keys
@@ -400,7 +404,9 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         return self._threads
 
     def _poll_recycled(self):
+        import time
         eng, pd = self.engine, _pydict()
+        tm, t0 = self.tick_timing, time.perf_counter()
         self._pending = None
         g = self._gen = self._gen ^ 1
         G = self._gens[g]
@@ -415,14 +421,23 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         if G.theta is not None:
             eng.download_async("theta", G.theta)
         eng.synchronize()
+        t1 = time.perf_counter()
         # the observations (most of the bytes) travel and are converted on worker threads while this thread refreshes the
-        # dictionaries: DMA into the page-locked block, then value / 255 -> float64 across the host cores
-        eng.download_async("obs", G.obs_u8)
+        # dictionaries: DMA into the page-locked block in a few chunks, chunk i + 1 in flight while chunk i is converted
+        # (value / 255 -> float64 across the host cores)
         T = self._host_threads()
+        E = self.num_envs
+        cuts = [E * i // 4 for i in range(5)] if E >= 1024 else [0, E]
 
         def finish_obs():
-            eng.synchronize()
-            eng.obs_u8_to_f64(G.obs_u8, G.obs_f64, T)
+            ta = time.perf_counter()
+            eng.download_async("obs", G.obs_u8[cuts[0]:cuts[1]], cuts[0], cuts[1] - cuts[0])
+            for i in range(len(cuts) - 1):
+                eng.synchronize()
+                if i + 2 < len(cuts):
+                    eng.download_async("obs", G.obs_u8[cuts[i + 1]:cuts[i + 2]], cuts[i + 1], cuts[i + 2] - cuts[i + 1])
+                eng.obs_u8_to_f64(G.obs_u8[cuts[i]:cuts[i + 1]], G.obs_f64[cuts[i]:cuts[i + 1]], T)
+            tm["obs_copy_and_convert_ms"] = (time.perf_counter() - ta) * 1e3
 
         job = _pool().submit(finish_obs)
         try:
@@ -443,8 +458,12 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             self._done_ids = {int(e) for e in np.nonzero(G.done)[0]}
             self._episode_over = set(self._done_ids)
             self._reset_obs = {}
+            t2 = time.perf_counter()
         finally:
             job.result()
+        t3 = time.perf_counter()
+        tm["step_and_small_fields_ms"], tm["refresh_dicts_ms"], tm["wait_for_obs_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
+        tm["poll_ms"] = (t3 - t0) * 1e3
         return G.obs, G.rewards, G.dones, G.infos, {}
 
     def send_actions_array(self, actions, active=None):
