@@ -46,6 +46,19 @@ constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = f
 }  // namespace ce
 #endif
 
+// -DCE_DUO_STAMPS (tools/duo_profile.py, never shipped): s_memtime stamps of the two waves of k_grid_step_duo into GridParams.debug
+#ifdef CE_DUO_STAMPS
+#define CE_DSTAMP(dbg_, k_)                                          \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    if (lane == 0 && (dbg_)) (dbg_)[(k_)] = t_;                      \
+  } while (0)
+#else
+#define CE_DSTAMP(dbg_, k_) ((void)0)
+#endif
+
 namespace ce {
 // This file is compiled twice.  The second translation unit (ce_grid_kernels_ctr.hip: -DCE_RNG_COUNTER) holds the grid kernels of
 // the counter-RNG mode (CE_FLAG_RNG_COUNTER, contracts_engine.h): same step logic, the env's random stream comes from
@@ -532,11 +545,14 @@ DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
 // index i0 - a; draws are scattered to J[index] in LDS.  The short segments below 32 cost a whole vector round
 // each, so they take the one-draw-per-ballot walk instead (3 VALU per draw), collecting J[i] in lane i.
 // Returns with r advanced past every consumed word.
-DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
+// `cancel` (duo helper only): an LDS word that turns 2 when the caller's speculative work is known to be unwanted — polled once
+// per batch of cached words, the walk is abandoned (its results are never read then).
+DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane, const volatile u32* cancel = nullptr) {
   constexpr u32 kVecMin = 8;
   rng_assert_uniform(r);
   u32 i0 = len - 1;
   while (i0 >= kVecMin) {
+    if (cancel != nullptr && rfl(*cancel) == 2u) return;
     const u32 lo = 1u << (31 - __builtin_clz(i0));  // segment [lo, i0] shares mask 2*lo - 1
     const u32 mask = 2 * lo - 1;
     u32 off = r.pos - r.cbase;
@@ -666,6 +682,14 @@ DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
   shuffle_small<0>(r, L0, len, lane);
 }
 
+// hand-over words of a two-wave workgroup (k_grid_step_duo), in LDS
+struct alignas(16) DuoX {
+  u32 agents[12];           // main -> helper: padded cell | orientation << 16 of agent a (after update_moves)
+  u32 rng_pos, rng_twists;  // helper -> main: its copy of the stream after the waste shuffle
+  u32 need;                 // main -> helper: 0 = not known yet, 1 = the waste list is shuffled this step, 2 = it is not
+  u32 pad;
+};
+
 // ----------------------------------------------------------------------------------------
 // per-wave LDS
 // ----------------------------------------------------------------------------------------
@@ -719,6 +743,9 @@ template <int KIND> struct Env {
   u32 WS[2];
   unsigned long long* dbg;  // diagnostic builds only
   bool waste_perm_dirty;    // the persistent waste list was shuffled in this launch
+  // two-wave workgroups (k_grid_step_duo): the helper wave's LDS block and the hand-over words; null otherwise
+  WaveLds<KIND>* LH;
+  struct DuoX* X;
 };
 
 DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-index deltas
@@ -803,7 +830,7 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   }
   if (rfl(E.rng.twists) != 0 && !diag::ablate_twist) {  // the key words only change at a twist; otherwise just the position moves
     uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngRow);
-    const uint4* src = (const uint4*)E.L->mt;
+    const uint4* src = (const uint4*)E.rng.mt;  // (a duo workgroup may have adopted the helper wave's copy of the stream)
     const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
     const uint4 r0 = src[E.lane], r1 = src[E.lane + 64], r2 = src[q2];
     dst[E.lane] = r0;
@@ -1243,7 +1270,10 @@ DEVINL bool below_hi(u32 a_tempered, u64 thr, bool& tie) {
 }
 DEVINL bool below_lo(u32 b_raw, u64 thr) { return (mt_temper(b_raw) >> 6) < ((u32)thr & 0x3ffffffu); }
 
-template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
+// DUO (k_grid_step_duo): the waste-list shuffle — draws and list update, the longest stretch of a step that shuffles — has
+// been computed by the workgroup's helper wave on its own copy of the stream while this wave ran moves / beams / the apple
+// scan; here it is only adopted (list, stream position, the helper's stream copy) behind one workgroup barrier.
+template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E) {
   typedef Geo<KIND> G;
   const GridTables& T = c_tab[KIND];
   const u32 lane = E.lane;
@@ -1269,6 +1299,7 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
     const u64 th = T.apple_thresh[nH];
     waste_on = (th & kWasteOnBit) != 0;
+    if (DUO && lane == 0) *(volatile u32*)&E.X->need = waste_on ? 1u : 2u;  // lets the helper skip the list update it will not be asked for
     // waste density >= 0.4 (cleanup_new.py:357-359): both probabilities are zero, so nothing can spawn and the rand(222)
     // call only moves the stream — about half the steps of a steady-state episode (the density hovers at the threshold:
     // a spawned waste switches the model off until the next one is cleaned).  The per-cell work below is skipped then;
@@ -1348,6 +1379,9 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
     }
   }
   window_close<G::RANDW>(E.rng, W);
+  if (DUO) CE_DSTAMP(E.dbg, 4);
+  if (DUO) __syncthreads();  // hand-over 1: the helper's shuffle results are in its LDS block (every step passes here)
+  if (DUO) CE_DSTAMP(E.dbg, 5);
   if (!scan) return;
   bool spawnA[AR], tie[AR];
   bool any_tie = false;
@@ -1375,7 +1409,20 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
         const u64 sb = ballot(needw[r] && (__builtin_popcount(ww[r] & 0x89010000u) & 1) == 0);
         if (tstar == 0xffffffffu && sb) tstar = ctz64(sb) + 64 * r;
       }
-      if (diag::seq_shuffle) {
+      if (DUO) {
+        // the helper consumed exactly the words this wave consumed up to here (mover shuffle, id shuffle, the rand() window)
+        // on its copy, then drew and applied the shuffle: its list, its stream position and its copy of the state are the env's
+        E.waste_perm_dirty = true;
+        const u32* wp = E.LH->U;
+        E.WP0 = wp[lane];
+        E.WP1 = lane + 64 < (u32)G::NWASTE ? wp[64 + lane] : 0u;
+        E.rng.mt = E.LH->mt;
+        E.rng.pos = rfl(E.X->rng_pos);
+        E.rng.twists = rfl(E.X->rng_twists);
+        E.rng.cbase = 0;
+        E.rng.ccount = 0;
+        E.rng.cvalid = 0;
+      } else if (diag::seq_shuffle) {
         shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
       } else {
         // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
@@ -1869,6 +1916,8 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
+  E.LH = nullptr;
+  E.X = nullptr;
 #ifdef CE_INSTRUMENTED
   E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
 #else
@@ -1977,7 +2026,7 @@ struct StepOutPlane {
 // One env-step on the state held in E / LDS: MapEnv.step, infos, contract transfer, metrics, observation, in-launch
 // auto-reset.  FUSED = false: the step is its own launch and the state is written back to HBM at the end.
 // FUSED = true (k_grid_rollout): the state stays resident for the next step; only the per-step outputs leave.
-template <int KIND, bool FUSED, class OUT>
+template <int KIND, bool FUSED, class OUT, bool DUO = false>
 DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u32 ACT, u32& t, double& theta, u32& fault,
                            bool& did_reset) {
   const GridTables& T = c_tab[KIND];
@@ -1999,6 +2048,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   CE_STAMP(1);
   if (!diag::ablate_moves) update_moves(E, ACT);
   CE_STAMP(2);
+  if (DUO) CE_DSTAMP(E.dbg, 2);
   if (!E.is_agent) E.P = 0xffffu;
 
   // eaten_apples: final position held an apple when the step was entered (nothing has touched
@@ -2056,9 +2106,18 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     }
   }
   CE_STAMP(3);
-  custom_map_update(E);
+  if (DUO) CE_DSTAMP(E.dbg, 3);
+  custom_map_update<KIND, DUO>(E);
   CE_TRUNCATE_SPAWN_RETURN();
   CE_STAMP(4);
+  if (DUO && t != p.horizon) {
+    // hand-over 2: the map is final and the agents stand where the step left them — the helper wave copies the map, paints
+    // the agents on ITS copy and writes every view while this wave goes on with features, rewards and metrics
+    if (E.is_agent) E.X->agents[lane] = E.P | (E.O << 16);
+    CE_DSTAMP(E.dbg, 6);
+    __syncthreads();
+    CE_DSTAMP(E.dbg, 7);
+  }
 
   // ---------------- rewards ----------------
   i32 base_rew = E.is_agent ? E.RW : 0;
@@ -2094,7 +2153,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       if (diag::ablate_features) store_grid(E, p);
       else store_grid_bits(E, p, presA, presW);  // the feature pass has just taken the map's presence ballots
     }
-    write_obs<KIND, FUSED>(E, p, out.obs(), true);
+    if (!DUO) write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
   // A quiet step — nobody ate, cleaned, fired or was hit: every reward, transfer and metric increment is zero — skips the
@@ -2263,6 +2322,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     if (fault) p.error_flags[E.e] |= fault;
   }
   CE_STAMP(8);
+  if (DUO) CE_DSTAMP(E.dbg, 8);
   if (!obs_early) write_obs(E, p, out.obs(), !did_reset);
   CE_STAMP(9);
   CE_REALSTAMP(15);
@@ -2347,6 +2407,174 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
   u32 fault = 0;
   bool did_reset = false;
   grid_step_core<KIND, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
+}
+
+// ----------------------------------------------------------------------------------------
+// Two waves per env for launches that leave wave slots free.  With every wave resident a step of the
+// batch lasts ONE wave's dependent chain (~22 k cycles alone on its SIMD), and two stretches of that chain
+// do not depend on what precedes them:
+//   * the waste-list shuffle (119 masked-rejection draws + the list update: ~9 k cycles on the steps that take it) depends
+//     only on the stream — the words consumed before it (mover shuffle, id shuffle, the rand(222) window) are a function of
+//     the ACTIONS and the stream, not of the map;
+//   * the observation pass only reads the final map and the agent table.
+// The workgroup's second wave (the helper) owns a second LDS block: it loads its own copy of the MT19937 row and the waste
+// list, walks the stream exactly as the main wave will (consume-only shuffles, the window), draws and applies the shuffle,
+// and parks list + stream position in LDS; the main wave adopts them behind one barrier (custom_map_update<DUO>) if the
+// step does shuffle, and drops them otherwise (the helper's work was speculative).  After the second barrier the helper
+// copies the final map, paints the agents on its copy and writes all n views while the main wave runs features, rewards,
+// metrics and the state stores.  Results are those of k_grid_step, bit for bit (tests/test_gpu_parity.py).
+// MT19937 build, cleanup kind; launch_grid_step picks it by launch size.
+// ----------------------------------------------------------------------------------------
+template <int KIND> DEVINL void duo_helper(const GridParams& p, WaveLds<KIND>* lds, DuoX* X, CE_GPTR(const uint8_t) acts, u32 env_first,
+                                           u32 n, CE_GPTR(u32) rng_base, CE_GPTR(uint8_t) waste_perm_base) {
+  typedef Geo<KIND> G;
+  Env<KIND> H;
+  H.lane = lane_id();
+  H.e = rfl(env_first + blockIdx.x);
+  H.n = n;
+  H.is_agent = H.lane < n;
+  H.L = lds + 1;
+  H.LH = nullptr;
+  H.X = nullptr;
+  H.dbg = nullptr;
+  H.waste_perm_dirty = false;
+  const u32 lane = H.lane;
+  const size_t ea = (size_t)H.e * n;
+#ifdef CE_DUO_STAMPS
+  H.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)H.e * 16 : nullptr;
+#endif
+  CE_DSTAMP(H.dbg, 9);
+  const u32 ACT = H.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
+  // own copy of the stream row and of the persistent waste list
+  const uint4* rsrc = (const uint4*)(rng_base + (size_t)H.e * kRngRow);
+  const u32 q2 = min(lane + 128u, (u32)kMtN / 4 - 1);
+  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
+  const u32 rpos = rng_base[(size_t)H.e * kRngRow + kMtN];
+  const auto wp = waste_perm_base + (size_t)H.e * 119;
+  u32 WP0 = GAT(wp, lane);
+  const u32 w1 = GAT(wp, min(lane + 64u, 118u));
+  u32 WP1 = lane + 64 < 119 ? w1 : 0;
+  const u32 t1 = (u32)p.timestep[H.e] + 1u;
+  const bool obs_early = t1 != p.horizon;
+  const u32 rgbv = c_rgb[lane & 15];
+  uint4* mt4 = (uint4*)H.L->mt;
+  mt4[lane] = r0;
+  mt4[lane + 64] = r1;
+  mt4[q2] = r2;
+  H.L->rgb[lane & 15] = rgbv;
+  CE_DSTAMP(H.dbg, 10);
+  __syncthreads();  // start line: the main wave has cleared X->need
+  const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
+  if (ballot(H.is_agent && ACT > max_action) != 0) return;  // the step is not taken (grid_step_core returns before any hand-over)
+  Rng& r = H.rng;
+  r.mt = H.L->mt;
+  r.pos = rfl(rpos);
+  r.cbase = 0;
+  r.ccount = 0;
+  r.cvalid = 0;
+  r.cache = 0;
+  r.twists = 0;
+  wave_sync();
+  {  // the words update_moves and update_custom_moves consume: np.random.shuffle of the m mover slots, then of the n ids
+    const u64 M = ballot(H.is_agent && ACT <= 4);
+    u32 d0 = 0;
+    if (M != 0) shuffle_small<2>(r, d0, popc64(M), lane);
+    shuffle_small<2>(r, d0, n, lane);
+  }
+  {  // rand(222): the window only moves the stream here
+    const StreamWindow W = window_open<G::RANDW>(r, lane);
+    if (W.alen < (u32)G::RANDW) rng_advance(r, lane);
+    window_close<G::RANDW>(r, W);
+  }
+  CE_DSTAMP(H.dbg, 11);
+  if (*(volatile u32*)&X->need != 2u) shuffle_draws(r, (u32)G::NWASTE, H.L->U, lane, (const volatile u32*)&X->need);
+  CE_DSTAMP(H.dbg, 12);
+  if (*(volatile u32*)&X->need != 2u) {  // (not known yet counts as wanted)
+    shuffle_apply_par(WP0, WP1, (u32)G::NWASTE, H.L->U, lane);
+    wave_sync();
+    H.L->U[lane] = WP0;
+    H.L->U[64 + lane] = WP1;
+  }
+  if (lane == 0) {
+    X->rng_pos = r.pos;
+    X->rng_twists = r.twists;
+  }
+  CE_DSTAMP(H.dbg, 13);
+  __syncthreads();  // hand-over 1
+  if (!obs_early) return;  // a done step writes its (reset) observation late, on the main wave
+  __syncthreads();  // hand-over 2: final map in the main wave's block, agents in X
+  CE_DSTAMP(H.dbg, 14);
+  {
+    const uint4* src = (const uint4*)lds[0].pmap;
+    uint4* dst = (uint4*)H.L->pmap;
+    constexpr u32 kLastMapQuad = (u32)G::PQUADS - 1;
+    const u32 q1 = min(lane + 64u, kLastMapQuad);
+    const uint4 m0 = src[lane], m1 = src[q1];
+    dst[lane] = m0;
+    dst[q1] = m1;
+    const u32 aw = X->agents[min(lane, n - 1u)];
+    H.P = H.is_agent ? (aw & 0xffffu) : 0xffffu;
+    H.O = (aw >> 16) & 3u;
+    H.RW = 0;
+  }
+  wave_sync();
+  write_obs<KIND, false>(H, p, p.obs, true);
+  CE_DSTAMP(H.dbg, 15);
+}
+
+template <int KIND, int NFIX>
+__global__ __launch_bounds__(128, CE_CLEANUP_WAVES) void k_grid_step_duo(
+    const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
+    uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
+  static_assert(KIND == CE_KIND_CLEANUP && !kCounterRng, "the helper wave mirrors the MT19937 walk of the cleanup step");
+  const GridParams& p = *pp;
+  __shared__ WaveLds<KIND> lds[2];
+  __shared__ DuoX dx;
+  const auto acts = (CE_GPTR(const uint8_t))call_actions;
+  const u32 nn = NFIX ? (u32)NFIX : num_agents;
+  if (rfl(threadIdx.x >> 6) != 0) {
+    duo_helper<KIND>(p, lds, &dx, acts, env_first, nn, (CE_GPTR(u32))rng_base, (CE_GPTR(uint8_t))waste_perm_base);
+    return;
+  }
+  Env<KIND> E;
+  GridParams ph;
+  ph.rng = (decltype(ph.rng))rng_base;
+  ph.grid = (decltype(ph.grid))grid_base;
+  ph.agents = (decltype(ph.agents))agents_base;
+  ph.waste_perm = (decltype(ph.waste_perm))waste_perm_base;
+  ph.debug = nullptr;
+  ph.n = nn;
+  env_begin(E, ph, lds, env_first, 0xffffffffu);
+  E.LH = lds + 1;
+  E.X = &dx;
+  const u32 lane = E.lane, n = E.n;
+  const size_t ea = (size_t)E.e * n;
+#ifdef CE_DUO_STAMPS
+  E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
+#endif
+  CE_DSTAMP(E.dbg, 0);
+  const u32 ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
+  load_env_state(E, ph);
+  CE_DSTAMP(E.dbg, 1);
+  u32 t = (u32)p.timestep[E.e];
+  double theta = p.theta[E.e];
+  u32 fault = 0;
+  bool did_reset = false;
+  {
+    // What can be said about "does this step shuffle the waste list" before the step has run: the spawn model looks at the
+    // waste count AFTER the step's CLEAN beams, which can only lower it, and the waste probability is non-zero exactly below
+    // a density threshold (monotone in the count: checked when the tables are uploaded).  So: already on -> stays on; off and
+    // nobody cleans -> stays off; off and somebody cleans -> not known until the beams are done (custom_map_update says so).
+    u32 nH0 = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      nH0 += popc64(ballot(both(lane + 64 * r < (u32)Geo<KIND>::NWASTE, (E.L->pmap[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
+    const bool on0 = (c_tab[KIND].apple_thresh[nH0] & kWasteOnBit) != 0;
+    const bool cleans = ballot(E.is_agent && ACT == 7) != 0;
+    if (lane == 0) *(volatile u32*)&dx.need = on0 ? 1u : cleans ? 0u : 2u;
+  }
+  __syncthreads();  // start line (see duo_helper)
+  grid_step_core<KIND, false, StepOutDirect, true>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
 }
 
 // Fused multi-step rollout (ce_rollout_fused): the env's state — map, agent table, persistent lists, MT19937 — is loaded
@@ -3686,7 +3914,11 @@ __global__ void k_ctr_selftest(u32* out) {
 // ----------------------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------------------
+static bool g_waste_on_monotone = true;  // the duo kernel's early "this step shuffles" rule rests on it (see k_grid_step_duo)
 int CE_LAUNCHER(upload_grid_tables)(int kind, const GridTables& t, const u32* rgb16) {
+  if (kind == CE_KIND_CLEANUP)
+    for (int k = 1; k < 120; ++k)
+      if (t.waste_on[k] && !t.waste_on[k - 1]) g_waste_on_monotone = false;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(GridTables), sizeof(GridTables) * kind) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_rgb), rgb16, sizeof(u32) * 16) != hipSuccess) return -1;
   return 0;
@@ -3717,6 +3949,15 @@ static unsigned extra_lds() {
   }
   return (unsigned)v;
 }
+// CE_DUO_MAX_ENVS: largest launch (envs) stepped by two-wave workgroups; 0 switches them off (A/B runs)
+static unsigned duo_max_envs() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CE_DUO_MAX_ENVS");
+    v = e ? atoi(e) : 1366;
+  }
+  return (unsigned)v;
+}
 #define CE_LAUNCH_GRID(kern)                                                                          \
   do {                                                                                                \
     const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;             \
@@ -3739,6 +3980,18 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
   hipLaunchKernelGGL((k_grid_step<K_, N_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
   if (kind == CE_KIND_CLEANUP) {
+#ifndef CE_RNG_COUNTER
+    // launches that leave wave slots free step each env with a two-wave workgroup (k_grid_step_duo): three slices of at most
+    // this many envs are 8 192 waves, the machine's wave slots
+    if (count <= duo_max_envs() && g_waste_on_monotone) {
+      dim3 block2(128);
+      if (p.n == 4) hipLaunchKernelGGL((k_grid_step_duo<CE_KIND_CLEANUP, 4>), grid, block2, extra_lds(), (hipStream_t)stream, p.actions, first,
+                                       p.n, (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+      else hipLaunchKernelGGL((k_grid_step_duo<CE_KIND_CLEANUP, 0>), grid, block2, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+                              (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+      return;
+    }
+#endif
     if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 8);
     else if (p.n == 4) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 4);  // BASELINE config 1
     else CE_STEP_LAUNCH(CE_KIND_CLEANUP, 0);
