@@ -3,7 +3,7 @@
 
     CONTRACTS_AMD_LIB=lib.so python tools/rate.py C4 C2:fused C1 cleanup_features,2,16384 ...
 
-RATE_PREROLL=N adds N untimed steps first.  A spec is a BASELINE config key (C1..C5, bench.py's WORKLOADS) or kind,agents,envs, optionally :fused and / or
+RATE_PREROLL=N adds N untimed steps first; RATE_STREAMS=S cuts the batch into S slices on S streams (default 3).  A spec is a BASELINE config key (C1..C5, bench.py's WORKLOADS) or kind,agents,envs, optionally :fused and / or
 @counter (the counter-RNG mode).  Protocol: 300-step
 pre-roll, then the median of 5 repeats of 300 steps (fused: 304 = 19 launches of 16), three env slices on three streams."""
 import os
@@ -34,6 +34,7 @@ for spec in sys.argv[1:]:
         n, E = int(n), int(E)
     fused = mode == "fused"
     K, T, PRE, S = (304, 16, 300, 3) if fused else (300, 0, 300, 3)
+    S = int(os.environ.get("RATE_STREAMS", S))  # env slices / streams (default 3, bench.py's)
     LONG = int(os.environ.get("RATE_PREROLL", "0"))  # extra untimed steps first (replaying the pre-roll planes): steady states
 
     env = BatchedEnv(kind, E, n, contract=CONTRACT[kind], horizon=1000, auto_reset=True, rng=rng or "mt19937")
