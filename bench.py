@@ -504,9 +504,10 @@ def boundary(wl, E, device_index):
         venv.send_actions(action_dicts[t % 8])
         obs, rew, dones, infos, _ = venv.poll()
         k = 0
-        for e in obs:  # a sampler touches every env's dictionaries
-            o, r, d, i = obs[e], rew[e], dones[e], infos[e]
-            k += len(o)
+        # a sampler touches every env's dictionaries (RLlib walks `unfiltered_obs.items()` and looks the env's rewards / dones /
+        # infos up beside it; the four mappings list the envs in the same order)
+        for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
+            k += len(o) + len(r) + len(i) + d["__all__"]
         return k
 
     for t in range(3):  # the first two ticks build the two dictionary generations
@@ -659,7 +660,7 @@ def run_rank(a):
             for S2 in (2, 4):
                 if S2 == a.streams or "error" in cl:
                     continue
-                r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5, ("policy_graph", "policy_graph16"))
+                r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5, ("policy_eager", "policy_graph", "policy_graph16"))
                 sweep[str(S2)] = {m: {k: v[k] for k in ("value", "ms_per_step", "host_calls_per_step") if k in v}
                                   for m, v in r2.get("modes", {}).items()} if "error" not in r2 else r2
                 if "error" not in r2 and r2["value"] > cl["value"]:
