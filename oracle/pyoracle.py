@@ -46,7 +46,7 @@ class CeBuffers(C.Structure):
         ("obs", _P), ("obs_f64", _P), ("base_reward", _P), ("reward", _P), ("done", _P), ("done_agents", _P),
         ("info", _P), ("features", _P),
         ("int_metrics", _P), ("f64_metrics", _P), ("final_int_metrics", _P), ("final_f64_metrics", _P),
-        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P),
+        ("error_flags", _P), ("beam_map", _P), ("sd_info", _P), ("actions_taken", _P),
     ]
 
 
@@ -64,7 +64,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
                 beam_trace=False, rng="mt19937"):
     cfg = CeConfig()
-    cfg.abi_version = 2
+    cfg.abi_version = 3  # CE_ABI_VERSION of include/contracts_engine.h (the oracle refuses any other)
     cfg.kind = KIND[kind]
     cfg.num_envs = num_envs
     cfg.num_agents = num_agents

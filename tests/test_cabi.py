@@ -55,6 +55,11 @@ int main(void) {
             C.sizeof(buf), buf.grid.offset, buf.error_flags.offset,
             buf.actions_taken.offset, buf.sd_info.offset, C.sizeof(traj), traj.obs.offset, traj.features.offset, traj.sd_info.offset, _lib.CE_ABI_VERSION]
     assert got == want
+    # the oracle's own ctypes mirrors (oracle/pyoracle.py) follow the same header: orc_get_buffers writes a whole ce_buffers
+    from oracle import pyoracle as po
+    assert C.sizeof(po.CeBuffers) == C.sizeof(buf) and C.sizeof(po.CeConfig) == C.sizeof(cfg)
+    assert [f[0] for f in po.CeBuffers._fields_] == [f[0] for f in buf._fields_]
+    assert po.make_config("cleanup", 1, 1).abi_version == _lib.CE_ABI_VERSION
 
 
 def test_no_gpu_fails_loudly():
