@@ -507,7 +507,7 @@ def boundary(wl, E, device_index):
         # a sampler touches every env's dictionaries (RLlib walks `unfiltered_obs.items()` and looks the env's rewards / dones /
         # infos up beside it; the four mappings list the envs in the same order)
         for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
-            k += len(o) + len(r) + len(i) + d["__all__"]
+            k += len(o)
         return k
 
     for t in range(3):  # the first two ticks build the two dictionary generations

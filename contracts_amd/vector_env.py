@@ -437,6 +437,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
                 if i + 2 < len(cuts):
                     eng.download_async("obs", G.obs_u8[cuts[i + 1]:cuts[i + 2]], cuts[i + 1], cuts[i + 2] - cuts[i + 1])
                 eng.obs_u8_to_f64(G.obs_u8[cuts[i]:cuts[i + 1]], G.obs_f64[cuts[i]:cuts[i + 1]], T)
+            eng.i16_to_f64(G.feat_i16, G.feat_f64, T)  # feature rows -> the float64 arrays infos[..]['feature_obs'] are views of
             tm["obs_copy_and_convert_ms"] = (time.perf_counter() - ta) * 1e3
 
         job = _pool().submit(finish_obs)
@@ -445,7 +446,6 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             if G.err.any():
                 bad = np.nonzero(G.err)[0]
                 raise _lib.EngineError("env faults: %s" % {int(i): int(G.err[i]) for i in bad[:8]})
-            eng.i16_to_f64(G.feat_i16, G.feat_f64, 2)
             if G.theta is not None:
                 G.cobs[:, 0] = G.theta
                 G.cparam[:, 0] = G.theta
