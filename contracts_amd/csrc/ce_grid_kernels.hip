@@ -2587,10 +2587,19 @@ __global__ __launch_bounds__(128, CE_CLEANUP_WAVES) void k_grid_step_duo(
 // are.  Each iteration therefore takes them through a value the compiler cannot see through: a real v_mov inside a
 // volatile asm (an empty asm with a "+v" operand would leave the SGPR -> VGPR copy hoistable, i.e. a VGPR held across
 // the loop per value), re-asserted wave-uniform with v_readfirstlane.  Two instructions per value and step.
+// (Round 4: the value stays in an SGPR — an empty volatile asm with a "+s" operand is just as opaque to the optimiser and costs
+// nothing; the v_mov + v_readfirstlane form it replaces was two VALU per value and step and cost spill slots: cleanup rollout
+// 11 -> 2 spilled SGPRs, harvest rollout 6 -> 3 spilled VGPRs, feature rollout 10 -> 2.  -DCE_OPAQUE_VMOV keeps the old form for A/B.)
 DEVINL u32 opaque_u32(u32 x) {
+#ifdef CE_OPAQUE_VMOV
   u32 v;
   asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
   return rfl(v);
+#else
+  u32 y = rfl(x);  // (folds away when x already lives in an SGPR)
+  asm volatile("" : "+s"(y));
+  return y;
+#endif
 }
 // ... and for the two read-only argument blocks the pointer is typed into the constant address space, so that the field
 // reads stay scalar loads (an integer-built pointer is a flat one to the compiler).
