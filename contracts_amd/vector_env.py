@@ -17,7 +17,7 @@ Built to stay usable at E = 16 384:
     caller never asks about is reset as well (RLlib's sampler resets every done sub-env, so it never notices);
     `batch_done_resets=False` resets exactly the env asked for;
   * `poll_tensors()` / `send_actions_array()` skip Python containers altogether (observations stay in HBM);
-  * grid kinds, `recycle_dicts=True` (the default): the dictionaries of a tick are not rebuilt but RECYCLED.  Two generations
+  * grid and feature-vector kinds, `recycle_dicts=True` (the default): the dictionaries of a tick are not rebuilt but RECYCLED.  Two generations
     of complete dictionary trees ({env: {agent: {"image": ..}}}, rewards, dones, infos) are kept over page-locked snapshot
     buffers; a tick copies the step's results into the older generation asynchronously (one DMA per field), converts the
     observations to the reference's float64 on worker threads, and rewrites only the dictionary entries whose values
@@ -159,8 +159,7 @@ class _DictGeneration:
         eng, E, n, keys = venv.engine, venv.num_envs, venv.num_agents, venv._keys
         b = eng.b
         F = b.num_features
-        self.obs_u8 = eng.host_alloc((E, b.obs_env_stride), np.uint8)
-        self.obs_f64 = np.empty((E, n, 15, 15, 3), np.float64)
+        self.grid = venv.kind in _GRID
         self.float_rewards = venv._float_rewards
         self.rew = eng.host_alloc((E, n), np.float64 if self.float_rewards else np.int32)
         self.done = eng.host_alloc((E,), np.uint8)
@@ -178,17 +177,36 @@ class _DictGeneration:
         second = _SECOND_INFO[venv.kind]
         contract = bool(venv.contract)
         zero = 0.0 if self.float_rewards else 0
-        obs_f64, feat_f64, cobs, cparam = self.obs_f64, self.feat_f64, self.cobs, self.cparam
+        feat_f64, cobs, cparam = self.feat_f64, self.cobs, self.cparam
+        if self.grid:
+            self.obs_u8 = eng.host_alloc((E, b.obs_env_stride), np.uint8)
+            self.obs_f64 = np.empty((E, n, 15, 15, 3), np.float64)
+            self.obs_vec = None
+        else:
+            # feature-vector kinds: the observation IS the feature row, with the wrapper's [theta, 0] appended under a contract
+            # (two_stage_train.py:113-117) — a second array then, the infos' feature_obs rows stay F long
+            self.obs_u8 = self.obs_f64 = None
+            self.obs_vec = np.zeros((E, n, F + 2), np.float64) if contract else feat_f64
+        self.key0 = None if venv.kind == "cleanup_features" else "eaten_apples"  # CleanupFeatures' infos carry the second counter only
         self.obs, self.rewards, self.dones, self.infos = {}, {}, {}, {}
         self.agent_infos = []
         for e in range(E):
-            img, fe = obs_f64[e], feat_f64[e]
-            if contract:
-                c, cp = cobs[e], cparam[e]
-                self.obs[e] = {k: {"image": img[i], "contract": c} for i, k in enumerate(keys)}
+            fe = feat_f64[e]
+            c, cp = cobs[e], cparam[e]
+            if self.grid:
+                img = self.obs_f64[e]
+                if contract:
+                    self.obs[e] = {k: {"image": img[i], "contract": c} for i, k in enumerate(keys)}
+                else:
+                    self.obs[e] = {k: {"image": img[i]} for i, k in enumerate(keys)}
+            else:
+                ov = self.obs_vec[e]
+                self.obs[e] = {k: ov[i] for i, k in enumerate(keys)}
+            if self.key0 is None:
+                inf = {k: ({second: 0, "contract_param": cp} if contract else {second: 0}) for k in keys}
+            elif contract:
                 inf = {k: {second: 0, "eaten_apples": 0, "feature_obs": fe[i], "contract_param": cp} for i, k in enumerate(keys)}
             else:
-                self.obs[e] = {k: {"image": img[i]} for i, k in enumerate(keys)}
                 inf = {k: {second: 0, "eaten_apples": 0, "feature_obs": fe[i]} for i, k in enumerate(keys)}
             self.infos[e] = inf
             self.agent_infos.extend(inf[k] for k in keys)
@@ -219,7 +237,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._reset_obs = {}                       # env_id -> reset observation (or the lazy map of its reset batch)
         self._acted = None                         # selfdrive: [E, n] which agents acted in the last step
         # recycled dict protocol (grid kinds): two generations of dictionary trees over page-locked snapshots
-        self._recycle = bool(recycle_dicts) and kind in _GRID
+        self._recycle = bool(recycle_dicts) and kind != "selfdrive"  # (selfdrive's dictionaries change their key sets with the acting cars)
         self._gens, self._gen = [None, None], 0
         self._act_planes, self._act_turn = None, 0
         self._keys_t = tuple(self._keys)
@@ -431,13 +449,18 @@ class BatchedBaseEnv(_RLlibBaseEnv):
 
         def finish_obs():
             ta = time.perf_counter()
-            eng.download_async("obs", G.obs_u8[cuts[0]:cuts[1]], cuts[0], cuts[1] - cuts[0])
-            for i in range(len(cuts) - 1):
-                eng.synchronize()
-                if i + 2 < len(cuts):
-                    eng.download_async("obs", G.obs_u8[cuts[i + 1]:cuts[i + 2]], cuts[i + 1], cuts[i + 2] - cuts[i + 1])
-                eng.obs_u8_to_f64(G.obs_u8[cuts[i]:cuts[i + 1]], G.obs_f64[cuts[i]:cuts[i + 1]], T)
+            if G.grid:
+                eng.download_async("obs", G.obs_u8[cuts[0]:cuts[1]], cuts[0], cuts[1] - cuts[0])
+                for i in range(len(cuts) - 1):
+                    eng.synchronize()
+                    if i + 2 < len(cuts):
+                        eng.download_async("obs", G.obs_u8[cuts[i + 1]:cuts[i + 2]], cuts[i + 1], cuts[i + 2] - cuts[i + 1])
+                    eng.obs_u8_to_f64(G.obs_u8[cuts[i]:cuts[i + 1]], G.obs_f64[cuts[i]:cuts[i + 1]], T)
             eng.i16_to_f64(G.feat_i16, G.feat_f64, T)  # feature rows -> the float64 arrays infos[..]['feature_obs'] are views of
+            if G.obs_vec is not None and G.obs_vec is not G.feat_f64:  # feature kinds under a contract: row = features + [theta, 0]
+                F = G.feat_f64.shape[2]
+                G.obs_vec[:, :, :F] = G.feat_f64
+                G.obs_vec[:, :, F] = G.theta[:, None]
             tm["obs_copy_and_convert_ms"] = (time.perf_counter() - ta) * 1e3
 
         job = _pool().submit(finish_obs)
@@ -453,7 +476,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
                 pd.refresh_floats(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
             else:
                 pd.refresh_ints(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
-            pd.refresh_infos(G.agent_infos, "eaten_apples", G.second, G.info, G.info_shadow)
+            pd.refresh_infos(G.agent_infos, G.key0, G.second, G.info, G.info_shadow)
             pd.refresh_dones(G.done_list, ("__all__", "a0", "a1"), G.done, G.done_shadow)
             self._done_ids = {int(e) for e in np.nonzero(G.done)[0]}
             self._episode_over = set(self._done_ids)

@@ -448,14 +448,18 @@ def test_try_reset_batching_is_optional_and_metrics_follow_the_tick():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,n,contract", [("cleanup", 8, "cleanup"), ("harvest", 3, None), ("cleanup", 2, None)])
+@pytest.mark.parametrize("kind,n,contract", [("cleanup", 8, "cleanup"), ("harvest", 3, None), ("cleanup", 2, None),
+                                             ("harvest_features", 2, "harvest_local"), ("harvest_features", 4, None),
+                                             ("cleanup_features", 2, "cleanup"), ("cleanup_features", 3, None)])
 def test_recycled_dict_protocol_equals_the_rebuilt_one(kind, n, contract):
     """recycle_dicts=True (dictionary trees kept over page-locked snapshots, refreshed in place by the C loops) hands out,
     tick for tick, what recycle_dicts=False builds from scratch — same keys in the same order, same value types, equal
     values — and what poll() returned at tick t is still intact at tick t + 1 (the two-generation contract)"""
     from contracts_amd.vector_env import BatchedBaseEnv
     E, T, horizon = 70, 45, 13
-    kw = dict(contract=contract, seed0=321, horizon=horizon, firing=True)
+    kw = dict(contract=contract, seed0=321, horizon=horizon)
+    if kind in ("cleanup", "harvest"):
+        kw["firing"] = True
     fast, slow = BatchedBaseEnv(kind, E, n, recycle_dicts=True, **kw), BatchedBaseEnv(kind, E, n, recycle_dicts=False, **kw)
     keys = ["a%d" % i for i in range(n)]
     rs = np.random.RandomState(4)
