@@ -108,6 +108,18 @@ typedef struct ce_config {
   double alpha, beta;      /* inequity aversion coefficients (map_env.py:71-72)            */
   /* selfdrive constructor kwargs (self_driving_car_accelerate.py:19) */
   double low_bound, high_bound, start_vel, start_vel_ambulance;
+  /* Grid kinds (CE_KIND_CLEANUP / CE_KIND_HARVEST): the ASCII layout the env is built from — the reference's `ascii_map`
+   * constructor argument (map_env.py:63,117-130, cleanup_new.py:107-128).  NULL = the kind's shipped layout (ce_static_map).
+   * Otherwise map_rows x map_cols characters, row-major, no terminators (copied by ce_create), in the reference's alphabet:
+   * '@' wall, ' ' floor, 'P' spawn point; cleanup: 'B' apple cell, 'H' waste, 'R' river (waste can appear), 'S' stream; harvest:
+   * 'A' apple.  Caps — a custom layout must fit the kind's frame and tables: at most the shipped layout's rows / columns
+   * (25 x 18 cleanup, 16 x 38 harvest), apple cells (103 / 155), waste cells (119), spawn points (10 / 20), at least one of
+   * each list the kind uses, and num_agents <= spawn points (the reference asserts "not enough spawn points", map_env.py:826).
+   * The layout must be walled in ('@' on its whole perimeter, like the shipped ones): the reference indexes the map with whatever
+   * cell a move names (Agent.return_valid_pos), so an open edge wraps around or raises there.  The view beyond the layout is
+   * black, as in the reference.  CE_EINVAL (ce_last_error says which rule) otherwise.  ABI 3. */
+  const char* ascii_map;
+  uint32_t map_rows, map_cols;
 } ce_config;
 
 /* Shapes, filled by ce_get_buffers.  Grid families: obs is the 15x15x3 egocentric

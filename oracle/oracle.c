@@ -293,16 +293,39 @@ typedef struct orc {
 
 static int in_bounds(const orc_t* o, int r, int c) { return 0 <= r && r < o->H && 0 <= c && c < o->W; }
 
-static void build_static(orc_t* o) {
+static int is_feat_kind(int kind);
+/* MapEnv.__init__ / CleanupEnv.__init__ / HarvestEnv.__init__ over the layout (map_env.py:117-130, cleanup_new.py:107-128):
+ * the shipped one, or the caller's `ascii_map` (ce_config.ascii_map, grid kinds) within the caps of contracts_engine.h */
+static int build_static(orc_t* o) {
   const int cleanup_map = o->kind == CE_KIND_CLEANUP || o->kind == CE_KIND_CLEANUP_FEATURES; /* same maps as the feature envs */
   const char** map = cleanup_map ? CLEANUP_MAP : HARVEST_MAP;
-  o->H = cleanup_map ? 25 : 16;
-  o->W = cleanup_map ? 18 : 38;
+  const char* custom = o->cfg.ascii_map;
+  const int frame_h = cleanup_map ? 25 : 16, frame_w = cleanup_map ? 18 : 38;
+  o->H = frame_h;
+  o->W = frame_w;
+  if (custom) {
+    if (is_feat_kind(o->kind) || o->cfg.map_rows < 1 || o->cfg.map_cols < 1 || (int)o->cfg.map_rows > frame_h ||
+        (int)o->cfg.map_cols > frame_w)
+      return CE_EINVAL;
+    o->H = (int)o->cfg.map_rows;
+    o->W = (int)o->cfg.map_cols;
+  }
   o->cells = o->H * o->W;
   o->n_apple = o->n_waste = o->n_spawn_static = 0;
+  const int cap_apple = cleanup_map ? 103 : 155, cap_waste = 119, cap_spawn = cleanup_map ? 10 : 20;
   for (int r = 0; r < o->H; r++)
     for (int c = 0; c < o->W; c++) {
-      char ch = map[r][c];
+      char ch = custom ? custom[r * o->W + c] : map[r][c];
+      if (custom && (r == 0 || c == 0 || r == o->H - 1 || c == o->W - 1) && ch != '@')
+        return CE_EINVAL; /* a layout must be walled in, like the shipped ones: the reference indexes the map with whatever cell a
+                             move names (Agent.return_valid_pos), so stepping over an open edge wraps around or raises there */
+      if (custom) { /* caps first: the tables below are sized for the shipped layouts */
+        if (ch == 'P' && o->n_spawn_static >= cap_spawn) return CE_EINVAL;
+        if (ch == (cleanup_map ? 'B' : 'A') && o->n_apple >= cap_apple) return CE_EINVAL;
+        if (cleanup_map && (ch == 'H' || ch == 'R') && o->n_waste >= cap_waste) return CE_EINVAL;
+        if (!(ch == '@' || ch == ' ' || ch == 'P' || (cleanup_map ? (ch == 'B' || ch == 'H' || ch == 'R' || ch == 'S') : ch == 'A')))
+          return CE_EINVAL;
+      }
       int idx = r * o->W + c;
       o->is_wall[idx] = ch == '@';
       o->base_cell[idx] = ch == '@' ? CE_CELL_WALL : CE_CELL_EMPTY;
@@ -322,9 +345,15 @@ static void build_static(orc_t* o) {
     }
   if (cleanup_map) {
     /* cleanup_new.py:114-115 appends the P cells a second time */
-    for (int i = 0; i < 10; i++) o->spawn_pts[10 + i] = o->spawn_pts[i];
+    for (int i = 0; i < o->n_spawn_static; i++) o->spawn_pts[o->n_spawn_static + i] = o->spawn_pts[i];
   }
+  if (custom && (o->n_spawn_static < 1 || o->n_apple < 1 || (cleanup_map && o->n_waste < 1) || o->n > o->n_spawn_static))
+    return CE_EINVAL;
+  return CE_OK;
 }
+/* length of the spawn list setup_agents shuffles: at construction the P cells; from the first reset on cleanup's doubled list */
+static int spawn_len_ctor(const orc_t* o) { return o->n_spawn_static; }
+static int spawn_len_reset(const orc_t* o) { return o->kind == CE_KIND_CLEANUP ? 2 * o->n_spawn_static : o->n_spawn_static; }
 
 /* ------------------------------------------------------------------------- */
 /* numpy list shuffle (untyped path of RandomState.shuffle)                   */
@@ -923,7 +952,7 @@ static void grid_seed_construct(orc_t* o, int ei, uint64_t seed, int mode) {
   if (!(mode & CE_SEED_CONSTRUCT)) return;
   rng_begin_op(&e->np_rng);
   /* MapEnv.__init__: spawn_points = the P cells in row-major order, then setup_agents() */
-  int base_len = o->kind == CE_KIND_CLEANUP ? 10 : 20;
+  int base_len = spawn_len_ctor(o);
   for (int i = 0; i < 20; i++) e->spawn_perm[i] = (uint8_t)i;
   for (int i = 0; i < 119; i++) e->waste_perm[i] = (uint8_t)i;
   memset(e->grid, CE_CELL_EMPTY, sizeof(e->grid)); /* world_map is blank until the first reset */
@@ -953,7 +982,7 @@ static void grid_reset(orc_t* o, int ei) {
   env_t* e = &o->envs[ei];
   int n = o->n;
   /* MapEnv.reset map_env.py:306-342 */
-  if (setup_agents(o, e, 20)) o->b.error_flags[ei] |= CE_FAULT_NO_SPAWN;
+  if (setup_agents(o, e, spawn_len_reset(o))) o->b.error_flags[ei] |= CE_FAULT_NO_SPAWN;
   memcpy(e->grid, o->base_cell, o->cells); /* reset_map: walls + custom_reset */
   if (o->cfg.flags & CE_FLAG_BEAM_TRACE) memset(o->b.beam_map + (size_t)ei * o->cells, CE_BEAM_NONE, o->cells); /* beam_pos = [] :316 */
   latch_zero_metrics(o, ei);               /* custom_reset re-creates metrics / total_reward_dict */
@@ -1887,7 +1916,7 @@ int orc_create(const ce_config* cfg, orc_t** out) {
   o->b.num_int_metrics = CE_MI_COUNT(n);
   o->b.num_f64_metrics = CE_MF_COUNT(n);
   if (is_feat_kind(o->kind)) {
-    build_static(o);
+    if (build_static(o) != CE_OK) return CE_EINVAL;
     o->b.grid_h = o->H;
     o->b.grid_w = o->W;
     o->b.grid_env_stride = CE_FEAT_STATE_BYTES;
@@ -1898,7 +1927,8 @@ int orc_create(const ce_config* cfg, orc_t** out) {
     ALLOC(rng, uint32_t, E * CE_RNG_WORDS_SELFDRIVE);
     ALLOC(features, int16_t, E * n * o->b.num_features);
   } else if (o->kind != CE_KIND_SELFDRIVE) {
-    build_static(o);
+    if (build_static(o) != CE_OK) return CE_EINVAL;
+    o->cfg.ascii_map = NULL; /* the caller's string is not ours to keep */
     o->b.grid_h = o->H;
     o->b.grid_w = o->W;
     o->b.obs_agent_stride = WIN * WIN * 3;

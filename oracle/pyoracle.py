@@ -28,6 +28,7 @@ class CeConfig(C.Structure):
         ("alpha", C.c_double), ("beta", C.c_double),
         ("low_bound", C.c_double), ("high_bound", C.c_double), ("start_vel", C.c_double),
         ("start_vel_ambulance", C.c_double),
+        ("ascii_map", C.c_char_p), ("map_rows", C.c_uint32), ("map_cols", C.c_uint32),
     ]
 
 
@@ -62,8 +63,14 @@ CONTRACT_SPACE = {
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
-                beam_trace=False, rng="mt19937"):
+                beam_trace=False, rng="mt19937", ascii_map=None):
     cfg = CeConfig()
+    if ascii_map is not None:  # the reference's `ascii_map` argument: a list of equally long strings (grid kinds)
+        rows = [str(r) for r in ascii_map]
+        if not rows or any(len(r) != len(rows[0]) for r in rows):
+            raise ValueError("ascii_map must be a non-empty list of equally long strings")
+        cfg.ascii_map = "".join(rows).encode("ascii")  # (ctypes keeps the bytes object alive with the structure)
+        cfg.map_rows, cfg.map_cols = len(rows), len(rows[0])
     cfg.abi_version = 3  # CE_ABI_VERSION of include/contracts_engine.h (the oracle refuses any other)
     cfg.kind = KIND[kind]
     cfg.num_envs = num_envs

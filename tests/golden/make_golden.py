@@ -178,6 +178,8 @@ def _run_grid_trace(R, kind, n, seed, T, episodes, firing, contract, action_p, a
             out[k] = v
     if static_waste is not None:
         out["static_waste"] = np.array(static_waste, np.int16)
+    if "ascii_map" in ek:
+        out["ascii_map"] = np.array([str(r) for r in ek["ascii_map"]])
     return out
 
 
@@ -246,6 +248,46 @@ def run_selfdrive_trace(R, n, seed, max_steps=400, episodes=2, act_scale=0.15, c
     return out
 
 
+CLEANUP_SMALL = ["@@@@@@@@@@@@",
+                 "@HRH   BBBB@",
+                 "@RHR P  BBB@",
+                 "@HRH   BBBB@",
+                 "@RHRSSS BBB@",
+                 "@HRH P BBBB@",
+                 "@RHR    BBB@",
+                 "@HRH P  BBB@",
+                 "@RHR   BBBB@",
+                 "@@@@@@@@@@@@"]
+CLEANUP_MID = ["@@@@@@@@@@@@@@@@"] + ["@%s%s%s@" % ("HRHRH" if r % 2 else "RHRHR", "  P " if r % 5 == 0 else ("SSSS" if r == 8 else "    "),
+                                               "BBBBB" if r % 3 else " BBBB") for r in range(18)] + ["@@@@@@@@@@@@@@@@"]
+HARVEST_SMALL = ["@@@@@@@@@@@@@@@@@@@@",
+                 "@ P  A   AA    P   @",
+                 "@   AAA   A  A     @",
+                 "@ A  A      AAA  A @",
+                 "@AAA    P    A  AAA@",
+                 "@ A   A   A      A @",
+                 "@    AAA AAA   P   @",
+                 "@  P  A   A    A   @",
+                 "@       A     AAA  @",
+                 "@  A   AAA     A   @",
+                 "@ AAA   A   P      @",
+                 "@@@@@@@@@@@@@@@@@@@@"]
+CLEANER_P = [.1, .1, .15, .1, .05, .1, .1, .3]
+
+
+def custom_map_jobs(S0):
+    return {
+        "m1_cleanup_small_n3": dict(kind="cleanup", n=3, seed=S0 + 60, T=[100, 100, 60], episodes=3, store_obs_steps=40, action_p=CLEANER_P,
+                                    extra_env_kwargs=dict(ascii_map=CLEANUP_SMALL, horizon=100)),
+        "m2_cleanup_mid_n4_fire": dict(kind="cleanup", n=4, seed=S0 + 61, T=[150, 90], episodes=2, store_obs_steps=30, firing=True,
+                                       action_p=CLEANER_P + [0.0], extra_env_kwargs=dict(ascii_map=CLEANUP_MID, horizon=150)),
+        "m3_harvest_small_n4": dict(kind="harvest", n=4, seed=S0 + 62, T=[120, 80], episodes=2, store_obs_steps=40, firing=True,
+                                    extra_env_kwargs=dict(ascii_map=HARVEST_SMALL, horizon=120)),
+        "m4_cleanup_small_n1_nocontract": dict(kind="cleanup", n=1, seed=S0 + 63, T=150, store_obs_steps=10, contract=False, action_p=CLEANER_P,
+                                               extra_env_kwargs=dict(ascii_map=CLEANUP_SMALL)),
+    }
+
+
 def main():
     R = load_reference()
     S0 = 73907
@@ -288,6 +330,10 @@ def main():
     jobs["g9b_harvest_n4_inequity_contract_done"] = dict(kind="harvest", n=4, seed=S0 + 36, T=[80, 30], episodes=2,
                                                          store_obs_steps=5,
                                                          extra_env_kwargs=dict(inequity_averse_reward=True, alpha=0.5, beta=0.25, horizon=80))
+    # custom layouts (the reference's `ascii_map` argument; walled in, within the engine's caps — include/contracts_engine.h):
+    # a small cleanup map whose waste list fits one 64-lane register, a larger one that needs two, a small harvest map
+    for name, kw in custom_map_jobs(S0).items():
+        jobs[name] = kw
     for s in range(6):  # short multi-seed traces (RNG / reset variety)
         jobs["g7_cleanup_n8_s%d" % s] = dict(kind="cleanup", n=8, seed=1000 + 17 * s, T=120, store_obs_steps=8,
                                              action_p=[.1, .1, .15, .1, .05, .1, .1, .3] if s % 2 else None)

@@ -28,6 +28,8 @@ def grid_kwargs(g):
         kw["collective"] = True
     if "inequity" in g and int(g["inequity"]):
         kw.update(inequity=True, alpha=float(g["alpha"]), beta=float(g["beta"]))
+    if "ascii_map" in g:  # m_* fixtures: the reference built on a custom layout
+        kw["ascii_map"] = [str(r) for r in g["ascii_map"]]
     return kind, int(g["n"]), kw
 
 
@@ -69,7 +71,7 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
     check_obs = check_obs and image_obs
 
     def spawn_cells():
-        sp = get("spawn_perm")[env]
+        sp = get("spawn_perm")[env][: len(g["ctor_spawn_perm"])]  # (the buffer is 20 entries wide; a custom layout uses fewer)
         return [int(p) % len(static_spawn) if kind == "cleanup" else int(p) for p in sp]
 
     counter = "rng_mode" in g and str(g["rng_mode"]) == "counter"  # p_* fixtures: the reference run over the counter stream
@@ -126,7 +128,8 @@ def replay_grid(g, impl, env=0, check_obs=True, sync=lambda: None, get=None):
                 assert np.array_equal(sha, g["obs_sha"][t]), "obs sha " + tag
             assert rng_record() == tuple(int(x) for x in g["mt"][t]), "generator state " + tag
             if kind == "cleanup":
-                assert np.array_equal(get("waste_perm")[env], g["waste_perm"][t]), "waste perm " + tag
+                nw = g["waste_perm"].shape[1]  # (119 for the shipped layout; the buffer is that wide for every layout)
+                assert np.array_equal(get("waste_perm")[env][:nw], g["waste_perm"][t]), "waste perm " + tag
         # metrics at the end of the recorded episode
         keys = str(g["metrics_keys_ep%d" % ep]).split(",")
         vals = g["metrics_vals_ep%d" % ep]
