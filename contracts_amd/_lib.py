@@ -32,6 +32,7 @@ class CeConfig(C.Structure):
         ("alpha", C.c_double), ("beta", C.c_double),
         ("low_bound", C.c_double), ("high_bound", C.c_double), ("start_vel", C.c_double),
         ("start_vel_ambulance", C.c_double),
+        ("ascii_map", C.c_char_p), ("map_rows", C.c_uint32), ("map_cols", C.c_uint32),
     ]
 
 

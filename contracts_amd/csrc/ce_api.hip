@@ -46,14 +46,30 @@ static const char* kHarvestMap[16] = {
 // colours: DEFAULT_COLOURS (map_env.py:24-42) + CLEANUP_COLORS (cleanup_new.py:42-47), packed 0x00BBGGRR
 static uint32_t rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
 
-template <int KIND> static void build_tables(GridTables& t) {
+// The static tables of a layout: the kind's shipped one (rows == nullptr) or a caller's (ce_config.ascii_map; H0 x W0 characters,
+// row-major).  Returns nullptr, or the rule of contracts_engine.h the layout breaks.  `counts` = {apple, waste, spawn} cells.
+template <int KIND> static const char* build_tables(GridTables& t, const char* rows, int H0, int W0, uint32_t num_agents, uint32_t counts[3]) {
   typedef Geo<KIND> G;
   const char** map = KIND == CE_KIND_CLEANUP ? kCleanupMap : kHarvestMap;
   std::memset(&t, 0, sizeof(t));
+  if (!rows) {
+    H0 = G::H;
+    W0 = G::W;
+  } else if (H0 < 1 || W0 < 1 || H0 > G::H || W0 > G::W) {
+    return "ascii_map: the layout does not fit the kind's frame (25 x 18 cleanup, 16 x 38 harvest)";
+  }
   int na = 0, nw = 0, ns = 0;
-  for (int r = 0; r < G::H; ++r)
-    for (int c = 0; c < G::W; ++c) {
-      const char ch = map[r][c];
+  for (int r = 0; r < H0; ++r)
+    for (int c = 0; c < W0; ++c) {
+      const char ch = rows ? rows[(size_t)r * W0 + c] : map[r][c];
+      if (rows) {
+        if ((r == 0 || c == 0 || r == H0 - 1 || c == W0 - 1) && ch != '@') return "ascii_map: the layout must be walled in ('@' on its whole perimeter)";
+        const bool known = ch == '@' || ch == ' ' || ch == 'P' || (KIND == CE_KIND_CLEANUP ? (ch == 'B' || ch == 'H' || ch == 'R' || ch == 'S') : ch == 'A');
+        if (!known) return "ascii_map: a character outside the kind's alphabet";
+        if (ch == 'P' && ns >= G::NSPAWN_CTOR) return "ascii_map: more spawn points than the shipped layout (10 cleanup, 20 harvest)";
+        if (ch == (KIND == CE_KIND_CLEANUP ? 'B' : 'A') && na >= G::NAPPLE) return "ascii_map: more apple cells than the shipped layout (103 cleanup, 155 harvest)";
+        if (KIND == CE_KIND_CLEANUP && (ch == 'H' || ch == 'R') && nw >= G::NWASTE) return "ascii_map: more waste cells than the shipped layout (119)";
+      }
       const uint32_t pad = (uint32_t)((r + kView) * G::PW + c + kView);
       const uint32_t packed = pad | ((uint32_t)c << 16) | ((uint32_t)r << 24);
       uint8_t code = CE_CELL_EMPTY;
@@ -72,12 +88,17 @@ template <int KIND> static void build_tables(GridTables& t) {
       t.base_pmap[pad] = code;
       t.base_pmap4[pad] = (uint8_t)(code << 2);
     }
+  if (rows && (ns < 1 || na < 1 || (KIND == CE_KIND_CLEANUP && nw < 1))) return "ascii_map: the layout needs at least one spawn point, one apple cell and (cleanup) one waste cell";
+  if (rows && num_agents > (uint32_t)ns) return "ascii_map: more agents than spawn points (the reference asserts 'not enough spawn points', map_env.py:826)";
+  counts[0] = (uint32_t)na;
+  counts[1] = (uint32_t)nw;
+  counts[2] = (uint32_t)ns;
   if (KIND == CE_KIND_CLEANUP)
-    for (int i = 0; i < 10; ++i) t.spawn[10 + i] = t.spawn[i];  // cleanup_new.py:114-115
+    for (int i = 0; i < ns; ++i) t.spawn[ns + i] = t.spawn[i];  // cleanup_new.py:114-115
   if (KIND == CE_KIND_CLEANUP) {
     // compute_probabilities (cleanup_new.py:351-368) for every possible #H, as exact 53-bit
     // thresholds: rand < p  <=>  X < ceil(p * 2^53) for the 53-bit integer X behind rand
-    const int potential = G::NWASTE;
+    const int potential = nw;
     for (int nH = 0; nH <= potential; ++nH) {
       volatile double free_area = (double)(potential - nH);
       volatile double density = 1 - free_area / (double)potential;
@@ -107,6 +128,7 @@ template <int KIND> static void build_tables(GridTables& t) {
       for (int kk = -5; kk <= 5; ++kk)
         if (j * j + kk * kk <= 5) t.close_off[k++] = (uint32_t)(int32_t)(j * G::PW + kk);  // harvest_new.py:326-336
   }
+  return nullptr;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -123,6 +145,12 @@ struct ce_engine {
   size_t gather_bytes;
   std::vector<char> h_gather;   // ... and its host landing buffer
   GridParams* d_gparams;        // device copy of the grid kernels' parameter block
+  // a caller's layout (ce_config.ascii_map): the handle's own tables in HBM, the lengths of its cell lists, its text
+  GridTables* d_tab;
+  GridTables* h_tab;
+  uint32_t map_counts[3];       // apple, waste, spawn cells
+  uint32_t map_h, map_w;
+  std::string map_text;
   std::vector<std::pair<void**, size_t>> allocs;
   std::string err;
   // timing
@@ -189,6 +217,9 @@ static int contract_ok(uint32_t kind, uint32_t contract) {
   return contract == CE_CONTRACT_SELFDRIVE_DISTPROP;
 }
 
+static uint32_t grid_napple(const ce_config& c) { return c.kind == CE_KIND_CLEANUP ? Geo<CE_KIND_CLEANUP>::NAPPLE : Geo<CE_KIND_HARVEST>::NAPPLE; }
+static uint32_t grid_nwaste(const ce_config& c) { return c.kind == CE_KIND_CLEANUP ? Geo<CE_KIND_CLEANUP>::NWASTE : Geo<CE_KIND_HARVEST>::NWASTE; }
+
 extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (!cfg || !out) return CE_EINVAL;
   *out = nullptr;
@@ -219,8 +250,25 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->d_gather = nullptr;
   h->gather_bytes = 0;
   h->d_gparams = nullptr;
+  h->d_tab = nullptr;
+  h->h_tab = nullptr;
+  h->map_h = h->map_w = 0;
+  h->map_counts[0] = h->map_counts[1] = h->map_counts[2] = 0;
+  h->cfg.ascii_map = nullptr;  // (the caller's string is copied below, never kept)
   std::memset(&h->buf, 0, sizeof(h->buf));
   *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
+  if (cfg->ascii_map) {  // a caller's layout: checked (and its tables built) before the device is touched
+    if (!is_grid(*cfg)) return fail(h, CE_EINVAL, "ascii_map belongs to the grid kinds (cleanup_new / harvest_new)");
+    h->h_tab = new (std::nothrow) GridTables();
+    if (!h->h_tab) return fail(h, CE_ENOMEM, "layout tables");
+    h->map_text.assign(cfg->ascii_map, (size_t)cfg->map_rows * cfg->map_cols);
+    const char* why = cfg->kind == CE_KIND_CLEANUP
+                          ? build_tables<CE_KIND_CLEANUP>(*h->h_tab, h->map_text.data(), (int)cfg->map_rows, (int)cfg->map_cols, cfg->num_agents, h->map_counts)
+                          : build_tables<CE_KIND_HARVEST>(*h->h_tab, h->map_text.data(), (int)cfg->map_rows, (int)cfg->map_cols, cfg->num_agents, h->map_counts);
+    if (why) return fail(h, CE_EINVAL, why);
+    h->map_h = cfg->map_rows;
+    h->map_w = cfg->map_cols;
+  }
 
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -246,8 +294,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (rc == CE_OK) rc = dalloc(h, &b.field, (count))
   if (is_grid(*cfg)) {
     const bool cl = cfg->kind == CE_KIND_CLEANUP;
-    b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
-    b.grid_w = cl ? Geo<0>::W : Geo<1>::W;
+    b.grid_h = h->h_tab ? h->map_h : (uint32_t)(cl ? Geo<0>::H : Geo<1>::H);  // a caller's layout: its own shape, embedded at the
+    b.grid_w = h->h_tab ? h->map_w : (uint32_t)(cl ? Geo<0>::W : Geo<1>::W);  // origin of the kind's frame (same strides / origin)
     h->grid_stride = cl ? Geo<0>::IMAGE_STRIDE : Geo<1>::IMAGE_STRIDE;  // of the ce_download / ce_upload image
     b.grid_env_stride = kGridStateBytes;                                  // of the packed state `grid` points to
     b.grid_row_stride = cl ? Geo<0>::PW : Geo<1>::PW;
@@ -266,6 +314,11 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
     A(features, E * n * b.num_features);
     A(beam_map, E * b.grid_h * b.grid_w);
     A(actions_taken, E * n);
+    if (h->h_tab) {
+      if (rc == CE_OK) rc = dalloc(h, &h->d_tab, 1);
+      if (rc == CE_OK && hipMemcpy(h->d_tab, h->h_tab, sizeof(GridTables), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(h, CE_ENODEV, "layout table upload failed");
+    }
   } else if (is_feat(*cfg)) {
     const bool cl = cfg->kind == CE_KIND_CLEANUP_FEATURES;
     b.grid_h = cl ? Geo<0>::H : Geo<1>::H;
@@ -285,8 +338,9 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
       struct BothTables {
         GridTables cleanup, harvest;
         BothTables() {
-          build_tables<CE_KIND_CLEANUP>(cleanup);
-          build_tables<CE_KIND_HARVEST>(harvest);
+          uint32_t cnt[3];
+          build_tables<CE_KIND_CLEANUP>(cleanup, nullptr, 0, 0, 0, cnt);
+          build_tables<CE_KIND_HARVEST>(harvest, nullptr, 0, 0, 0, cnt);
         }
       };
       static const BothTables built;  // once per process (thread-safe static); uploaded to this handle's device below
@@ -346,6 +400,7 @@ extern "C" int ce_destroy(ce_handle h) {
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   if (h->ev_mask) (void)hipEventDestroy(h->ev_mask);
   if (h->ev_reset) (void)hipEventDestroy(h->ev_reset);
+  delete h->h_tab;
   delete h;
   return CE_OK;
 }
@@ -396,6 +451,13 @@ static GridParams grid_params(ce_engine* h) {
   p.debug = h->d_debug;
   p.beam_map = b.beam_map;
   p.actions_taken = b.actions_taken;
+  p.tab = (decltype(p.tab))h->d_tab;
+  p.custom_map = h->d_tab ? 1u : 0u;
+  p.napple = h->map_counts[0];
+  p.nwaste = h->map_counts[1];
+  p.nspawn = h->map_counts[2];
+  p.map_h = h->map_h;
+  p.map_w = h->map_w;
   p.E = h->cfg.num_envs;
   p.n = h->cfg.num_agents;
   p.horizon = h->cfg.horizon;
@@ -700,7 +762,7 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
       if (hipError_t e = order_after_reset(h, stream); e != hipSuccess)
         return fail(h, CE_ENODEV, "fused rollout: the stream could not be ordered after the last ce_reset", e);
       if (is_grid(h->cfg))
-        (counter_rng(h->cfg) ? launch_grid_rollout_ctr : launch_grid_rollout)((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
+        (counter_rng(h->cfg) ? launch_grid_rollout_ctr : launch_grid_rollout)((int)h->cfg.kind, h->cfg.num_agents, h->d_tab != nullptr, h->d_gparams, ra, stream);
       else if (h->cfg.kind == CE_KIND_SELFDRIVE) launch_sd_rollout(sd_params(h), ra, stream);
       else launch_feat_rollout((int)h->cfg.kind, h->cfg.num_agents, h->d_gparams, ra, stream);
       if (h->timing_armed) h->timed_launches++;
@@ -838,7 +900,8 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
     // device first, as every other field does, so the presence bits are read between steps and not inside one
     e2 = hipDeviceSynchronize();
     if (e2 == hipSuccess) {
-      launch_grid_expand((int)h->cfg.kind, h->buf.grid, tmp, env_begin, env_count, nullptr);
+      launch_grid_expand((int)h->cfg.kind, h->buf.grid, tmp, env_begin, env_count, h->d_tab, h->d_tab ? h->map_counts[0] : grid_napple(h->cfg),
+                         h->d_tab ? h->map_counts[1] : grid_nwaste(h->cfg), nullptr);
       e2 = hipDeviceSynchronize();
     }
     if (e2 == hipSuccess) e2 = hipMemcpy(dst, tmp, (size_t)env_count * f.env_bytes, hipMemcpyDeviceToHost);
@@ -1026,7 +1089,8 @@ extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uin
     e2 = hipDeviceSynchronize();  // no step kernel may still be writing the bits this upload replaces
     if (e2 == hipSuccess) e2 = hipMemcpy(tmp, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
     if (e2 == hipSuccess) {
-      launch_grid_pack((int)h->cfg.kind, tmp, h->buf.grid, h->buf.error_flags, env_begin, env_count, nullptr);
+      launch_grid_pack((int)h->cfg.kind, tmp, h->buf.grid, h->buf.error_flags, env_begin, env_count, h->d_tab,
+                       h->d_tab ? h->map_counts[0] : grid_napple(h->cfg), h->d_tab ? h->map_counts[1] : grid_nwaste(h->cfg), nullptr);
       e2 = hipDeviceSynchronize();
     }
     (void)hipFree(tmp);

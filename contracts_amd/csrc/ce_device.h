@@ -101,12 +101,15 @@ struct GridParams {
   CE_GPTR(unsigned long long) debug;  // [E][16] phase cycle stamps (only written by CE_PHASE_STAMPS builds)
   CE_GPTR(uint8_t) beam_map;          // [E][H*W] CE_BEAM_*, written under CE_FLAG_BEAM_TRACE only
   CE_GPTR(uint8_t) actions_taken;     // [E][n] the action ids a ce_step_policy launch derived from the policy's output
+  CE_GPTR(const GridTables) tab;      // the handle's own static tables (a caller's layout, ce_config.ascii_map); null = c_tab[kind]
   // inputs
   CE_GPTR(const uint8_t) actions;  // [E][n]
   CE_GPTR(const uint8_t) mask;     // [E] or null (seed/reset)
   uint32_t E, n, horizon, contract, flags, obs_env_stride, num_features;
   uint32_t replay_constructor;
   uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
+  uint32_t custom_map;            // 1 = the kernels' CM instances run: tables from `tab`, list lengths below
+  uint32_t napple, nwaste, nspawn, map_h, map_w;
   double contract_low, contract_high, null_prob, alpha, beta;
 };
 
@@ -160,8 +163,10 @@ void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_feat_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
 int upload_grid_tables(int kind, const GridTables& t, const uint32_t* rgb16);
-void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, uint32_t env_first, uint32_t env_count, void* stream);
-void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, uint32_t* error_flags, uint32_t env_first, uint32_t env_count, void* stream);
+void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, uint32_t env_first, uint32_t env_count, const GridTables* tab,
+                        uint32_t napple, uint32_t nwaste, void* stream);
+void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, uint32_t* error_flags, uint32_t env_first, uint32_t env_count,
+                      const GridTables* tab, uint32_t napple, uint32_t nwaste, void* stream);
 void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,
                     const uint8_t* mask_dev, uint32_t E, int python_seeding, void* stream);
 // `p` carries the per-call pointers (actions / mask) and the batch size; `dp` is the device-resident copy of
@@ -170,7 +175,7 @@ void launch_grid_construct(int kind, const GridParams& p, const GridParams* dp, 
 void launch_grid_reset(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step_policy(int kind, int policy, const GridParams& p, const GridParams* dp, void* stream);
-void launch_grid_rollout(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
+void launch_grid_rollout(int kind, uint32_t num_agents, bool custom_map, const GridParams* dp, const RolloutArgs& ra, void* stream);
 // the same kernels over the counter-RNG stream (CE_FLAG_RNG_COUNTER; ce_grid_kernels_ctr.hip), with their own constant tables
 inline namespace ctr {
 int upload_grid_tables_ctr(int kind, const GridTables& t, const uint32_t* rgb16);
@@ -179,7 +184,7 @@ void launch_grid_construct_ctr(int kind, const GridParams& p, const GridParams* 
 void launch_grid_reset_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step_ctr(int kind, const GridParams& p, const GridParams* dp, void* stream);
 void launch_grid_step_policy_ctr(int kind, int policy, const GridParams& p, const GridParams* dp, void* stream);
-void launch_grid_rollout_ctr(int kind, uint32_t num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream);
+void launch_grid_rollout_ctr(int kind, uint32_t num_agents, bool custom_map, const GridParams* dp, const RolloutArgs& ra, void* stream);
 int launch_selftest_ctr(uint32_t* out_dev, void* stream);
 }  // namespace ctr
 void launch_sd_construct(const SdParams& p, void* stream);

@@ -746,10 +746,37 @@ template <int KIND> struct Env {
   // two-wave workgroups (k_grid_step_duo): the helper wave's LDS block and the hand-over words; null otherwise
   WaveLds<KIND>* LH;
   struct DuoX* X;
+  // The layout the env is built from (env_geometry): the static tables and the lengths of its cell lists.  For the shipped layout
+  // these are literals — everything is inlined into the kernel, so they fold exactly like the Geo<KIND> constants they stand
+  // for; a kernel instance for a caller's layout (ce_config.ascii_map, CM = true) reads them from the parameter block.
+  const GridTables* T;
+  u32 napple, nwaste, randw, nspawn;  // apple / waste cells, stream words of the spawn model's rand() call, 'P' cells
+  u32 cells, mapw;                    // rows x columns and columns of the layout (the beam_map's shape)
 };
 
 DEVINL i32 dir_delta(int PW, u32 o) {  // ORIENTATIONS map_env.py:22 as padded-index deltas
   return o == 0 ? -PW : o == 1 ? 1 : o == 2 ? PW : -1;
+}
+
+template <int KIND, bool CM> DEVINL void env_geometry(Env<KIND>& E, const GridParams& p) {
+  typedef Geo<KIND> G;
+  if (CM) {
+    E.T = (const GridTables*)p.tab;
+    E.napple = p.napple;
+    E.nwaste = p.nwaste;
+    E.randw = 2u * (p.napple + p.nwaste);
+    E.nspawn = p.nspawn;
+    E.cells = p.map_h * p.map_w;
+    E.mapw = p.map_w;
+  } else {
+    E.T = &c_tab[KIND];
+    E.napple = (u32)G::NAPPLE;
+    E.nwaste = (u32)G::NWASTE;
+    E.randw = (u32)G::RANDW;
+    E.nspawn = (u32)G::NSPAWN_CTOR;
+    E.cells = (u32)(G::H * G::W);
+    E.mapw = (u32)G::W;
+  }
 }
 
 template <int KIND> DEVINL u32 pad_of(u32 row, u32 col) { return __umul24(row + kView, (u32)Geo<KIND>::PW) + col + kView; }
@@ -780,17 +807,16 @@ template <int KIND> DEVINL u32 agent_on(const Env<KIND>& E, u32 cell) {
 // state load / store
 // ----------------------------------------------------------------------------------------
 template <int KIND> DEVINL void load_static(Env<KIND>& E) {
-  typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     u32 idx = E.lane + 64 * r;
-    E.AP[r] = idx < (u32)G::NAPPLE ? T.apple[idx < 160 ? idx : 0] : 0;
+    E.AP[r] = idx < E.napple ? T.apple[idx < 160 ? idx : 0] : 0;
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     u32 idx = E.lane + 64 * r;
-    E.WS[r] = idx < (u32)G::NWASTE ? T.waste[idx < 128 ? idx : 0] : 0;
+    E.WS[r] = idx < E.nwaste ? T.waste[idx < 128 ? idx : 0] : 0;
   }
   if (E.lane < 16) E.L->rgb[E.lane] = c_rgb[E.lane];
 }
@@ -862,13 +888,13 @@ template <int KIND> DEVINL void paint_presence(Env<KIND>& E, const u32 (&bits)[8
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
     const u64 m = (u64)bits[2 * r] | (u64)bits[2 * r + 1] << 32;
-    pm_put(pm, E.lane + 64 * r < (u32)G::NAPPLE, cell_pad(E.AP[r]), select_by_mask(m, kApple, kEmpty));
+    pm_put(pm, E.lane + 64 * r < E.napple, cell_pad(E.AP[r]), select_by_mask(m, kApple, kEmpty));
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const u64 m = (u64)bits[4 + 2 * r] | (u64)bits[5 + 2 * r] << 32;
-      pm_put(pm, E.lane + 64 * r < (u32)G::NWASTE, cell_pad(E.WS[r]), select_by_mask(m, kWaste, kRiver));
+      pm_put(pm, E.lane + 64 * r < E.nwaste, cell_pad(E.WS[r]), select_by_mask(m, kWaste, kRiver));
     }
   }
 }
@@ -900,11 +926,11 @@ template <int KIND> DEVINL void store_grid(Env<KIND>& E, const GridParams& p, bo
   u64 presA[3] = {0, 0, 0}, presW[2] = {0, 0};
 #pragma unroll
   for (int r = 0; r < AR; ++r)
-    presA[r] = ballot(both(E.lane + 64 * r < (u32)G::NAPPLE, (pm[cell_pad(E.AP[r])] & kCodeMask) == kApple));
+    presA[r] = ballot(both(E.lane + 64 * r < E.napple, (pm[cell_pad(E.AP[r])] & kCodeMask) == kApple));
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-      presW[r] = ballot(both(E.lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
+      presW[r] = ballot(both(E.lane + 64 * r < E.nwaste, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
   }
   store_grid_bits(E, p, presA, presW, blank);
 }
@@ -945,7 +971,7 @@ template <int KIND> DEVINL void store_perms(Env<KIND>& E, const GridParams& p, b
 // LDS image (MT words, padded map) is built.  Used by the step kernel.
 template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p) {
   typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
   const u32 lane = E.lane;
   // Every load and LDS store below is unconditional: a lane past the end of a list repeats the last element (clamped
   // index, same value to the same address).  A divergent `if` around a single load costs a compare, an exec save /
@@ -986,14 +1012,14 @@ template <int KIND> DEVINL void load_env_state(Env<KIND>& E, const GridParams& p
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const u32 idx = lane + 64 * r;
-    const u32 v = T.apple[min(idx, (u32)G::NAPPLE - 1u)];
-    E.AP[r] = idx < (u32)G::NAPPLE ? v : 0;
+    const u32 v = T.apple[min(idx, E.napple - 1u)];
+    E.AP[r] = idx < E.napple ? v : 0;
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const u32 idx = lane + 64 * r;
-    const u32 v = T.waste[G::NWASTE ? min(idx, (u32)(G::NWASTE ? G::NWASTE - 1 : 0)) : 0u];
-    E.WS[r] = idx < (u32)G::NWASTE ? v : 0;
+    const u32 v = T.waste[G::NWASTE ? min(idx, E.nwaste - 1u) : 0u];
+    E.WS[r] = idx < E.nwaste ? v : 0;
   }
   const u32 rgbv = c_rgb[lane & 15];
   if (kCounterRng) {  // the step's generation, computed under the loads above
@@ -1170,9 +1196,8 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
 // ----------------------------------------------------------------------------------------
 // render support (CE_FLAG_BEAM_TRACE): MapEnv.beam_pos as a per-cell map, cleared at step entry and by reset()
 template <int KIND> DEVINL void clear_beam_map(Env<KIND>& E, const GridParams& p) {
-  typedef Geo<KIND> G;
-  const auto bm = p.beam_map + (size_t)E.e * (G::H * G::W);
-  for (u32 k = E.lane; k < (u32)(G::H * G::W); k += 64) GAT(bm, k) = CE_BEAM_NONE;
+  const auto bm = p.beam_map + (size_t)E.e * E.cells;
+  for (u32 k = E.lane; k < E.cells; k += 64) GAT(bm, k) = CE_BEAM_NONE;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the beams of this step overwrite these bytes from other lanes
 }
 
@@ -1197,8 +1222,8 @@ template <int KIND> DEVINL u32 fire_beam(Env<KIND>& E, const GridParams& p, u32 
   const u32 f = rb ? (u32)__builtin_ctz(rb) : 5u;  // first stopping cell of this ray
   const bool processed = in_beam && (step < f || (step == f && !invalid));
   if (p.flags & CE_FLAG_BEAM_TRACE) {  // firing_points (map_env.py:788,813); the walls around the map keep them inside
-    const auto bm = p.beam_map + (size_t)E.e * (G::H * G::W);
-    if (processed) GAT(bm, __umul24(row_of<KIND>(cell), (u32)G::W) + col_of<KIND>(cell)) = is_clean ? CE_BEAM_CLEAN : CE_BEAM_FIRE;
+    const auto bm = p.beam_map + (size_t)E.e * E.cells;
+    if (processed) GAT(bm, __umul24(row_of<KIND>(cell), E.mapw) + col_of<KIND>(cell)) = is_clean ? CE_BEAM_CLEAN : CE_BEAM_FIRE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a later beam of this step overwrites in list order
   }
   u32 cleaned = 0;
@@ -1235,7 +1260,7 @@ struct StreamWindow {
   u32* mt;
   u32 pos, alen;  // window start in the current generation; words of the window that lie in it
 };
-template <int RANDW> DEVINL StreamWindow window_open(Rng& r, u32 lane) {
+DEVINL StreamWindow window_open(Rng& r, u32 lane, u32 RANDW) {
   rng_assert_uniform(r);
   if (r.pos >= kGen) {
     rng_advance(r, lane);
@@ -1258,7 +1283,7 @@ DEVINL u32 window_read_new(const StreamWindow& w, bool need, u32 s, u32 old) {
   const u32 v = w.mt[ok ? s - w.alen : 0u];
   return ok ? v : old;
 }
-template <int RANDW> DEVINL void window_close(Rng& r, const StreamWindow& w) {
+DEVINL void window_close(Rng& r, const StreamWindow& w, u32 RANDW) {
   r.pos = w.alen < (u32)RANDW ? (u32)RANDW - w.alen : w.pos + (u32)RANDW;
   r.ccount = 0;
 }
@@ -1275,7 +1300,7 @@ DEVINL bool below_lo(u32 b_raw, u64 thr) { return (mt_temper(b_raw) >> 6) < ((u3
 // scan; here it is only adopted (list, stream position, the helper's stream copy) behind one workgroup barrier.
 template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E) {
   typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
   const u32 lane = E.lane;
   const u64 lt = (1ull << lane) - 1ull;
   uint8_t* pm = E.L->pmap;
@@ -1293,7 +1318,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
     // compute_probabilities: #H on the map -> host-precomputed 53-bit threshold
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const bool v = lane + 64 * r < (u32)G::NWASTE;
+      const bool v = lane + 64 * r < E.nwaste;
       hmask[r] = ballot(both(v, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste));
       nH += popc64(hmask[r]);
     }
@@ -1315,7 +1340,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
   if (scan) {
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
-    const bool v = lane + 64 * r < (u32)G::NAPPLE;
+    const bool v = lane + 64 * r < E.napple;
     const u32 cell = cell_pad(E.AP[r]);
     elig[r] = both(v, pm[cell] == kEmpty);
     if (KIND == CE_KIND_CLEANUP) {
@@ -1338,7 +1363,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
   }
   CE_SUBSTAMP(11);
   // waste walk candidates: the t-th non-waste cell of the (shuffled) list gets double rbase + t
-  const u32 ncand = (u32)G::NWASTE - nH;
+  const u32 ncand = E.nwaste - nH;
   bool needw[2] = {false, false};
   u32 sw[2] = {0, 0};
   if (KIND == CE_KIND_CLEANUP) {
@@ -1349,7 +1374,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
       sw[r] = 2 * (rbase + t);
     }
   }
-  StreamWindow W = window_open<G::RANDW>(E.rng, lane);
+  StreamWindow W = window_open(E.rng, lane, E.randw);
   u32 wa[AR], wb[AR], ww[2] = {0, 0};
 #pragma unroll
   for (int r = 0; r < AR; ++r) wa[r] = wb[r] = 0;
@@ -1364,7 +1389,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
       for (int r = 0; r < 2; ++r) ww[r] = window_read_old(W, needw[r], sw[r]);
     }
   }
-  if (W.alen < (u32)G::RANDW) {  // the window runs into the next generation
+  if (W.alen < E.randw) {  // the window runs into the next generation
     rng_advance(E.rng, lane);
     if (scan) {
 #pragma unroll
@@ -1378,7 +1403,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
       }
     }
   }
-  window_close<G::RANDW>(E.rng, W);
+  window_close(E.rng, W, E.randw);
   if (DUO) CE_DSTAMP(E.dbg, 4);
   if (DUO) __syncthreads();  // hand-over 1: the helper's shuffle results are in its LDS block (every step passes here)
   if (DUO) CE_DSTAMP(E.dbg, 5);
@@ -1415,7 +1440,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
         E.waste_perm_dirty = true;
         const u32* wp = E.LH->U;
         E.WP0 = wp[lane];
-        E.WP1 = lane + 64 < (u32)G::NWASTE ? wp[64 + lane] : 0u;
+        E.WP1 = lane + 64 < E.nwaste ? wp[64 + lane] : 0u;
         E.rng.mt = E.LH->mt;
         E.rng.pos = rfl(E.X->rng_pos);
         E.rng.twists = rfl(E.X->rng_twists);
@@ -1423,17 +1448,20 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
         E.rng.ccount = 0;
         E.rng.cvalid = 0;
       } else if (diag::seq_shuffle) {
-        shuffle_core<true>(E.rng, E.WP0, E.WP1, (u32)G::NWASTE, lane);
+        shuffle_core<true>(E.rng, E.WP0, E.WP1, E.nwaste, lane);
+      } else if (E.nwaste <= 64u) {  // a caller's small layout (never the shipped one: 119): the list lives in one register
+        E.waste_perm_dirty = true;
+        shuffle_lanes1(E.rng, E.WP0, E.nwaste, lane);
       } else {
         // U is free scratch: first the draw list J[0..118], then the step-mask table of the list update (which
         // spills into S)
         E.waste_perm_dirty = true;
-        shuffle_draws(E.rng, (u32)G::NWASTE, E.L->U, lane);
+        shuffle_draws(E.rng, E.nwaste, E.L->U, lane);
         CE_SUBSTAMP(10);
         static_assert(offsetof(WaveLds<KIND>, S) == offsetof(WaveLds<KIND>, U) + sizeof(E.L->U), "S must follow U");
         static_assert(KIND != CE_KIND_CLEANUP || sizeof(E.L->U) + sizeof(E.L->S) >= 8 * G::NWASTE, "step-mask table does not fit");
-        if (diag::serial_apply) shuffle_apply(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
-        else shuffle_apply_par(E.WP0, E.WP1, (u32)G::NWASTE, E.L->U, lane);
+        if (diag::serial_apply) shuffle_apply(E.WP0, E.WP1, E.nwaste, E.L->U, lane);
+        else shuffle_apply_par(E.WP0, E.WP1, E.nwaste, E.L->U, lane);
       }
       CE_SUBSTAMP(13);
       if (tstar != 0xffffffffu) {  // the tstar-th candidate in shuffled order gets the waste
@@ -1441,7 +1469,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
         // the presence ballots taken above — no lookup of the entry's cell, no map read; only the chosen entry's cell
         // is fetched (a readlane of the static table held in E.WS)
         static_assert(KIND != CE_KIND_CLEANUP || (G::NWASTE > 64 && G::NWASTE <= 128), "two lane rounds");
-        const bool v1 = lane + 64 < (u32)G::NWASTE;
+        const bool v1 = lane + 64 < E.nwaste;
         const u32 w0 = E.WP0, w1 = v1 ? E.WP1 : 0u;
         const u64 h0 = w0 < 64u ? hmask[0] : hmask[1], h1 = w1 < 64u ? hmask[0] : hmask[1];
         const bool cand0 = ((h0 >> (w0 & 63u)) & 1ull) == 0;
@@ -1612,7 +1640,7 @@ template <int KIND> DEVINL void zero_metrics(Env<KIND>& E, const GridParams& p) 
 // spawn list, take the LAST free entry, randint(4) orientation)
 // ----------------------------------------------------------------------------------------
 template <int KIND> DEVINL bool setup_agents(Env<KIND>& E, u32 list_len) {
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
   const u32 lane = E.lane;
   bool ok = true;
   E.P = 0xffffu;
@@ -1659,11 +1687,11 @@ template <int KIND> DEVINL void sample_theta(Env<KIND>& E, const GridParams& p, 
 // MapEnv.reset + CleanupEnv/HarvestEnv.reset + wrapper reset (state ends up in E / LDS)
 template <int KIND> DEVINL void reset_env(Env<KIND>& E, const GridParams& p, double& theta, u32& t, u32& fault) {
   typedef Geo<KIND> G;
-  if (!setup_agents(E, 20)) fault |= CE_FAULT_NO_SPAWN;
+  if (!setup_agents(E, KIND == CE_KIND_CLEANUP ? 2u * E.nspawn : E.nspawn)) fault |= CE_FAULT_NO_SPAWN;  // cleanup's doubled list (cleanup_new.py:114-115)
   if (!E.is_agent) E.P = 0xffffu;
   wave_sync();
   {  // reset_map + custom_reset: the static padded base map
-    const u32* src = (const u32*)c_tab[KIND].base_pmap;
+    const u32* src = (const u32*)E.T->base_pmap;
     u32* dst = (u32*)E.L->pmap;
     for (u32 k = E.lane; k < (u32)G::PCELLS / 4; k += 64) dst[k] = src[k] << kScale;
   }
@@ -1712,7 +1740,7 @@ template <class P> DEVINL void store_feat2(P f, u32 idx, u32 lo, u32 hi, bool al
 template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned,
                                                 u64 (&presA)[3], u64 (&presW)[2]) {
   typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
   const u32 lane = E.lane, n = E.n;
   uint8_t* pm = E.L->pmap;
   const u32 nf = p.num_features;
@@ -1732,7 +1760,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   constexpr u32 NCHUNK = KIND == CE_KIND_CLEANUP ? 32u : 48u;  // 4-cell chunks per list (a multiple of the largest group, 16 lanes)
   constexpr u32 kNoKey = 0x7f000000u;  // list entry of an absent cell: its key (sad << 16) + entry stays above every real key, no wrap
   constexpr u32 NENT = NCHUNK * 4u;
-  static_assert(NENT >= (u32)G::NAPPLE && (KIND != CE_KIND_CLEANUP || NENT >= (u32)G::NWASTE), "key list too short");
+  static_assert(NENT >= (u32)G::NAPPLE && (KIND != CE_KIND_CLEANUP || NENT >= (u32)G::NWASTE), "key list too short");  // (a caller's layout never has more cells than the shipped one)
   static_assert(KIND == CE_KIND_CLEANUP ? 2 * NENT * 4 <= sizeof(E.L->U) + sizeof(E.L->S) : NENT * 4 <= sizeof(E.L->U), "scratch");
   u32* keyA = E.L->U;
   u32* keyW = E.L->U + NENT;
@@ -1742,7 +1770,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     bool f = false;
     u32 rc = 0;
     if (r < 3) {
-      f = both(lane + 64 * r < (u32)G::NAPPLE, pm[cell_pad(E.AP[r < 3 ? r : 0])] == kApple);
+      f = both(lane + 64 * r < E.napple, pm[cell_pad(E.AP[r < 3 ? r : 0])] == kApple);
       rc = cell_rc(E.AP[r < 3 ? r : 0]);
     }
     const u64 fb = ballot(f);
@@ -1753,7 +1781,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
     for (u32 r = 0; r < 2; ++r) {
-      const bool f = both(lane + 64 * r < (u32)G::NWASTE, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste);
+      const bool f = both(lane + 64 * r < E.nwaste, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste);
       presW[r] = ballot(f);
       nwaste += popc64(presW[r]);
       keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
@@ -1927,21 +1955,21 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
 }
 
 // --- seed + "construct": replay the RNG use of MapEnv.__init__ (map_env.py:122-131) ---
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+template <int KIND, bool CM> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_construct(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
                  u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds, env_first, env_end)) return;
+  env_geometry<KIND, CM>(E, p);
   if (call_mask && call_mask[E.e] == 0) return;
-  typedef Geo<KIND> G;
   load_static(E);
   load_rng(E, p);
   E.SP = E.lane < 20 ? E.lane : 0;
   E.WP0 = E.lane;
   E.WP1 = E.lane + 64;
   u32 fault = 0;
-  if (!setup_agents(E, (u32)G::NSPAWN_CTOR)) fault |= CE_FAULT_NO_SPAWN;
+  if (!setup_agents(E, E.nspawn)) fault |= CE_FAULT_NO_SPAWN;
   zero_pmap(E);  // world_map is blank until the first reset
   store_grid(E, p, true);
   store_agents(E, p);
@@ -1966,12 +1994,13 @@ template <int KIND> DEVINL void clear_step_outputs(Env<KIND>& E, const GridParam
   }
 }
 
-template <int KIND> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
+template <int KIND, bool CM> __global__ __launch_bounds__(64 * kWavesPerBlock) void k_grid_reset(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, const uint8_t* __restrict__ call_mask,
                  u32 env_first, u32 env_end) {
   const GridParams& p = *pp;
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, p, lds, env_first, env_end)) return;
+  env_geometry<KIND, CM>(E, p);
   if (call_mask && call_mask[E.e] == 0) return;
   load_static(E);
   load_rng(E, p);
@@ -2029,7 +2058,7 @@ struct StepOutPlane {
 template <int KIND, bool FUSED, class OUT, bool DUO = false>
 DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u32 ACT, u32& t, double& theta, u32& fault,
                            bool& did_reset) {
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = *E.T;
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
   const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
@@ -2364,7 +2393,7 @@ template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, 
   return is_agent ? arg : 4u;
 }
 
-template <int KIND, int NFIX, int POLICY = 0>
+template <int KIND, int NFIX, int POLICY = 0, bool CM = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(
     const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
     uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
@@ -2387,6 +2416,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
   ph.n = NFIX ? (u32)NFIX : num_agents;
   const auto acts = (CE_GPTR(const uint8_t))call_actions;
   env_begin(E, ph, lds, env_first, 0xffffffffu);
+  env_geometry<KIND, CM>(E, p);
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
 
@@ -2438,6 +2468,7 @@ template <int KIND> DEVINL void duo_helper(const GridParams& p, WaveLds<KIND>* l
   H.X = nullptr;
   H.dbg = nullptr;
   H.waste_perm_dirty = false;
+  env_geometry<KIND, false>(H, p);
   const u32 lane = H.lane;
   const size_t ea = (size_t)H.e * n;
 #ifdef CE_DUO_STAMPS
@@ -2482,9 +2513,9 @@ template <int KIND> DEVINL void duo_helper(const GridParams& p, WaveLds<KIND>* l
     shuffle_small<2>(r, d0, n, lane);
   }
   {  // rand(222): the window only moves the stream here
-    const StreamWindow W = window_open<G::RANDW>(r, lane);
+    const StreamWindow W = window_open(r, lane, (u32)G::RANDW);
     if (W.alen < (u32)G::RANDW) rng_advance(r, lane);
-    window_close<G::RANDW>(r, W);
+    window_close(r, W, (u32)G::RANDW);
   }
   CE_DSTAMP(H.dbg, 11);
   if (*(volatile u32*)&X->need != 2u) shuffle_draws(r, (u32)G::NWASTE, H.L->U, lane, (const volatile u32*)&X->need);
@@ -2545,6 +2576,7 @@ __global__ __launch_bounds__(128, CE_CLEANUP_WAVES) void k_grid_step_duo(
   ph.debug = nullptr;
   ph.n = nn;
   env_begin(E, ph, lds, env_first, 0xffffffffu);
+  env_geometry<KIND, false>(E, p);
   E.LH = lds + 1;
   E.X = &dx;
   const u32 lane = E.lane, n = E.n;
@@ -2568,8 +2600,8 @@ __global__ __launch_bounds__(128, CE_CLEANUP_WAVES) void k_grid_step_duo(
     u32 nH0 = 0;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-      nH0 += popc64(ballot(both(lane + 64 * r < (u32)Geo<KIND>::NWASTE, (E.L->pmap[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
-    const bool on0 = (c_tab[KIND].apple_thresh[nH0] & kWasteOnBit) != 0;
+      nH0 += popc64(ballot(both(lane + 64 * r < E.nwaste, (E.L->pmap[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
+    const bool on0 = (E.T->apple_thresh[nH0] & kWasteOnBit) != 0;
     const bool cleans = ballot(E.is_agent && ACT == 7) != 0;
     if (lane == 0) *(volatile u32*)&dx.need = on0 ? 1u : cleans ? 0u : 2u;
   }
@@ -2617,13 +2649,14 @@ template <class T> DEVINL const T& opaque_block(const T* q) {
 // headline — and 6 / 4 waves (80 / 128 VGPRs, few / no spills) for launches that leave at most that many waves per SIMD, where
 // every wave is resident anyway and spills only cost.  launch_grid_rollout picks by the size of the launch.
 // NFIX as for k_grid_step: the instance for n = 8 folds every branch on the number of agents (and frees the register n lives in).
-template <int KIND, int WAVES, int NFIX> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+template <int KIND, int WAVES, int NFIX, bool CM = false> __global__ __launch_bounds__(64 * kWavesPerBlock, WAVES) void k_grid_rollout(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
   // the by-value argument block is read in place from the kernarg segment (it follows the 8-byte pp)
   static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
   const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   __shared__ WaveLds<KIND> lds[kWavesPerBlock];
   Env<KIND> E;
   if (!env_begin(E, *pp, lds, rap->env_first, rap->env_end)) return;
+  env_geometry<KIND, CM>(E, *pp);
   if (NFIX) {
     E.n = (u32)NFIX;
     E.is_agent = E.lane < E.n;
@@ -3680,9 +3713,9 @@ template <int GK, int NFIX> __global__ __launch_bounds__(64, CE_FEAT_ROLLOUT_WAV
 // ce_download / ce_upload("grid"): packed presence bits <-> the padded map image (one wave per env)
 // ----------------------------------------------------------------------------------------
 template <int KIND> __global__ __launch_bounds__(64) void k_grid_expand(const uint8_t* __restrict__ state, uint8_t* __restrict__ image,
-                                                                     u32 env_first, u32 env_count) {
+                                                                     u32 env_first, u32 env_count, const GridTables* tab, u32 napple, u32 nwaste) {
   typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = tab ? *tab : c_tab[KIND];  // a handle built from a caller's layout carries its own tables
   if (blockIdx.x >= env_count) return;
   const u32 lane = lane_id(), e = env_first + blockIdx.x;
   const u32* bits = (const u32*)(state + (size_t)e * kGridStateBytes);
@@ -3693,14 +3726,15 @@ template <int KIND> __global__ __launch_bounds__(64) void k_grid_expand(const ui
   if (blank) return;
   __syncthreads();
   uint8_t* img = image + (size_t)blockIdx.x * G::IMAGE_STRIDE;
-  for (u32 c = lane; c < (u32)G::NAPPLE; c += 64) img[cell_pad(T.apple[c])] = (bits[c >> 5] >> (c & 31)) & 1u ? CE_CELL_APPLE : CE_CELL_EMPTY;
+  for (u32 c = lane; c < napple; c += 64) img[cell_pad(T.apple[c])] = (bits[c >> 5] >> (c & 31)) & 1u ? CE_CELL_APPLE : CE_CELL_EMPTY;
   if (KIND == CE_KIND_CLEANUP)
-    for (u32 c = lane; c < (u32)G::NWASTE; c += 64) img[cell_pad(T.waste[c])] = (bits[4 + (c >> 5)] >> (c & 31)) & 1u ? CE_CELL_WASTE : CE_CELL_RIVER;
+    for (u32 c = lane; c < nwaste; c += 64) img[cell_pad(T.waste[c])] = (bits[4 + (c >> 5)] >> (c & 31)) & 1u ? CE_CELL_WASTE : CE_CELL_RIVER;
 }
 template <int KIND> __global__ __launch_bounds__(64) void k_grid_pack(const uint8_t* __restrict__ image, uint8_t* __restrict__ state,
-                                                                   u32* __restrict__ error_flags, u32 env_first, u32 env_count) {
+                                                                   u32* __restrict__ error_flags, u32 env_first, u32 env_count, const GridTables* tab,
+                                                                   u32 napple, u32 nwaste) {
   typedef Geo<KIND> G;
-  const GridTables& T = c_tab[KIND];
+  const GridTables& T = tab ? *tab : c_tab[KIND];
   if (blockIdx.x >= env_count) return;
   __shared__ uint8_t chk[G::PCELLS];
   const u32 lane = lane_id(), e = env_first + blockIdx.x;
@@ -3714,30 +3748,30 @@ template <int KIND> __global__ __launch_bounds__(64) void k_grid_pack(const uint
   __syncthreads();
   u32 w = 0;
   bool bad = false;
-  for (u32 r = 0; r < ((u32)G::NAPPLE + 63) / 64; ++r) {
+  for (u32 r = 0; r < (napple + 63) / 64; ++r) {
     const u32 c = lane + 64 * r;
-    const u32 cell = cell_pad(T.apple[c < (u32)G::NAPPLE ? c : 0]);
-    const uint8_t v = c < (u32)G::NAPPLE ? chk[cell] : (uint8_t)0;
-    const u64 m = ballot(c < (u32)G::NAPPLE && v == CE_CELL_APPLE);
-    bad = bad || (c < (u32)G::NAPPLE && v != CE_CELL_APPLE && v != CE_CELL_EMPTY);
+    const u32 cell = cell_pad(T.apple[c < napple ? c : 0]);
+    const uint8_t v = c < napple ? chk[cell] : (uint8_t)0;
+    const u64 m = ballot(c < napple && v == CE_CELL_APPLE);
+    bad = bad || (c < napple && v != CE_CELL_APPLE && v != CE_CELL_EMPTY);
     if (lane == 2 * r) w = (u32)m;
     if (lane == 2 * r + 1) w = (u32)(m >> 32);
   }
   if (KIND == CE_KIND_CLEANUP)
     for (u32 r = 0; r < 2; ++r) {
       const u32 c = lane + 64 * r;
-      const u32 cell = cell_pad(T.waste[c < (u32)G::NWASTE ? c : 0]);
-      const uint8_t v = c < (u32)G::NWASTE ? chk[cell] : (uint8_t)0;
-      const u64 m = ballot(c < (u32)G::NWASTE && v == CE_CELL_WASTE);
-      bad = bad || (c < (u32)G::NWASTE && v != CE_CELL_WASTE && v != CE_CELL_RIVER);
+      const u32 cell = cell_pad(T.waste[c < nwaste ? c : 0]);
+      const uint8_t v = c < nwaste ? chk[cell] : (uint8_t)0;
+      const u64 m = ballot(c < nwaste && v == CE_CELL_WASTE);
+      bad = bad || (c < nwaste && v != CE_CELL_WASTE && v != CE_CELL_RIVER);
       if (lane == 4 + 2 * r) w = (u32)m;
       if (lane == 5 + 2 * r) w = (u32)(m >> 32);
     }
   __syncthreads();
   // every other cell must be the static map: neutralise the variable cells, then compare with the base image
-  for (u32 c = lane; c < (u32)G::NAPPLE; c += 64) chk[cell_pad(T.apple[c])] = T.base_pmap[cell_pad(T.apple[c])];
+  for (u32 c = lane; c < napple; c += 64) chk[cell_pad(T.apple[c])] = T.base_pmap[cell_pad(T.apple[c])];
   if (KIND == CE_KIND_CLEANUP)
-    for (u32 c = lane; c < (u32)G::NWASTE; c += 64) chk[cell_pad(T.waste[c])] = T.base_pmap[cell_pad(T.waste[c])];
+    for (u32 c = lane; c < nwaste; c += 64) chk[cell_pad(T.waste[c])] = T.base_pmap[cell_pad(T.waste[c])];
   __syncthreads();
   for (u32 k = lane; k < (u32)G::PCELLS; k += 64) bad = bad || chk[k] != T.base_pmap[k];
   if (blank) {
@@ -3971,11 +4005,17 @@ static unsigned duo_max_envs() {
   do {                                                                                                \
     const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;             \
     dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);             \
-    if (kind == CE_KIND_CLEANUP)                                                                      \
-      hipLaunchKernelGGL(kern<CE_KIND_CLEANUP>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
+    if (kind == CE_KIND_CLEANUP && !p.custom_map)                                                     \
+      hipLaunchKernelGGL((kern<CE_KIND_CLEANUP, false>), grid, block, extra_lds(), (hipStream_t)stream, dp, \
+                         p.actions, p.mask, first, first + count);                                    \
+    else if (kind == CE_KIND_CLEANUP)                                                                 \
+      hipLaunchKernelGGL((kern<CE_KIND_CLEANUP, true>), grid, block, extra_lds(), (hipStream_t)stream, dp, \
+                         p.actions, p.mask, first, first + count);                                    \
+    else if (!p.custom_map)                                                                           \
+      hipLaunchKernelGGL((kern<CE_KIND_HARVEST, false>), grid, block, extra_lds(), (hipStream_t)stream, dp, \
                          p.actions, p.mask, first, first + count);                                    \
     else                                                                                              \
-      hipLaunchKernelGGL(kern<CE_KIND_HARVEST>, grid, block, extra_lds(), (hipStream_t)stream, dp,    \
+      hipLaunchKernelGGL((kern<CE_KIND_HARVEST, true>), grid, block, extra_lds(), (hipStream_t)stream, dp, \
                          p.actions, p.mask, first, first + count);                                    \
   } while (0)
 
@@ -3988,6 +4028,15 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
 #define CE_STEP_LAUNCH(K_, N_)                                                                                          \
   hipLaunchKernelGGL((k_grid_step<K_, N_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
+  if (p.custom_map) {  // a caller's layout (ce_config.ascii_map): the instance that reads tables and list lengths from the block
+    if (kind == CE_KIND_CLEANUP)
+      hipLaunchKernelGGL((k_grid_step<CE_KIND_CLEANUP, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+                         (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+    else
+      hipLaunchKernelGGL((k_grid_step<CE_KIND_HARVEST, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+                         (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
+    return;
+  }
   if (kind == CE_KIND_CLEANUP) {
 #ifndef CE_RNG_COUNTER
     // launches that leave wave slots free step each env with a two-wave workgroup (k_grid_step_duo): three slices of at most
@@ -4027,15 +4076,34 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
       else CE_STEP_LAUNCH(CE_KIND_HARVEST, 0, P_);                 \
     }                                                              \
   } while (0)
-  if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY(CE_POLICY_BYTES_MOD);
+#define CE_STEP_POLICY_CM(K_, P_)                                                                                       \
+  hipLaunchKernelGGL((k_grid_step<K_, 0, P_, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+                     (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
+  if (p.custom_map) {
+    if (kind == CE_KIND_CLEANUP) {
+      if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY_CM(CE_KIND_CLEANUP, CE_POLICY_BYTES_MOD);
+      else CE_STEP_POLICY_CM(CE_KIND_CLEANUP, CE_POLICY_ARGMAX_F32);
+    } else {
+      if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY_CM(CE_KIND_HARVEST, CE_POLICY_BYTES_MOD);
+      else CE_STEP_POLICY_CM(CE_KIND_HARVEST, CE_POLICY_ARGMAX_F32);
+    }
+  } else if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY(CE_POLICY_BYTES_MOD);
   else CE_STEP_POLICY(CE_POLICY_ARGMAX_F32);
+#undef CE_STEP_POLICY_CM
 #undef CE_STEP_POLICY
 #undef CE_STEP_LAUNCH
 }
 
-void CE_LAUNCHER(launch_grid_rollout)(int kind, u32 num_agents, const GridParams* dp, const RolloutArgs& ra, void* stream) {
+void CE_LAUNCHER(launch_grid_rollout)(int kind, u32 num_agents, bool custom_map, const GridParams* dp, const RolloutArgs& ra, void* stream) {
   const u32 count = ra.env_end - ra.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+  if (custom_map) {  // a caller's layout: one instance per kind, at the occupancy the shipped rollout runs at
+    if (kind == CE_KIND_CLEANUP)
+      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_CLEANUP, CE_CLEANUP_ROLLOUT_WAVES, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+    else
+      hipLaunchKernelGGL((k_grid_rollout<CE_KIND_HARVEST, CE_HARVEST_ROLLOUT_WAVES, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, dp, ra);
+    return;
+  }
   // a launch of fewer waves than a third of the machine's 8 192 wave slots (three slices are in flight) never queues; one of
   // a sixth leaves four waves per SIMD
   constexpr u32 kMidLaunch = 2730, kSmallLaunch = 1366;
@@ -4056,13 +4124,15 @@ void CE_LAUNCHER(launch_grid_rollout)(int kind, u32 num_agents, const GridParams
 }
 
 #ifndef CE_RNG_COUNTER
-void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, void* stream) {
-  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
-  else hipLaunchKernelGGL(k_grid_expand<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count);
+void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_first, u32 env_count, const GridTables* tab, u32 napple,
+                        u32 nwaste, void* stream) {
+  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count, tab, napple, nwaste);
+  else hipLaunchKernelGGL(k_grid_expand<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count, tab, napple, nwaste);
 }
-void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error_flags, u32 env_first, u32 env_count, void* stream) {
-  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_pack<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count);
-  else hipLaunchKernelGGL(k_grid_pack<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count);
+void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error_flags, u32 env_first, u32 env_count, const GridTables* tab,
+                      u32 napple, u32 nwaste, void* stream) {
+  if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_pack<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count, tab, napple, nwaste);
+  else hipLaunchKernelGGL(k_grid_pack<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, image, state, error_flags, env_first, env_count, tab, napple, nwaste);
 }
 
 #define CE_LAUNCH_FEAT(kern)                                                                                    \

@@ -34,12 +34,21 @@ _FIELD_DTYPES = {
 def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=False, auto_reset=False,
                 collective=False, inequity=False, alpha=0.0, beta=0.0, collision_on=False, null_prob=0.0,
                 env_index_base=0, device=0, contract_low=None, contract_high=None, external_theta=False,
-                beam_trace=False, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8, rng="mt19937"):
+                beam_trace=False, low_bound=-10.0, high_bound=10.0, start_vel=0.2, start_vel_ambulance=0.8, rng="mt19937",
+                ascii_map=None):
     """rng: "mt19937" = the reference's numpy stream (every parity claim is about this mode); "counter" = the engine's own
-    Philox4x32-10 stream (CE_FLAG_RNG_COUNTER, grid kinds only): 16 bytes of generator state per env, no np.random.seed trace"""
+    Philox4x32-10 stream (CE_FLAG_RNG_COUNTER, grid kinds only): 16 bytes of generator state per env, no np.random.seed trace.
+    ascii_map: the reference's constructor argument (a list of equally long strings; grid kinds) — None = the shipped layout;
+    a custom one must be walled in and within the shipped layout's frame and cell counts (ce_config.ascii_map, the header)"""
     if rng not in ("mt19937", "counter"):
         raise ValueError("rng must be 'mt19937' or 'counter', got %r" % (rng,))
     cfg = CeConfig()
+    if ascii_map is not None:
+        rows = [str(r) for r in ascii_map]
+        if not rows or any(len(r) != len(rows[0]) for r in rows):
+            raise ValueError("ascii_map must be a non-empty list of equally long strings")
+        cfg.ascii_map = "".join(rows).encode("ascii")  # (the structure keeps the bytes object alive; ce_create copies the text)
+        cfg.map_rows, cfg.map_cols = len(rows), len(rows[0])
     cfg.abi_version = _lib.CE_ABI_VERSION
     cfg.kind = _lib.KIND[kind]
     cfg.num_envs, cfg.num_agents, cfg.horizon = num_envs, num_agents, horizon
@@ -385,7 +394,8 @@ class BatchedEnv:
         b = self.b
         if self.kind in _lib.FEAT_KINDS or self.kind == "selfdrive":
             return b.grid_env_stride
-        return ((b.grid_h + 14) * b.grid_row_stride + 15) // 16 * 16
+        frame_rows = {"cleanup": 25, "harvest": 16}[self.kind]  # (a custom layout sits at the origin of the kind's frame)
+        return ((frame_rows + 14) * b.grid_row_stride + 15) // 16 * 16
 
     def _grid_interior(self, raw):
         """strided [cnt, H, W] view of the interior of raw bordered grid slices [cnt, grid_env_stride]"""

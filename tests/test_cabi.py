@@ -120,3 +120,34 @@ def test_library_is_the_build_of_these_sources():
     assert rec["lib_sha16"] == b._sha16(b.LIB)
     assert set(rec["translation_units"]) == {"ce_api.hip", "ce_grid_kernels.hip", "ce_grid_kernels_ctr.hip", "ce_selfdrive_kernels.hip"}
     assert not b.needs_build()
+
+
+def test_custom_layout_rules_are_checked_before_the_device():
+    """ce_config.ascii_map: a layout that breaks a rule of the header is refused with CE_EINVAL and a message naming the rule —
+    on any box, before the device is looked for; a valid one gets as far as the device check (CE_ENODEV here, no GPU)"""
+    from contracts_amd import _lib
+    from contracts_amd.engine import make_config
+    L = _lib.load()
+
+    def create(kind, n, rows):
+        cfg = make_config(kind, 4, n, ascii_map=rows)
+        h = C.c_void_p()
+        rc = L.ce_create(C.byref(cfg), C.byref(h))
+        msg = (L.ce_last_error(h) or b"").decode() if h else ""
+        if h:
+            L.ce_destroy(h)
+        return rc, msg
+
+    ok = ["@@@@@@", "@HB P@", "@RB P@", "@@@@@@"]
+    for kind, n, rows, word in (("cleanup", 3, ok, "spawn points"), ("cleanup", 1, ["@@@@@@", "@HB P ", "@RB P@", "@@@@@@"], "walled"),
+                                ("cleanup", 1, ["@@@@@@", "@ B P@", "@@@@@@"], "at least one"), ("cleanup", 1, ["@@@@@@", "@HA P@", "@@@@@@"], "alphabet"),
+                                ("harvest", 1, ["@" * 40] * 3, "frame"), ("harvest_features", 2, ["@@@@", "@AP@", "@@@@"], "grid kinds"),
+                                ("cleanup", 1, ["@" * 18] + ["@" + "B" * 16 + "@"] * 8 + ["@HP" + "@" * 15] + ["@" * 18], "apple cells")):
+        rc, msg = create(kind, n, rows)
+        assert rc == -22 and word in msg, (kind, rows[:2], rc, msg)
+    import torch
+    if not torch.cuda.is_available():
+        rc, msg = create("cleanup", 2, ok)
+        assert rc == -19, (rc, msg)
+    with pytest.raises(ValueError):
+        make_config("cleanup", 1, 1, ascii_map=["@@@", "@@"])

@@ -25,7 +25,7 @@ def test_selftest_wave_primitives():
     assert rc == 0 and mask.value == 0, "selftest failed mask=%#x" % mask.value
 
 
-GRID_FIXTURES = [f for f in gc.fixtures("g") if "selfdrive" not in f]
+GRID_FIXTURES = [f for f in gc.fixtures("g") if "selfdrive" not in f] + gc.fixtures("m")  # m_*: the reference on hand-made layouts
 
 
 @pytest.mark.parametrize("name", GRID_FIXTURES)
