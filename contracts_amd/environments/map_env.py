@@ -129,12 +129,19 @@ class GridEnvAdapter(VectorHookMixin, _Base):
     def __init__(self, ascii_map=None, num_agents=1, disable_firing=True, image_obs=True, return_agent_actions=False,
                  use_collective_reward=False, inequity_averse_reward=False, alpha=0.0, beta=0.0, horizon=1000,
                  one_hot_id=False, rng="global", device=0, vector_rng=None, **kwargs):
-        if ascii_map is not None and [str(r) for r in ascii_map] != static_map(self.KIND):
-            # the reference's constructors pass their module's map explicitly (cleanup_new.py:62, harvest_new.py:51):
-            # that layout is accepted; any other one would need tables and per-map draw counts the kernels fix at
-            # compile time
-            raise NotImplementedError("the HIP engine steps the shipped %s layout only (ce_static_map); "
-                                      "other ascii maps are not supported" % self.KIND)
+        # the reference's constructors pass their module's map explicitly (cleanup_new.py:62, harvest_new.py:51); any other
+        # layout goes to the engine as ce_config.ascii_map (walled in, within the shipped layout's frame and cell counts:
+        # ce_create names the rule a layout breaks)
+        rows = None if ascii_map is None else [r.decode("ascii") if isinstance(r, bytes) else str(r) for r in ascii_map]
+        self._map_rows = None if rows is None or rows == static_map(self.KIND) else rows
+        if self._map_rows is not None:
+            rows = self._map_rows
+            if not rows or any(len(r) != len(rows[0]) for r in rows):
+                raise ValueError("ascii_map must be a non-empty list of equally long strings")
+            self.GRID_SHAPE = (len(rows), len(rows[0]))
+            self.N_APPLE_CELLS = sum(r.count("B" if self.KIND == "cleanup" else "A") for r in rows)
+            if self.KIND == "cleanup":
+                self.POTENTIAL_WASTE_AREA = sum(r.count("H") + r.count("R") for r in rows)
         if inequity_averse_reward:
             assert num_agents > 1, "Cannot use inequity aversion with only one agent!"  # map_env.py:294
         self.num_agents = num_agents
@@ -169,7 +176,8 @@ class GridEnvAdapter(VectorHookMixin, _Base):
             self._engine = BatchedEnv(
                 self.KIND, 1, self.num_agents, horizon=self.horizon, firing=not self.disable_firing,
                 collective=self.use_collective_reward, inequity=self.inequity_averse_reward, alpha=self.alpha,
-                beta=self.beta, device=self._device, beam_trace=True)  # render() overlays the step's beams
+                beta=self.beta, device=self._device, beam_trace=True,  # render() overlays the step's beams
+                ascii_map=self._map_rows)
             c, lo, hi, null_prob = self._contract
             if c is not None:
                 self._engine.set_contract(c, lo, hi, null_prob)
@@ -370,7 +378,7 @@ class GridEnvAdapter(VectorHookMixin, _Base):
 
     @property
     def _static_rows(self):
-        return static_map(self.KIND)
+        return getattr(self, "_map_rows", None) or static_map(self.KIND)
 
     @property
     def apple_points(self):

@@ -72,7 +72,7 @@ def _engine_config(base):
             return None  # the vector hook hands out image observations only
         return kind, dict(horizon=base.horizon, firing=not base.disable_firing, collective=base.use_collective_reward,
                           inequity=base.inequity_averse_reward, alpha=base.alpha, beta=base.beta,
-                          rng=getattr(base, "vector_rng", "mt19937"))
+                          rng=getattr(base, "vector_rng", "mt19937"), ascii_map=getattr(base, "_map_rows", None))
     if kind in ("harvest_features", "cleanup_features"):
         if getattr(base, "image_obs", False) and kind == "harvest_features":
             return None  # the history-dependent painted map is a host-side view of the single-env adapter

@@ -20,7 +20,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from counter_stream import CounterWords, patched  # noqa: E402
-from make_golden import run_grid_trace  # noqa: E402
+from make_golden import CLEANUP_MID, HARVEST_SMALL, run_grid_trace  # noqa: E402
 from ref_harness import load_reference  # noqa: E402
 
 CLEANER = [.1, .1, .15, .1, .05, .1, .1, .3]  # CLEAN-heavy: the waste density crosses both spawn thresholds
@@ -44,6 +44,11 @@ def jobs():
         "p5_harvest_n3_short_nocontract": dict(kind="harvest", n=3, seed=S0 + 46, T=[40] * 5, episodes=5, store_obs_steps=10,
                                                contract=False, extra_env_kwargs=dict(horizon=40)),
         "p6_cleanup_n1": dict(kind="cleanup", n=1, seed=S0 + 47, T=200, store_obs_steps=10, action_p=CLEANER),
+        # a hand-made layout (the reference's ascii_map argument) on the counter stream: 90 waste cells, four episodes
+        "p7_cleanup_custom_n4": dict(kind="cleanup", n=4, seed=S0 + 48, T=[60, 60, 60, 30], episodes=4, store_obs_steps=10, action_p=CLEANER,
+                                     extra_env_kwargs=dict(ascii_map=CLEANUP_MID, horizon=60)),
+        "p7_harvest_custom_n5": dict(kind="harvest", n=5, seed=S0 + 49, T=[80, 50], episodes=2, store_obs_steps=10, firing=True,
+                                     extra_env_kwargs=dict(ascii_map=HARVEST_SMALL, horizon=80)),
     }
 
 

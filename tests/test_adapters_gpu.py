@@ -27,6 +27,13 @@ def test_grid_adapter_trace(name, steps):
     _grid_adapter_trace(name, steps, host_contract=False)
 
 
+@pytest.mark.parametrize("name,steps", [("m1_cleanup_small_n3", 260), ("m2_cleanup_mid_n4_fire", 240), ("m3_harvest_small_n4", 200)])
+def test_grid_adapter_trace_custom_layout(name, steps):
+    """CleanupEnv(ascii_map=...) / HarvestEnv(ascii_map=...) on hand-made layouts, process-global np.random and all, against
+    the reference's own trace on the same layout"""
+    _grid_adapter_trace(name, steps, host_contract=False)
+
+
 class _PayPerCleanedSquare:
     """what a user of the reference writes: a Contract subclass with its own compute_transfer (scalar transfers, split
     evenly by the wrapper).  No `engine_contract`: the wrapper must call it on the host, with the reference's arguments."""
@@ -79,6 +86,8 @@ def _grid_adapter_trace(name, steps, host_contract):
         extra = dict(inequity_averse_reward=True, alpha=float(g["alpha"]), beta=float(g["beta"]))
     if int(g["horizon"]) != 1000:
         extra["horizon"] = int(g["horizon"])
+    if "ascii_map" in g:  # m_* fixtures: the reference on a hand-made layout (the constructors' first argument)
+        extra["ascii_map"] = [str(r) for r in g["ascii_map"]]
     env = cls(num_agents=n, disable_firing=not bool(int(g["firing"])), **extra)
     assert _mt_fp() == tuple(int(x) for x in g["ctor_mt"])  # the constructor consumed the global stream
     contract = bool(int(g["contract"]))

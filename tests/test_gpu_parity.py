@@ -564,3 +564,51 @@ def test_selfdrive_reset_windows_across_generation_ends(n):
     same("after fused auto-resets")
     env.close()
     orc.close()
+
+
+@pytest.mark.parametrize("kind,rng,fused", [("cleanup", "mt19937", False), ("cleanup", "mt19937", True), ("cleanup", "counter", False),
+                                            ("cleanup", "counter", True), ("harvest", "mt19937", True), ("harvest", "counter", False)])
+def test_custom_layout_rollouts_vs_oracle(kind, rng, fused):
+    """hand-made layouts (ce_config.ascii_map) through the CM kernel instances: many envs, distinct seeds, in-launch resets,
+    per-step and fused launches, both streams, beams traced — everything compared after every launch.  The small cleanup layout
+    has 24 waste cells (the one-register list walk), the other 90 (the two-register path the shipped layout takes)."""
+    import sys
+    import os
+    import torch
+    sys.path.insert(0, os.path.join(gc.GOLDEN_DIR))
+    from make_golden import CLEANUP_MID, CLEANUP_SMALL, HARVEST_SMALL
+    from oracle.pyoracle import Oracle
+    for rows, n in (((CLEANUP_SMALL, 3), (CLEANUP_MID, 4)) if kind == "cleanup" else ((HARVEST_SMALL, 5),)):
+        E, T = 150, 90
+        kw = dict(contract="cleanup" if kind == "cleanup" else "harvest_local", firing=True, horizon=25, auto_reset=True,
+                  beam_trace=True, rng=rng, ascii_map=rows)
+        env, orc = _engine(kind, E, n, **kw), Oracle(kind, E, n, **kw)
+        assert env.download("grid").shape == (E, len(rows), len(rows[0])) == orc.grid.shape
+        seeds = np.arange(E, dtype=np.uint64) * 131 + 9
+        for o in (env, orc):
+            o.seed(seeds)
+            o.reset()
+        fields = [f for f in FIELDS_GRID if not (rng == "counter" and f == "rng")] + (["waste_perm"] if kind == "cleanup" else []) + ["beam_map"]
+        _compare(env, orc, fields, "after reset")
+        rs = np.random.RandomState(5)
+        na = env.num_actions
+        p = np.full(na, 0.6 / (na - 1))
+        p[7 if kind == "cleanup" else 2] = 0.4
+        t = 0
+        while t < T:
+            c = int(rs.randint(1, 8)) if fused else 1
+            a = rs.choice(na, size=(c, E, n), p=p).astype(np.uint8)
+            if fused:
+                dev = torch.from_numpy(a).cuda()
+                env.rollout_fused(dev.data_ptr(), c, int(rs.choice([0, 3])))
+                env.synchronize()
+            else:
+                env.step(a[0])
+            for k in range(c):
+                orc.step(a[k])
+            t += c
+            _compare(env, orc, fields, "step %d" % t)
+            if rng == "counter":
+                assert np.array_equal(env.download("rng")[:, :3], orc.rng[:, :3])
+        env.check_faults()
+        env.close()
