@@ -646,7 +646,7 @@ def test_harvest_features_image_obs_trace():
     c.close()
 
 
-def test_shipped_ascii_map_is_accepted_and_others_are_refused():
+def test_shipped_ascii_map_and_layouts_within_the_caps_are_accepted():
     from contracts_amd.environments import cleanup_new, harvest_new
     assert len(cleanup_new.CLEANUP_MAP) == 25 and len(harvest_new.HARVEST_MAP[0]) == 38
     first = []
@@ -656,10 +656,27 @@ def test_shipped_ascii_map_is_accepted_and_others_are_refused():
         first.append(env.reset())
         env.close()
     assert all(np.array_equal(first[0][k]["image"], first[1][k]["image"]) for k in ("a0", "a1"))
+    # a layout of one's own (here: the shipped one minus an apple cell) goes to the engine as ce_config.ascii_map ...
     other = list(harvest_new.HARVEST_MAP)
     other[3] = other[3].replace("A", " ", 1)
-    with pytest.raises(NotImplementedError, match="shipped harvest layout"):
-        harvest_new.HarvestEnv(ascii_map=other, num_agents=2)
+    env = harvest_new.HarvestEnv(ascii_map=other, num_agents=2)
+    env.reset()
+    assert len(env.apple_points) == 154 and env.world_map.shape == (16, 38) and env.N_APPLE_CELLS == 154
+    assert sorted(map(tuple, env.current_apple_points)) == sorted(map(tuple, env.apple_points))  # harvest starts with every apple
+    env.close()
+    small = ["@@@@@@@", "@HB  P@", "@RB  P@", "@@@@@@@"]
+    env = cleanup_new.CleanupEnv(ascii_map=small, num_agents=2)
+    o = env.reset()
+    assert env.world_map.shape == (4, 7) and env.potential_waste_area == 2 and o["a0"]["image"].shape == (15, 15, 3)
+    assert env.full_map_to_colors().shape == (4, 7, 3) and env.global_observation_space["image"].shape == (4, 7, 3)
+    env.step({"a0": 7, "a1": 4})
+    env.close()
+    # ... and one that breaks a rule of the header is refused by ce_create, which names the rule
+    from contracts_amd._lib import EngineError
+    with pytest.raises(EngineError, match="walled in"):
+        cleanup_new.CleanupEnv(ascii_map=["@@@@@@@", "@HB  P ", "@RB  P@", "@@@@@@@"], num_agents=1)
+    with pytest.raises(EngineError, match="more agents than spawn points"):
+        cleanup_new.CleanupEnv(ascii_map=small, num_agents=3)
 
 
 @pytest.mark.parametrize("name", ["inspect_cleanup_n4", "inspect_harvest_n5"])

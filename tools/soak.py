@@ -33,6 +33,15 @@ while time.time() < t_end:
     trace = (not feat) and rs.rand() < 0.5
     if trace:
         kw["beam_trace"] = True
+    if not feat and rs.rand() < 0.3:  # a hand-made layout (ce_config.ascii_map): the CM kernel instances
+        sys.path.insert(0, "tests/golden")
+        from make_golden import CLEANUP_MID, CLEANUP_SMALL, HARVEST_SMALL
+        rows = HARVEST_SMALL if kind == "harvest" else (CLEANUP_SMALL if rs.rand() < 0.5 else CLEANUP_MID)
+        cap = sum(r.count("P") for r in rows)
+        n = min(n, cap)
+        if inequity and n < 2:
+            kw["inequity"] = inequity = False
+        kw["ascii_map"] = rows
     env, orc = BatchedEnv(kind, E, n, **kw), Oracle(kind, E, n, **kw)
     seeds = rs.randint(0, 2 ** 31 - 1, size=E).astype(np.uint64)
     for o in (env, orc):
