@@ -3491,9 +3491,15 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
       wave_sync();
     }
   }
-  // ---- spawn, features ----
+  // ---- spawn, features ----  (-DCE_FEAT_ABLATE=1 / 2: instruction-count probes, wrong results, never shipped)
+#if !defined(CE_FEAT_ABLATE) || CE_FEAT_ABLATE != 1
   feat_spawn(E, p);
+#endif
+#if defined(CE_FEAT_ABLATE) && CE_FEAT_ABLATE == 2
+  const u32 feat8 = 0;
+#else
   const u32 feat8 = feat_features(E, p, out.features(), cleaned);
+#endif
   t += 1;
   const bool done = t == p.horizon;
   // ---- metrics (same layout as the grid kinds) ----
