@@ -43,7 +43,7 @@ class CleanupEnv(GridEnvAdapter):
         """the waste list in its current order — np.random.shuffle permutes it in place whenever waste may spawn
         (cleanup_new.py:339); the engine keeps the permutation"""
         pts = [[r, c] for r, row in enumerate(self._static_rows) for c, x in enumerate(row) if x in "HR"]
-        return [pts[i] for i in self._engine.download("waste_perm")[0]]
+        return [pts[i] for i in self._engine.download("waste_perm")[0][:len(pts)]]  # (the buffer is 119 wide for every layout)
 
     @property
     def current_waste_points(self):

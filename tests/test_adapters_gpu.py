@@ -669,6 +669,8 @@ def test_shipped_ascii_map_and_layouts_within_the_caps_are_accepted():
     o = env.reset()
     assert env.world_map.shape == (4, 7) and env.potential_waste_area == 2 and o["a0"]["image"].shape == (15, 15, 3)
     assert env.full_map_to_colors().shape == (4, 7, 3) and env.global_observation_space["image"].shape == (4, 7, 3)
+    assert sorted(map(tuple, env.waste_points)) == [(1, 1), (2, 1)] and sorted(map(tuple, env.spawn_points)) == [(1, 5), (1, 5), (2, 5), (2, 5)]
+    assert sorted(map(tuple, env.apple_points)) == [(1, 2), (2, 2)] and env.get_map_with_agents().shape == (4, 7)
     env.step({"a0": 7, "a1": 4})
     env.close()
     # ... and one that breaks a rule of the header is refused by ce_create, which names the rule

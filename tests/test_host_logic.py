@@ -360,6 +360,18 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     with pytest.raises(ValueError):
         feat.to_base_env(num_envs=2)  # needs make_env to build the other sub-env
 
+    # a layout of one's own travels to the batched hook as the engine's ascii_map (the shipped one stays None)
+    small = ["@@@@@@@", "@HB  P@", "@RB  P@", "@@@@@@@"]
+    custom = CleanupEnv(ascii_map=small, num_agents=2, rng="private")
+    assert custom.GRID_SHAPE == (4, 7) and custom.POTENTIAL_WASTE_AREA == 2 and custom.N_APPLE_CELLS == 2
+    assert custom.global_observation_space["image"].shape == (4, 7, 3)
+    made.clear()
+    custom.to_base_env(num_envs=8)
+    assert made[-1].kw["ascii_map"] == small and made[-1].cfg.map_rows == 4 and made[-1].cfg.map_cols == 7
+    made.clear()
+    CleanupEnv(num_agents=2, rng="private").to_base_env(num_envs=8)
+    assert made[-1].kw["ascii_map"] is None and not made[-1].cfg.ascii_map
+
     # an unseeded env: replica 0's seed is what the global np.random would draw next, but the global stream does not move
     np.random.seed(4242)
     before = np.random.get_state()[1].copy(), np.random.get_state()[2]
