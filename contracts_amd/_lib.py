@@ -93,6 +93,8 @@ EXPORTS = {
     "ce_download_async": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ce_step_host_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_obs_u8_to_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "ce_download_obs_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                      C.c_uint32, C.c_void_p]),
     "ce_i16_to_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "ce_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ce_timing_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -4,13 +4,18 @@
 // state besides the per-process constant tables (idempotent uploads).
 #include <hip/hip_runtime.h>
 
-#include <emmintrin.h>
+#include <immintrin.h>
+
+#include <pthread.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -151,6 +156,7 @@ struct ce_engine {
   uint32_t map_counts[3];       // apple, waste, spawn cells
   uint32_t map_h, map_w;
   std::string map_text;
+  std::vector<hipEvent_t> obs_events;  // ce_download_obs_f64: one behind each part of the copy
   std::vector<std::pair<void**, size_t>> allocs;
   std::string err;
   // timing
@@ -400,6 +406,7 @@ extern "C" int ce_destroy(ce_handle h) {
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   if (h->ev_mask) (void)hipEventDestroy(h->ev_mask);
   if (h->ev_reset) (void)hipEventDestroy(h->ev_reset);
+  for (hipEvent_t ev : h->obs_events) (void)hipEventDestroy(ev);
   delete h->h_tab;
   delete h;
   return CE_OK;
@@ -960,69 +967,188 @@ extern "C" int ce_step_host_async(ce_handle h, const void* host_actions, uint32_
   return ce_step_range(h, h->d_stage_actions, nullptr, env_begin, env_count, stream);
 }
 
-// uint8 pitched observation block -> the reference's float64 images (value / 255: cleanup_new.py:258, harvest_new.py:229),
-// dense [envs][n][15][15][3].  A 256-entry table of the same double division numpy performs; rows split over worker threads.
-extern "C" int ce_obs_u8_to_f64(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
-                                uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads) {
-  if (!pitched || !out || obs_row_stride < 45 || threads == 0) return CE_EINVAL;
+// ---- host worker pool: the conversions below run every tick, and creating + joining 16 threads per call costs more than a
+// quarter of the work at the headline batch (measured: the 4-part pipeline was slower than the unsplit one).  Threads are
+// started on first use, sleep on a condition variable between jobs and live until the process exits.
+namespace {
+class HostPool {
+ public:
+  // fn(begin, end) over [0, total) in pieces of `grain`, on up to `threads` threads (the caller is one of them)
+  void run(uint32_t threads, size_t total, size_t grain, const std::function<void(size_t, size_t)>& fn) {
+    if (total == 0) return;
+    if (grain == 0) grain = 1;
+    const size_t pieces = (total + grain - 1) / grain;
+    const uint32_t T = (uint32_t)std::min<size_t>(std::min<uint32_t>(threads, 256u), pieces);
+    if (T <= 1) {
+      fn(0, total);
+      return;
+    }
+    std::lock_guard<std::mutex> one_job(job_m_);
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      while (started_ < T - 1) {
+        std::thread(&HostPool::worker, this, started_).detach();
+        ++started_;
+      }
+      fn_ = &fn, total_ = total, grain_ = grain;
+      next_.store(0, std::memory_order_relaxed);
+      helpers_ = left_ = T - 1;
+      ++gen_;
+    }
+    wake_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return left_ == 0; });
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const size_t b = next_.fetch_add(grain_, std::memory_order_relaxed);
+      if (b >= total_) return;
+      (*fn_)(b, std::min(b + grain_, total_));
+    }
+  }
+  void worker(uint32_t id) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      wake_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      if (id >= helpers_) continue;
+      lk.unlock();
+      drain();
+      lk.lock();
+      if (--left_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex job_m_, m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(size_t, size_t)>* fn_ = nullptr;
+  size_t total_ = 0, grain_ = 1;
+  std::atomic<size_t> next_{0};
+  uint64_t gen_ = 0;
+  uint32_t started_ = 0, helpers_ = 0, left_ = 0;
+};
+
+HostPool* g_host_pool = nullptr;  // never destroyed: its threads may be asleep in it when the process exits
+HostPool& host_pool() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    g_host_pool = new HostPool;
+    // a forked child inherits the object but none of its threads: give it a fresh pool on first use
+    pthread_atfork(nullptr, nullptr, [] { g_host_pool = new HostPool; });
+  });
+  return *g_host_pool;
+}
+
+// one view (675 doubles) from a buffer that shares dst's alignment modulo 32 bytes: scalar head up to the first 32-byte boundary,
+// 32-byte streaming stores, scalar tail
+__attribute__((target("avx"))) void stream_view_avx(double* dst, const double* t, int head) {
+  int i = 0;
+  for (; i < head; ++i) dst[i] = t[i];
+  for (; i + 3 < 15 * 45; i += 4) _mm256_stream_pd(dst + i, _mm256_load_pd(t + i));
+  for (; i < 15 * 45; ++i) dst[i] = t[i];
+}
+
+// uint8 pitched observation views -> float64 value / 255, dense [envs][n][15][15][3], on the pool.  A 256-entry table of the
+// same double division numpy performs.
+void convert_views(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
+                   uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads) {
   static double lut[256];
   static std::once_flag once;
   std::call_once(once, [] {
     for (int v = 0; v < 256; ++v) lut[v] = (double)v / 255.0;
   });
   const size_t views = (size_t)num_envs * num_agents;
-  // Streaming stores, two doubles at a time: the block is ~43 KB per env
-  // (0.7 GB at the headline batch), written once and read by the caller much later — ordinary stores would first READ every
-  // destination line into the cache (read-for-ownership), doubling the memory traffic of what is a bandwidth-bound loop.
+  // Streaming stores: the block is ~43 KB per env (0.7 GB at the headline batch), written once and read by the caller much
+  // later — ordinary stores would first READ every destination line into the cache (read-for-ownership), doubling the memory
+  // traffic of what is a bandwidth-bound loop.
   // (a view is assembled in a cache-resident buffer first: its rows start 8 bytes off a 16-byte boundary every other time, and
   // an ordinary store into a line that streaming stores are filling stalls the write-combining buffers — measured 4 x slower)
-  auto work = [=](size_t v0, size_t v1) {
-    alignas(16) double tmp[15 * 45 + 1];
+  // 32-byte streaming stores where the host has them (half the store instructions); CE_HOST_SSE_ONLY=1 keeps the 16-byte form for A/B
+  static const bool wide = __builtin_cpu_supports("avx") && !getenv("CE_HOST_SSE_ONLY");
+  const std::function<void(size_t, size_t)> work = [=](size_t v0, size_t v1) {
+    alignas(32) double tmp[15 * 45 + 4];
     for (size_t v = v0; v < v1; ++v) {
       const size_t e = v / num_agents, a = v % num_agents;
       const uint8_t* src = pitched + e * obs_env_stride + a * obs_agent_stride;
+      double* dst = out + v * (size_t)(15 * 45);
+      // the view lands in tmp at the offset that gives tmp + k and dst + k the same alignment modulo 32 bytes
+      const int head = (int)((32u - ((uintptr_t)dst & 31u)) & 31u) / 8;  // doubles before dst's first 32-byte boundary (0..3)
+      double* t = tmp + ((4 - head) & 3);
       for (int r = 0; r < 15; ++r) {
         const uint8_t* s = src + (size_t)r * obs_row_stride;
-        double* d = tmp + r * 45;
+        double* d = t + r * 45;
         for (int k = 0; k < 45; ++k) d[k] = lut[s[k]];
       }
-      double* dst = out + v * (size_t)(15 * 45);
-      int i = 0;
-      if (((uintptr_t)dst & 15u) != 0) dst[0] = tmp[0], i = 1;  // odd views start 8 bytes off a 16-byte boundary
-      for (; i + 1 < 15 * 45; i += 2) _mm_stream_pd(dst + i, _mm_loadu_pd(tmp + i));
-      if (i < 15 * 45) dst[i] = tmp[i];
+      if (wide) stream_view_avx(dst, t, head);
+      else {
+        int i = 0;
+        if (((uintptr_t)dst & 15u) != 0) dst[0] = t[0], i = 1;  // odd views start 8 bytes off a 16-byte boundary
+        for (; i + 1 < 15 * 45; i += 2) _mm_stream_pd(dst + i, _mm_loadu_pd(t + i));
+        if (i < 15 * 45) dst[i] = t[i];
+      }
     }
     _mm_sfence();
   };
-  const uint32_t T = (uint32_t)std::min<size_t>(threads, views ? views : 1);
-  if (T <= 1) {
-    work(0, views);
-    return CE_OK;
+  // pieces a few times smaller than a thread's share: the threads that start late or share a core take fewer of them
+  host_pool().run(threads, views, std::max<size_t>(64, views / ((size_t)threads * 4 + 1)), work);
+}
+}  // namespace
+
+// uint8 pitched observation block -> the reference's float64 images (value / 255: cleanup_new.py:258, harvest_new.py:229)
+extern "C" int ce_obs_u8_to_f64(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
+                                uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads) {
+  if (!pitched || !out || obs_row_stride < 45 || threads == 0) return CE_EINVAL;
+  convert_views(pitched, out, num_envs, num_agents, obs_env_stride, obs_agent_stride, obs_row_stride, threads);
+  return CE_OK;
+}
+
+// The observation leg of a dict-protocol tick in one call: the slice's pitched uint8 views travel to `staging` (page-locked) in
+// `parts` copies issued back to back on `stream`, an event behind each; part i is converted into `out` (float64, dense) on the
+// pool while parts i + 1 .. are still on the wire.  Returns when `out` is complete.
+extern "C" int ce_download_obs_f64(ce_handle h, uint32_t env_begin, uint32_t env_count, void* staging, uint64_t staging_bytes, double* out,
+                                   uint64_t out_bytes, uint32_t parts, uint32_t threads, void* stream) {
+  if (!h || !staging || !out || threads == 0) return CE_EINVAL;
+  begin_call(h);
+  if (!is_grid(h->cfg)) return fail(h, CE_EINVAL, "ce_download_obs_f64: image observations are a grid-kind field");
+  if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "slice out of range");
+  const ce_buffers& b = h->buf;
+  const uint32_t n = h->cfg.num_agents;
+  if (staging_bytes < (uint64_t)env_count * b.obs_env_stride || out_bytes < (uint64_t)env_count * n * (15 * 45 * 8))
+    return fail(h, CE_EINVAL, "destination too small");
+  parts = std::max(1u, std::min(std::min(parts, 16u), env_count));
+  while (h->obs_events.size() < parts) {
+    hipEvent_t ev = nullptr;
+    const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "event for the observation copy", e);
+    h->obs_events.push_back(ev);
   }
-  std::vector<std::thread> pool;
-  pool.reserve(T - 1);
-  for (uint32_t t = 1; t < T; ++t) pool.emplace_back(work, views * t / T, views * (t + 1) / T);
-  work(0, views / T);
-  for (auto& th : pool) th.join();
+  auto cut = [&](uint32_t i) { return (uint32_t)((uint64_t)env_count * i / parts); };
+  for (uint32_t i = 0; i < parts; ++i) {
+    const size_t off = (size_t)cut(i) * b.obs_env_stride, len = (size_t)(cut(i + 1) - cut(i)) * b.obs_env_stride;
+    hipError_t e = hipMemcpyAsync((char*)staging + off, (const char*)b.obs + (size_t)env_begin * b.obs_env_stride + off, len,
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventRecord(h->obs_events[i], (hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "observation copy", e);
+  }
+  for (uint32_t i = 0; i < parts; ++i) {
+    const hipError_t e = hipEventSynchronize(h->obs_events[i]);
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "observation copy", e);
+    convert_views((const uint8_t*)staging + (size_t)cut(i) * b.obs_env_stride, out + (size_t)cut(i) * n * (15 * 45), cut(i + 1) - cut(i), n,
+                  b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, threads);
+  }
   return CE_OK;
 }
 
 // int16 feature rows -> float64 (the reference's feature_obs entries are floats), `threads` worker threads
 extern "C" int ce_i16_to_f64(const int16_t* src, double* out, uint64_t count, uint32_t threads) {
   if (!src || !out || threads == 0) return CE_EINVAL;
-  auto work = [=](uint64_t i0, uint64_t i1) {
-    for (uint64_t i = i0; i < i1; ++i) out[i] = (double)src[i];
+  const std::function<void(size_t, size_t)> work = [=](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) out[i] = (double)src[i];
   };
-  const uint32_t T = (uint32_t)std::min<uint64_t>(threads, count / 65536 + 1);
-  if (T <= 1) {
-    work(0, count);
-    return CE_OK;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(T - 1);
-  for (uint32_t t = 1; t < T; ++t) pool.emplace_back(work, count * t / T, count * (t + 1) / T);
-  work(0, count / T);
-  for (auto& th : pool) th.join();
+  host_pool().run(threads, (size_t)count, 65536, work);
   return CE_OK;
 }
 

@@ -270,6 +270,13 @@ class BatchedEnv:
         check(self._L.ce_obs_u8_to_f64(pitched.ctypes.data, out.ctypes.data, envs, self.n, b.obs_env_stride, b.obs_agent_stride,
                                        b.obs_row_stride, int(threads)), self._h, "ce_obs_u8_to_f64")
 
+    def download_obs_f64(self, staging, out, threads, parts=4, env_begin=0, env_count=None, stream=None):
+        """ce_download_obs_f64: the slice's image observations -> `out` (float64 [envs, n, 15, 15, 3]) through the page-locked
+        `staging` block, copy and conversion overlapped part by part; returns with `out` complete (GIL released throughout)"""
+        cnt = self.E - env_begin if env_count is None else env_count
+        check(self._L.ce_download_obs_f64(self._h, int(env_begin), int(cnt), staging.ctypes.data, staging.nbytes, out.ctypes.data,
+                                          out.nbytes, int(parts), int(threads), stream), self._h, "ce_download_obs_f64")
+
     def i16_to_f64(self, src, out, threads):
         check(self._L.ce_i16_to_f64(src.ctypes.data, out.ctypes.data, src.size, int(threads)), self._h, "ce_i16_to_f64")
 

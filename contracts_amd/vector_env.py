@@ -418,7 +418,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
                 cores = os.cpu_count() or 2
-            self._threads = max(1, min(16, cores - 1))
+            self._threads = max(1, min(32 if cores >= 128 else 16, cores - 1))
         return self._threads
 
     def _poll_recycled(self):
@@ -440,22 +440,15 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             eng.download_async("theta", G.theta)
         eng.synchronize()
         t1 = time.perf_counter()
-        # the observations (most of the bytes) travel and are converted on worker threads while this thread refreshes the
-        # dictionaries: DMA into the page-locked block in a few chunks, chunk i + 1 in flight while chunk i is converted
-        # (value / 255 -> float64 across the host cores)
+        # the observations (most of the bytes) travel and are converted while this thread refreshes the dictionaries: one
+        # library call (no GIL hand-offs with the refresh loops) that copies into the page-locked block in parts and converts
+        # part i (value / 255 -> float64 across the host cores) while the later parts are still on the wire
         T = self._host_threads()
-        E = self.num_envs
-        cuts = [E * i // 4 for i in range(5)] if E >= 1024 else [0, E]
 
         def finish_obs():
             ta = time.perf_counter()
             if G.grid:
-                eng.download_async("obs", G.obs_u8[cuts[0]:cuts[1]], cuts[0], cuts[1] - cuts[0])
-                for i in range(len(cuts) - 1):
-                    eng.synchronize()
-                    if i + 2 < len(cuts):
-                        eng.download_async("obs", G.obs_u8[cuts[i + 1]:cuts[i + 2]], cuts[i + 1], cuts[i + 2] - cuts[i + 1])
-                    eng.obs_u8_to_f64(G.obs_u8[cuts[i]:cuts[i + 1]], G.obs_f64[cuts[i]:cuts[i + 1]], T)
+                eng.download_obs_f64(G.obs_u8, G.obs_f64, T, parts=4 if self.num_envs >= 1024 else 1)
             eng.i16_to_f64(G.feat_i16, G.feat_f64, T)  # feature rows -> the float64 arrays infos[..]['feature_obs'] are views of
             if G.obs_vec is not None and G.obs_vec is not G.feat_f64:  # feature kinds under a contract: row = features + [theta, 0]
                 F = G.feat_f64.shape[2]

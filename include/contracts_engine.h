@@ -415,7 +415,11 @@ int ce_download_many(ce_handle h, uint32_t env_begin, uint32_t env_count, const 
  *   passed the copy (double-buffer it).
  * ce_obs_u8_to_f64: format conversion on the host, `threads` worker threads: the pitched uint8 observation block (as
  *   downloaded: ce_buffers.obs strides) -> the reference's float64 images value / 255 (cleanup_new.py:258,
- *   harvest_new.py:229), dense [envs][n][15][15][3]. */
+ *   harvest_new.py:229), dense [envs][n][15][15][3].
+ * ce_download_obs_f64: the observation leg of a tick in one call — the slice's views travel to `staging` (page-locked,
+ *   env_count * obs_env_stride bytes) in `parts` copies issued back to back on `stream`, and each part is converted into
+ *   `out` (float64, dense, as ce_obs_u8_to_f64) while the later ones are still on the wire; returns when `out` is complete.
+ * The conversions run on a process-wide pool of worker threads started on first use (`threads` = how many take part). */
 int ce_host_alloc(uint64_t bytes, void** out);
 int ce_host_free(void* p);
 int ce_download_async(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes,
@@ -424,6 +428,8 @@ int ce_step_host_async(ce_handle h, const void* host_actions, uint32_t env_begin
 int ce_i16_to_f64(const int16_t* src, double* out, uint64_t count, uint32_t threads); /* feature rows -> feature_obs floats */
 int ce_obs_u8_to_f64(const uint8_t* pitched, double* out, uint32_t num_envs, uint32_t num_agents, uint32_t obs_env_stride,
                      uint32_t obs_agent_stride, uint32_t obs_row_stride, uint32_t threads);
+int ce_download_obs_f64(ce_handle h, uint32_t env_begin, uint32_t env_count, void* staging, uint64_t staging_bytes, double* out,
+                        uint64_t out_bytes, uint32_t parts, uint32_t threads, void* stream);
 
 /* Timing of the last N ce_step launches measured with HIP events on the launch stream
  * (bench.py roofline leg).  ce_timing_begin arms recording, ce_timing_end returns the mean
