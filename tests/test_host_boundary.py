@@ -30,6 +30,38 @@ def test_obs_u8_to_f64_is_numpy_division():
     assert np.array_equal(out[:, 0, 0].reshape(6, 45), full[:, :45] / 255)
 
 
+def test_host_pool_serves_changing_thread_counts_and_concurrent_callers():
+    """the conversions share one process-wide worker pool: calls with growing / shrinking thread counts, sizes below one
+    piece, and two callers at once all return complete, exact blocks"""
+    import threading
+    from contracts_amd import _lib
+    L = _lib.load()
+    rs = np.random.RandomState(5)
+    n, row, agent = 3, 48, 720
+    blocks = {E: rs.randint(0, 256, size=(E, n * agent)).astype(np.uint8) for E in (1, 7, 300, 1500)}
+
+    def convert(E, threads):
+        out = np.full((E, n, 15, 15, 3), -1.0)
+        assert L.ce_obs_u8_to_f64(blocks[E].ctypes.data, out.ctypes.data, E, n, n * agent, agent, row, threads) == 0
+        return out
+
+    want = {E: b.reshape(E, n, 15, row)[..., :45].reshape(E, n, 15, 15, 3) / 255 for E, b in blocks.items()}
+    for threads in (2, 9, 4, 33, 1, 16):
+        for E in blocks:
+            assert np.array_equal(convert(E, threads), want[E]), (E, threads)
+    bad = []
+
+    def hammer(E, threads):
+        for _ in range(20):
+            if not np.array_equal(convert(E, threads), want[E]):
+                bad.append((E, threads))
+
+    ts = [threading.Thread(target=hammer, args=a) for a in ((1500, 6), (300, 11), (1500, 3))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+
+
 def test_i16_to_f64():
     from contracts_amd import _lib
     L = _lib.load()
