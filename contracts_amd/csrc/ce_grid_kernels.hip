@@ -3633,17 +3633,16 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
   }
 }
 
-// NFIX: the number of agents as a compile-time constant (0 = p.n), as for k_grid_step; the instance is for n = 2 (BASELINE config 0)
-template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
-                                                                   const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
-  const GridParams& p = *pp;
-  __shared__ FeatLds<GK> lds;
+// One single-step launch's work for env `e` on the whole wave.  NFIX: the number of agents as a compile-time constant
+// (0 = p.n), as for k_grid_step; the instance is for n = 2 (BASELINE config 0)
+template <int GK, int NFIX>
+DEVINL void feat_step_one(const GridParams& p, const uint8_t* __restrict__ call_actions, FeatLds<GK>* lds, u32 e) {
   FEnv<GK> E;
-  if (!feat_begin(E, p, &lds, env_first, env_end)) return;
-  if (NFIX) {
-    E.n = (u32)NFIX;
-    E.is_agent = E.lane < E.n;
-  }
+  E.lane = lane_id();
+  E.e = rfl(e);
+  E.n = NFIX ? (u32)NFIX : p.n;
+  E.is_agent = E.lane < E.n;
+  E.L = lds;
   const u32 ACT = E.is_agent ? (u32)GAT((CE_GPTR(const uint8_t))call_actions + (size_t)E.e * E.n, E.lane) : 4u;
   if (ballot(E.is_agent && ACT > (GK == CE_KIND_HARVEST ? 7u : 8u)) != 0) {  // validated before anything is loaded or written
     if (E.lane == 0) p.error_flags[E.e] |= CE_FAULT_BAD_ACTION;
@@ -3654,6 +3653,503 @@ template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step
   double theta = p.theta[E.e];
   bool did_reset = false;
   feat_step_core<GK, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
+}
+template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
+                                                                   const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
+  __shared__ FeatLds<GK> lds;
+  const u32 e = env_first + blockIdx.x;
+  if (e >= env_end) return;
+  feat_step_one<GK, NFIX>(*pp, call_actions, &lds, e);
+}
+
+// ----------------------------------------------------------------------------------------
+// HarvestFeatures with two agents (BASELINE config 0), FOUR envs per wave.  One wave per env leaves 62 of 64 lanes idle in
+// everything that is per agent or per env (moves, consume, metrics, transfers, stores): the kernel above is bound by the
+// vector instructions a wave issues, not by bytes.  Here a row of 16 lanes (a DPP row) is one env: lane sl of a row owns the
+// ten consecutive apple cells 10 sl .. 10 sl + 9 (row-major list order = lane-major order), per-env values live replicated in
+// the row's lanes, counts and ranks come from row scans / the row's 16 bits of a ballot, broadcasts from ds_swizzle.
+// Draws that run over the end of the CPython generator's 624 words (one step in ~30 per env) get the twist from the whole
+// wave: the row's key words pass through LDS, the row takes its words from both generations, the new key goes back to HBM.
+// The draws are taken sixteen per row at a time, in list order, however many there are.
+// A step that is not the common case otherwise — a bad action id, the horizon (metrics of the episode + reset), a second row
+// of the same wave crossing the generation end in the same step — is left untouched by the packed pass and taken afterwards
+// by the whole wave through the one-env code above, env by env (a launch lasts as long as its slowest wave: this has to
+// stay rare).
+// Same results as k_feat_step<HARVEST, 2> field for field (tests/test_feature_kinds_gpu.py runs both).
+// ----------------------------------------------------------------------------------------
+namespace quad {
+typedef Geo<CE_KIND_HARVEST> G;
+constexpr u32 kCellsPerLane = 10;
+constexpr u32 kAbs8 = kAbsent << 8;  // list stamps are kept shifted left by 8: (stamp << 8) | cell index is the tie-break key
+static_assert(16 * kCellsPerLane >= (u32)G::NAPPLE && 16 * kCellsPerLane == CE_FEAT_APPLE_SLOTS, "a row covers the list slots");
+
+struct alignas(16) Lds {
+  uint8_t pm[4][G::PQUADS * 16];  // presence map of each row's env
+  uint16_t L[4][CE_FEAT_APPLE_SLOTS];  // compacted cells to draw for (padded index), then the cells that got an apple
+  u32 tw[kMtN];                   // one CPython generator at a time, for a row whose draws run over the generation end
+};
+
+template <int K> DEVINL u32 row_bcast(u32 v) { return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (K << 5)); }  // lane K of the row
+template <int CTRL> DEVINL u32 dpp_zero(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> DEVINL u32 dpp_keep(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+DEVINL u32 row_scan_incl(u32 v) {  // inclusive prefix sum over the row's lanes
+  v += dpp_zero<0x111>(v);
+  v += dpp_zero<0x112>(v);
+  v += dpp_zero<0x114>(v);
+  v += dpp_zero<0x118>(v);
+  return v;
+}
+DEVINL u32 row_min_all(u32 v) {  // butterfly over row rotations: every lane ends with the row's minimum
+  u32 t = dpp_keep<0x128>(v);
+  v = t < v ? t : v;
+  t = dpp_keep<0x124>(v);
+  v = t < v ? t : v;
+  t = dpp_keep<0x122>(v);
+  v = t < v ? t : v;
+  t = dpp_keep<0x121>(v);
+  v = t < v ? t : v;
+  return v;
+}
+// the row's 16 bits of a ballot
+DEVINL u32 row_bits(u64 b, u32 sub) {
+  const u32 w = (sub & 2u) ? (u32)(b >> 32) : (u32)b;
+  return (sub & 1u) ? w >> 16 : w & 0xffffu;
+}
+DEVINL u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
+DEVINL void add_i64(CE_GPTR(int64_t) a, long long v) { (void)__hip_atomic_fetch_add((CE_GPTR(long long))a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL void add_f64(CE_GPTR(double) a, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64(a, v); }
+
+// apples within j^2 + k^2 <= 5 of padded cell `c` (row-uniform) in the row's map: 21 offsets over 16 lanes, two rounds
+DEVINL u32 close_count(const uint8_t* pm, const GridTables& T, u32 c, u32 sl, u32 sub) {
+  const i32 o0 = (i32)T.close_off[sl], o1 = (i32)T.close_off[16u + (sl < 5u ? sl : 0u)];
+  const bool v0 = pm[(i32)c + o0] == CE_CELL_APPLE;
+  const bool v1 = sl < 5u && pm[(i32)c + o1] == CE_CELL_APPLE;
+  return popc32(row_bits(ballot(v0), sub)) + popc32(row_bits(ballot(v1), sub));
+}
+}  // namespace quad
+
+#if defined(CE_DIAGNOSTIC) && defined(CE_PHASE_STAMPS)  // tools/quad_profile.py: where a wave of the packed kernel spends its life
+#define CE_QSTAMP(k)                                                               \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    __builtin_amdgcn_s_waitcnt(0);                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    if (lane == 0 && p.debug) p.debug[(size_t)e_row0 * 16 + (k)] = t_;             \
+  } while (0)
+#else
+#define CE_QSTAMP(k) ((void)0)
+#endif
+__global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, u32 env_first,
+                                                         u32 env_end) {
+  using namespace quad;
+  const GridParams& p = *pp;
+  const GridTables& T = c_tab[CE_KIND_HARVEST];
+  __shared__ union {
+    quad::Lds q;
+    FeatLds<CE_KIND_HARVEST> one;
+  } lds;
+  const u32 lane = lane_id(), sl = lane & 15u, sub = lane >> 4;
+  const u32 e_row0 = env_first + 4u * blockIdx.x;
+  if (e_row0 >= env_end) return;
+  const bool live = e_row0 + sub < env_end;
+  const u32 e = live ? e_row0 + sub : env_end - 1u;  // rows past the end shadow the last env: they load, compute and store nothing
+  CE_QSTAMP(0);
+  uint8_t* pm = lds.q.pm[sub];
+  const u32 below = (1u << sl) - 1u;
+
+  // ---- loads: actions, clocks, the two agents, the list stamps (20 bytes per lane), the stream window ----
+  const u32 act2 = (u32)GAT((CE_GPTR(const uint16_t))call_actions, e);
+  const u32 ACT0 = act2 & 0xffu, ACT1 = act2 >> 8;
+  const u32 t_old = (u32)GAT(p.timestep, e);
+  const double theta = GAT(p.theta, e);
+  const u32 wbase = e * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID;
+  u32 pos = GAT(p.rng, wbase + (u32)kMtN);
+  // a row whose position is within 48 words of the generation end will probably need the twist below: its key words are
+  // requested now and parked in LDS once the map work is done, instead of being waited for in the middle of the step
+  u32 tw_row = 0xffffffffu;
+  uint4 pf0 = {}, pf1 = {}, pf2 = {};
+  const u32 q2 = min(lane + 128u, (u32)kMtN / 4u - 1u);
+  {
+    const u64 near_end = ballot(live && sl == 0u && pos + 48u > (u32)kMtN);
+    if (near_end != 0) {
+      tw_row = ctz64(near_end) >> 4;
+      const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(e_row0 + tw_row) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+      pf0 = key4[lane];
+      pf1 = key4[lane + 64u];
+      pf2 = key4[q2];
+    }
+  }
+  const auto st32 = (CE_GPTR(u32))p.grid;
+  const u32 stw = e * (CE_FEAT_STATE_BYTES / 4u);
+  u32 sd[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) sd[k] = GAT(st32, stw + 5u * sl + (u32)k);
+  u32 next_a = GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u);
+  const u32 ag0 = GAT((CE_GPTR(const u32))p.agents, 2u * e), ag1 = GAT((CE_GPTR(const u32))p.agents, 2u * e + 1u);
+  u32 APAD[kCellsPerLane], ARC[kCellsPerLane];
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) {
+    const u32 idx = kCellsPerLane * sl + r;
+    const u32 v = T.apple[idx < (u32)G::NAPPLE ? idx : 0u];
+    APAD[r] = idx < (u32)G::NAPPLE ? cell_pad(v) : 0u;  // the slots past the list end aim at byte 0 of the map and are never valid
+    ARC[r] = cell_rc(v);
+  }
+  const u32 q0w = min(pos + 2u * sl, (u32)kMtN - 2u), q1w = min(pos + 2u * sl + 32u, (u32)kMtN - 2u);
+  const u32 wa0 = GAT(p.rng, wbase + q0w), wb0 = GAT(p.rng, wbase + q0w + 1u);
+  const u32 wa1 = GAT(p.rng, wbase + q1w), wb1 = GAT(p.rng, wbase + q1w + 1u);
+  CE_QSTAMP(1);
+  {  // the map with every apple present (16-byte copies; the last round's idle lanes repeat the last quad)
+    const uint4* bsrc = (const uint4*)T.base_pmap;
+    uint4* pm128 = (uint4*)pm;
+#pragma unroll
+    for (u32 k = 0; k < ((u32)G::PQUADS + 15u) / 16u; ++k) {
+      const u32 q = min(sl + 16u * k, (u32)G::PQUADS - 1u);
+      pm128[q] = bsrc[q];
+    }
+  }
+  u32 AS8[kCellsPerLane];  // stamp << 8
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = (r & 1u) ? (sd[r >> 1] >> 8) & 0xffff00u : (sd[r >> 1] << 8) & 0xffff00u;
+  u32 P0 = pad_of<CE_KIND_HARVEST>(ag0 & 0xffu, (ag0 >> 8) & 0xffu), O0 = (ag0 >> 16) & 3u;
+  u32 P1 = pad_of<CE_KIND_HARVEST>(ag1 & 0xffu, (ag1 >> 8) & 0xffu), O1 = (ag1 >> 16) & 3u;
+  const bool lastl = sl == 15u;  // lane 15 owns cells 150 .. 159: the last five are past the list end
+#define CE_QVALID(r) (!(lastl && (r) >= (u32)G::NAPPLE - 150u))
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r)
+    if (!CE_QVALID(r)) AS8[r] = kAbs8;
+  wave_sync();
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) pm[AS8[r] == kAbs8 ? APAD[r] : 0u] = CE_CELL_EMPTY;  // (byte 0 is the border corner: empty)
+  wave_sync();
+
+  CE_QSTAMP(2);
+  // ---- move_squares in dict order: stayers first, then the movers by key; a mover is refused by a wall or a claimed square ----
+  const bool m0 = ACT0 < 4u, m1 = ACT1 < 4u;
+  const i32 d0 = ACT0 == 0 ? -1 : ACT0 == 1 ? 1 : ACT0 == 2 ? -(i32)G::PW : (i32)G::PW;
+  const i32 d1 = ACT1 == 0 ? -1 : ACT1 == 1 ? 1 : ACT1 == 2 ? -(i32)G::PW : (i32)G::PW;
+  const u32 tg0 = m0 ? (u32)((i32)P0 + d0) : P0, tg1 = m1 ? (u32)((i32)P1 + d1) : P1;
+  const bool w0 = pm[tg0] == CE_CELL_WALL, w1 = pm[tg1] == CE_CELL_WALL;
+  const u32 N0 = (m0 && !w0 && !(!m1 && tg0 == P1)) ? tg0 : P0;
+  const u32 N1 = (m1 && !w1 && tg1 != N0) ? tg1 : P1;
+  P0 = N0;
+  P1 = N1;
+
+  // ---- consume in move_squares order (a1 eats first only when it stays and a0 moves) ----
+  const bool swap = m0 && !m1;
+  const u32 pf = swap ? P1 : P0, ps = swap ? P0 : P1;
+  bool dirty = false;
+  u32 eat_f = 0, eat_s = 0, ecl_f = 0, ecl_s = 0;
+  {
+    const bool ef = pm[pf] == CE_CELL_APPLE;
+    if (ballot(ef) != 0) {
+      const u32 close = close_count(pm, T, pf, sl, sub);  // counted before the apple is removed
+      eat_f = ef ? 1u : 0u;
+      ecl_f = ef && close < 4u ? 1u : 0u;
+      wave_sync();
+      pm_put(pm, ef && sl == 0u, pf, CE_CELL_EMPTY);
+#pragma unroll
+      for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = ef && APAD[r] == pf ? kAbs8 : AS8[r];
+      dirty = dirty || ef;
+      wave_sync();
+    }
+    const bool es = pm[ps] == CE_CELL_APPLE;
+    if (ballot(es) != 0) {
+      const u32 close = close_count(pm, T, ps, sl, sub);
+      eat_s = es ? 1u : 0u;
+      ecl_s = es && close < 4u ? 1u : 0u;
+      wave_sync();
+      pm_put(pm, es && sl == 0u, ps, CE_CELL_EMPTY);
+#pragma unroll
+      for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = es && APAD[r] == ps ? kAbs8 : AS8[r];
+      dirty = dirty || es;
+      wave_sync();
+    }
+  }
+  const u32 eat0 = swap ? eat_s : eat_f, eat1 = swap ? eat_f : eat_s;
+  const u32 ecl0 = swap ? ecl_s : ecl_f, ecl1 = swap ? ecl_f : ecl_s;
+  // ---- rotations ----
+  O0 = (O0 + (ACT0 == 5u ? 1u : ACT0 == 6u ? 3u : 0u)) & 3u;
+  O1 = (O1 + (ACT1 == 5u ? 1u : ACT1 == 6u ? 3u : 0u)) & 3u;
+
+  CE_QSTAMP(3);
+  if (tw_row != 0xffffffffu) {
+    uint4* tw4 = (uint4*)lds.q.tw;
+    tw4[lane] = pf0;
+    tw4[lane + 64u] = pf1;
+    tw4[q2] = pf2;
+  }
+  // ---- spawn_apples: one random.random() per absent cell no agent stands on, in list order ----
+  bool el[kCellsPerLane];
+  u32 cnt = 0, nabs = 0;
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) {
+    const bool ab = CE_QVALID(r) && AS8[r] == kAbs8;
+    el[r] = ab && APAD[r] != P0 && APAD[r] != P1;
+    cnt += el[r] ? 1u : 0u;
+    nabs += ab ? 1u : 0u;
+  }
+  const u32 incl = row_scan_incl(cnt | nabs << 16);  // both counts ride one scan
+  const u32 tot = row_bcast<15>(incl);
+  const u32 nelig = tot & 0xffffu;
+  u32 napples = (u32)G::NAPPLE - (tot >> 16);
+  const bool simple = live && ACT0 <= 7u && ACT1 <= 7u && t_old + 1u != p.horizon;
+  // Draws that cross the generation end get the twist from the whole wave, the row's key passing through lds.q.tw.  The
+  // buffer serves one row at a time: the first pass below takes every row that does not twist plus the first one that does,
+  // each further twisting row of the wave (rare) gets a pass of its own.
+  const bool over = simple && pos + 2u * nelig > (u32)kMtN;
+#if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 1  // timing probes (wrong results): 1 = no twist, no one-env rows
+  u64 tw_pending = 0;
+#else
+  u64 tw_pending = ballot(over && sl == 0u);
+#endif
+  CE_QSTAMP(4);
+  for (bool first_pass = true;; first_pass = false) {
+  const u32 tws = tw_pending ? ctz64(tw_pending) >> 4 : 0xffffffffu;
+  const bool istw = over && sub == tws;
+  const bool inpass = first_pass ? simple && (!over || istw) : istw;
+  u32 c_tw = 0xffffffffu;  // the chunk of 16 draws in which the twisting row passes word 624
+  if (tw_pending != 0) {
+    if (tws != tw_row) {  // (not the row whose key was parked in LDS ahead of time)
+      const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+      uint4* tw4 = (uint4*)lds.q.tw;
+      wave_sync();
+      const uint4 r0 = key4[lane], r1 = key4[lane + 64u], r2 = key4[q2];
+      tw4[lane] = r0;
+      tw4[lane + 64u] = r1;
+      tw4[q2] = r2;
+    }
+    tw_row = 0xffffffffu;  // the buffer holds a twisted key after this pass
+    const u32 pos_tw = rdl(pos, tws << 4);
+    c_tw = pos_tw >= 593u ? 0u : (593u - pos_tw + 31u) >> 5;  // smallest c with pos + 32 c + 31 >= 624
+    wave_sync();
+  }
+  CE_QSTAMP(5);
+#if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 2
+  if (false) {
+#else
+  if (ballot(inpass && nelig != 0u) != 0) {
+#endif
+    // the cells to draw for, compacted in list order (the q-th one takes double q of the stream)
+    uint16_t* L = lds.q.L[sub];
+    {
+      u32 rk = (incl & 0xffffu) - cnt;  // list rank of this lane's first eligible cell
+#pragma unroll
+      for (u32 r = 0; r < kCellsPerLane; ++r) {
+        if (inpass && el[r]) L[rk] = (uint16_t)APAD[r];
+        rk += el[r] ? 1u : 0u;
+      }
+    }
+    wave_sync();
+    const u64 th0 = T.apple_thresh[0], th1 = T.apple_thresh[1], th2 = T.apple_thresh[2], th3 = T.apple_thresh[3];
+    const u32* tw = lds.q.tw;
+    u32 nsp = 0, na = 0, nb = 0;
+    // sixteen draws of every row at a time, in list order: a later chunk sees the apples of the earlier ones as 0x42 marks
+    for (u32 c = 0; ballot(inpass && 16u * c < nelig) != 0; ++c) {
+      const u32 q = 16u * c + sl;
+      const bool act = inpass && q < nelig;
+      u32 wa = c == 0 ? wa0 : c == 1 ? wa1 : na, wb = c == 0 ? wb0 : c == 1 ? wb1 : nb;
+      if (ballot(inpass && 16u * (c + 1u) < nelig && c >= 1u) != 0) {  // the words of the next chunk (the first two came with the loads)
+        const u32 i = min(pos + 2u * q + 32u, (u32)kMtN - 2u);
+        na = GAT(p.rng, wbase + i);
+        nb = GAT(p.rng, wbase + i + 1u);
+      }
+      if (tw_pending != 0) {  // the twisting row: words below 624 from the current key, the rest from the twisted one
+        const u32 w = pos + 2u * q;
+        if (c <= c_tw) {
+          if (istw && w < (u32)kMtN) wa = tw[w];
+          if (istw && w + 1u < (u32)kMtN) wb = tw[w + 1u];
+        }
+        if (c == c_tw) {
+          wave_sync();
+          mt_twist(lds.q.tw, lane);
+          wave_sync();
+          const auto key4 = (CE_GPTR(uint4))(p.rng + (size_t)(e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+          const uint4* tw4 = (const uint4*)lds.q.tw;
+          const uint4 r0 = tw4[lane], r1 = tw4[lane + 64u], r2 = tw4[q2];
+          key4[lane] = r0;
+          key4[lane + 64u] = r1;
+          key4[q2] = r2;
+        }
+        if (c >= c_tw) {
+          if (istw && w >= (u32)kMtN && w < 2u * (u32)kMtN) wa = tw[w - (u32)kMtN];
+          if (istw && w + 1u >= (u32)kMtN && w + 1u < 2u * (u32)kMtN) wb = tw[w + 1u - (u32)kMtN];
+        }
+      }
+      const i32 cell = (i32)L[act ? q : 0u];  // idle lanes alias entry 0: a valid interior cell, never written by them
+      const u64 X = (((u64)(mt_temper(wa) >> 5)) << 26) | (u64)(mt_temper(wb) >> 6);
+      bool sp = false;
+      // the neighbour count of a cell includes apples spawned EARLIER in this very pass (harvest_features.py:139-151): iterate the
+      // parallel decision from "none spawned" upwards, as feat_spawn does
+      for (;;) {
+        u32 num = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j)
+#pragma unroll
+          for (int k = -1; k <= 1; ++k) {
+            const bool earlier = j < 0 || (j == 0 && k < 0);
+            const uint8_t x = pm[cell + j * G::PW + k];
+            num += (x == CE_CELL_APPLE || (earlier && x == 0x42)) ? 1u : 0u;
+          }
+        const bool z = act && X < (num == 0 ? th0 : num == 1 ? th1 : num == 2 ? th2 : th3);
+        const bool changed = z != sp;
+        sp = z;
+        if (ballot(changed) == 0) break;
+        wave_sync();
+        pm_put(pm, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
+        wave_sync();
+      }
+      const u32 sb = row_bits(ballot(sp), sub);
+      if (ballot(sp) != 0) {  // the list of this pass's apples grows over the entries already consumed (rank <= q)
+        wave_sync();
+        if (sp) L[nsp + popc32(sb & below)] = (uint16_t)cell;
+        wave_sync();
+      }
+      nsp += popc32(sb);
+    }
+    if (ballot(nsp != 0u) != 0) {  // appended in list order: stamps continue the list; the owners of the cells take theirs
+      for (u32 k = 0; ballot(k < nsp) != 0; ++k) {
+        const bool on = k < nsp;
+        const u32 cellk = L[on ? k : 0u];
+        if (on && sl == 0u) pm[cellk] = CE_CELL_APPLE;
+        const u32 stamp8 = (next_a + k) << 8;
+#pragma unroll
+        for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = on && APAD[r] == cellk ? stamp8 : AS8[r];
+      }
+      wave_sync();
+      next_a += nsp;
+      napples += nsp;
+      dirty = dirty || nsp != 0u;
+    }
+    pos += inpass ? 2u * nelig : 0u;
+    pos -= pos > (u32)kMtN ? (u32)kMtN : 0u;  // (the twist above)
+  }
+  tw_pending &= tw_pending - 1;
+  if (tw_pending == 0) break;
+  }
+
+  CE_QSTAMP(6);
+  // ---- feature vectors (the observation): closest apple = min over (manhattan distance, list stamp) ----
+  const u32 prc0 = col_of<CE_KIND_HARVEST>(P0) | row_of<CE_KIND_HARVEST>(P0) << 8;
+  const u32 prc1 = col_of<CE_KIND_HARVEST>(P1) | row_of<CE_KIND_HARVEST>(P1) << 8;
+  u32 best0 = 0xffffffffu, best1 = 0xffffffffu;
+#if !defined(CE_QUAD_ABLATE) || CE_QUAD_ABLATE < 3
+#pragma unroll
+#else
+#pragma unroll
+  for (u32 r = 0; r < 1; ++r) best0 = best1 = AS8[r];
+  if (false)
+#endif
+  for (u32 r = 0; r < kCellsPerLane; ++r) {
+    const u32 pen = AS8[r] == kAbs8 ? 128u : 0u;  // absent cells sort behind every present one (distances stay below 64)
+    const u32 kk = AS8[r] | (kCellsPerLane * sl + r);
+    const u32 k0 = __builtin_amdgcn_sad_u8(ARC[r], prc0, pen) << 24 | kk, k1 = __builtin_amdgcn_sad_u8(ARC[r], prc1, pen) << 24 | kk;
+    best0 = k0 < best0 ? k0 : best0;
+    best1 = k1 < best1 ? k1 : best1;
+  }
+  best0 = row_min_all(best0);
+  best1 = row_min_all(best1);
+  const u32 mine = sl == 0u ? best0 : best1;  // lane a of a row writes agent a's vector
+  u32 ca = 0;
+  if ((mine >> 24) < 128u) ca = cell_rc(T.apple[mine & 0xffu]);
+  const u32 cn0 = close_count(pm, T, P0, sl, sub), cn1 = close_count(pm, T, P1, sl, sub);
+
+  CE_QSTAMP(7);
+  // ---- rewards, infos, transfers (two_stage_train.py:62-121), metrics ----
+  const u32 t = t_old + 1u;
+  const bool me0 = sl == 0u, agent = sl < 2u;
+  const u32 rew = me0 ? eat0 : eat1, ecl = me0 ? ecl0 : ecl1, cn = me0 ? cn0 : cn1;
+  const bool out = simple && agent;
+  double rw = (double)rew;
+  const u32 nmi = CE_MI_COUNT(2), nmf = CE_MF_COUNT(2);
+  const auto mi = p.int_metrics;
+  const auto mf = p.f64_metrics;
+  const u32 mib = e * nmi, mfb = e * nmf;
+  if (ballot(simple && (eat0 | eat1) != 0u) != 0) {
+    const bool touched = simple && (eat0 | eat1) != 0u;
+    // one wave owns these rows for the launch: an atomic add without a return value is the same read-modify-write minus
+    // the wait for the read (bitwise the same sums, integer and double alike)
+    if (touched && sl < 4u) {  // lane k < 4 of the row holds global metric k
+      const u32 add = sl == CE_MI_TOTAL_APPLES_EATEN || sl == CE_MI_RAW_ENV_REWARDS ? eat0 + eat1 : sl == CE_MI_LOW_DENSITY_APPLES ? ecl0 + ecl1 : 0u;
+      if (add) quad::add_i64(&GAT(mi, mib + sl), (long long)add);
+    }
+    if (touched && agent && rew) {
+      quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_A, sl)), (long long)rew);
+      if (ecl) quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_B, sl)), (long long)ecl);
+      quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_R, sl)), (long long)rew);
+      if (t_old) quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_TR, sl)), (long long)t_old * (long long)rew);
+    }
+  }
+  if (p.contract != CE_CONTRACT_NONE) {
+    double tr0, tr1;
+    if (p.contract == CE_CONTRACT_CLEANUP) tr0 = tr1 = 0.0;  // HarvestFeatures cleans nothing
+    else {
+      tr0 = (cn0 < 4u && ecl0 > 0u) ? theta : 0.0;
+      tr1 = (cn1 < 4u && ecl1 > 0u) ? theta : 0.0;
+    }
+    // agents with a zero transfer are skipped, in agent order (n = 2: the other agent's share is the whole transfer)
+    double total = 0.0;
+    if (tr0 != 0.0) {
+      rw = me0 ? rw - tr0 : rw + tr0;
+      total += tr0;
+    }
+    if (tr1 != 0.0) {
+      rw = me0 ? rw + tr1 : rw - tr1;
+      total += tr1;
+    }
+    if (simple && total != 0.0 && sl == 0u) quad::add_f64(&GAT(mf, mfb + CE_MF_TRANSFERS), total);
+    const bool any_rew = row_bits(ballot(agent && rw != 0.0), sub) != 0u;
+    if (out && any_rew) {
+      quad::add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_R, sl)), rw);
+      quad::add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_TR, sl)), (double)t_old * rw);
+    }
+  }
+  CE_QSTAMP(8);
+  // ---- stores (rows that took the packed step) ----
+  if (out) {
+    GAT(p.base_reward, 2u * e + sl) = (i32)rew;
+    GAT(p.reward, 2u * e + sl) = rw;
+    GAT((CE_GPTR(uint16_t))p.info, 2u * e + sl) = (uint16_t)(rew | ecl << 8);  // info[a][0..1] as one short
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32 Pm = me0 ? P0 : P1, Om = me0 ? O0 : O1, Pc = me0 ? P1 : P0, Oc = me0 ? O1 : O0;  // compute_closest_pos: a0 -> a1, a1 -> a0
+    const u32x4 head = {row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 16, Om | row_of<CE_KIND_HARVEST>(Pc) << 16,
+                        col_of<CE_KIND_HARVEST>(Pc) | Oc << 16, (ca >> 8) | (ca & 0xffu) << 16};
+    const auto f32 = (CE_GPTR(u32))p.features;
+    const u32 fb = (2u * e + sl) * 7u;  // 14 int16 per agent
+    GAT(f32, fb) = head.x;
+    GAT(f32, fb + 1u) = head.y;
+    GAT(f32, fb + 2u) = head.z;
+    GAT(f32, fb + 3u) = head.w;
+    GAT(f32, fb + 4u) = cn | napples << 16;
+    GAT(f32, fb + 5u) = 0u;
+    GAT(f32, fb + 6u) = 0u;
+    GAT((CE_GPTR(u32))p.agents, 2u * e + sl) = row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 8 | Om << 16;
+  }
+  if (simple && sl == 0u) {
+    GAT(p.done, e) = 0;
+    GAT(p.timestep, e) = (i32)t;
+    GAT(p.rng, wbase + (u32)kMtN) = pos;
+    if (dirty) GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u) = next_a;
+  }
+  if (simple && dirty) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) GAT(st32, stw + 5u * sl + (u32)k) = (AS8[2 * k] >> 8) | (AS8[2 * k + 1] << 8);
+  }
+  CE_QSTAMP(9);
+#undef CE_QVALID
+  // ---- the rows left over: one env at a time on the whole wave ----
+  u64 rest = ballot(live && !simple && sl == 0u);
+#if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 1
+  rest = 0;
+#endif
+  if (rest != 0) {
+    wave_sync();
+    for (; rest; rest &= rest - 1) {
+      feat_step_one<CE_KIND_HARVEST, 2>(p, call_actions, &lds.one, e_row0 + (ctz64(rest) >> 4));
+      wave_sync();
+    }
+  }
+  CE_QSTAMP(10);
 }
 
 // Fused multi-step rollout of the feature-vector envs (ce_rollout_fused): list stamps, agents and the CPython `random`
@@ -4153,12 +4649,22 @@ void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error
   } while (0)
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_construct); }
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_reset); }
+// CE_FEAT_QUAD=0 keeps the one-env-per-wave kernel for HarvestFeatures n = 2 (A/B runs, tests that compare the two)
+static bool feat_quad_on() {
+  static const bool on = [] {
+    const char* v = getenv("CE_FEAT_QUAD");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) {
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
 #define CE_FEAT_STEP_LAUNCH(K_, N_) \
   hipLaunchKernelGGL((k_feat_step<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, p.actions, p.mask, first, first + count)
   if (kind == CE_KIND_HARVEST_FEATURES) {
-    if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 2);
+    if (p.n == 2 && feat_quad_on())
+      hipLaunchKernelGGL(k_feat_step_quad, dim3((count + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, dp, p.actions, first, first + count);
+    else if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 2);
     else CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 0);
   } else {
     if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_CLEANUP, 2);

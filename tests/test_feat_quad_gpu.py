@@ -1,0 +1,80 @@
+"""k_feat_step_quad (HarvestFeatures, two agents, four envs per wave — BASELINE config 0's single-step kernel) against the
+oracle: every persistent and output field after every step, with batch sizes that leave a partly filled wave, short horizons
+(the episode end + reset take the one-env path inside the same launch), both contract settings, slices that start off a
+multiple of four, and bad action ids in some envs (fault flag set, the env left untouched)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["grid", "agents", "rng", "timestep", "theta", "base_reward", "reward", "done", "info", "features", "int_metrics",
+          "f64_metrics", "final_int_metrics", "final_f64_metrics", "error_flags"]
+
+
+def _same(env, orc, E, tag):
+    for f in FIELDS:
+        x, y = env.download(f, raw=True) if f == "grid" else env.download(f), getattr(orc, f)
+        if f == "rng":
+            x, y = x.reshape(E, 2, 628)[:, :, :625], y.reshape(E, 2, 628)[:, :, :625]
+        ok = np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+        assert ok, "field %s differs %s (envs %s)" % (f, tag, np.nonzero((np.asarray(x) != np.asarray(y)).reshape(E, -1).any(axis=1))[0][:8])
+
+
+def _pair(E, **kw):
+    from contracts_amd.engine import BatchedEnv
+    from oracle.pyoracle import Oracle
+    env, orc = BatchedEnv("harvest_features", E, 2, **kw), Oracle("harvest_features", E, 2, **kw)
+    seeds = (np.arange(E) * 104729 + 17).astype(np.uint64)
+    for o in (env, orc):
+        o.seed(seeds)
+        o.reset()
+    return env, orc
+
+
+@pytest.mark.parametrize("E,contract,horizon,T", [(203, "harvest_local", 23, 120), (64, None, 1000, 400), (1, "harvest_local", 7, 40),
+                                                  (6, None, 1, 12), (1031, "harvest_local", 1000, 90)])
+def test_quad_step_vs_oracle(E, contract, horizon, T):
+    env, orc = _pair(E, contract=contract, horizon=horizon, auto_reset=True)
+    rs = np.random.RandomState(E + horizon)
+    for t in range(T):
+        a = rs.randint(0, 8, size=(E, 2)).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        _same(env, orc, E, "at step %d" % t)
+    env.close()
+    orc.close()
+
+
+def test_quad_step_eats_a_lot():
+    """agents that mostly walk (few turns): more apples eaten, more cells to draw for, longer spawn passes"""
+    E, T = 257, 300
+    env, orc = _pair(E, contract="harvest_local", horizon=1000, auto_reset=True)
+    rs = np.random.RandomState(9)
+    for t in range(T):
+        a = rs.choice(8, size=(E, 2), p=[.22, .22, .22, .22, .03, .03, .03, .03]).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        _same(env, orc, E, "at step %d" % t)
+    env.close()
+    orc.close()
+
+
+def test_quad_step_slices_and_bad_actions():
+    import torch
+    E, T = 150, 60
+    env, orc = _pair(E, contract="harvest_local", horizon=31, auto_reset=True)
+    rs = np.random.RandomState(3)
+    cuts = [0, 5, 6, 71, 150]  # slices starting off a multiple of four, a one-env slice
+    for t in range(T):
+        a = rs.randint(0, 8, size=(E, 2)).astype(np.uint8)
+        bad = rs.rand(E) < 0.05
+        a[bad, rs.randint(0, 2)] = 8 + rs.randint(0, 200)
+        dev = torch.from_numpy(a).cuda()
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            env.step_range_device(dev.data_ptr(), lo, hi - lo)
+        torch.cuda.synchronize()
+        orc.step(a)
+        _same(env, orc, E, "at step %d" % t)
+        assert (env.download("error_flags")[bad] & 1).all()
+    env.close()
+    orc.close()
