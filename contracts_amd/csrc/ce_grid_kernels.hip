@@ -162,7 +162,7 @@ DEVINL u32 mt_mix(u32 a, u32 b, u32 c) {  // new = c ^ twist(a,b)
 typedef __attribute__((address_space(3))) u32 lds_u32;
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
-__device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) {
+DEVINL void mt_twist_body(lds_u32* mt, u32 lane) {
   lds_u32x4* Q = (lds_u32x4*)mt;
   constexpr u32 kQuads = (u32)kMtN / 4;  // 156
   wave_sync();
@@ -187,9 +187,14 @@ __device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) {
   }
 }
 
+__device__ __noinline__ void mt_twist_lds(lds_u32* mt, u32 lane) { mt_twist_body(mt, lane); }
+
 DEVINL void mt_twist(u32* mt, u32 lane) {
   if (!diag::ablate_twist) mt_twist_lds((lds_u32*)mt, lane);
 }
+// the same inlined: for a caller that holds most of its register budget live at the call (a real call saves and restores
+// the caller's registers through scratch memory around it)
+DEVINL void mt_twist_inline(u32* mt, u32 lane) { mt_twist_body((lds_u32*)mt, lane); }
 
 // Counter mode (CE_FLAG_RNG_COUNTER, contracts_engine.h): Philox4x32-10 (Salmon et al., SC'11; Random123), ten rounds of
 //   (c0, c1, c2, c3) <- (hi(M1 c2) ^ c1 ^ k0, lo(M1 c2), hi(M0 c0) ^ c3 ^ k1, lo(M0 c0)),  k0 += W0, k1 += W1.
@@ -3635,8 +3640,8 @@ DEVINL void feat_step_core(FEnv<GK>& E, const GridParams& p, const OUT& out, u32
 
 // One single-step launch's work for env `e` on the whole wave.  NFIX: the number of agents as a compile-time constant
 // (0 = p.n), as for k_grid_step; the instance is for n = 2 (BASELINE config 0)
-template <int GK, int NFIX>
-DEVINL void feat_step_one(const GridParams& p, const uint8_t* __restrict__ call_actions, FeatLds<GK>* lds, u32 e) {
+template <int GK, int NFIX, class OUT>
+DEVINL void feat_step_one(const GridParams& p, const uint8_t* __restrict__ call_actions, FeatLds<GK>* lds, u32 e, const OUT& out) {
   FEnv<GK> E;
   E.lane = lane_id();
   E.e = rfl(e);
@@ -3652,14 +3657,14 @@ DEVINL void feat_step_one(const GridParams& p, const uint8_t* __restrict__ call_
   u32 t = (u32)p.timestep[E.e], fault = 0;
   double theta = p.theta[E.e];
   bool did_reset = false;
-  feat_step_core<GK, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
+  feat_step_core<GK, false>(E, p, out, ACT, t, theta, fault, did_reset);
 }
 template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions,
                                                                    const uint8_t* __restrict__ call_mask, u32 env_first, u32 env_end) {
   __shared__ FeatLds<GK> lds;
   const u32 e = env_first + blockIdx.x;
   if (e >= env_end) return;
-  feat_step_one<GK, NFIX>(*pp, call_actions, &lds, e);
+  feat_step_one<GK, NFIX>(*pp, call_actions, &lds, e, StepOutDirect{*pp});
 }
 
 // ----------------------------------------------------------------------------------------
@@ -3683,11 +3688,18 @@ constexpr u32 kCellsPerLane = 10;
 constexpr u32 kAbs8 = kAbsent << 8;  // list stamps are kept shifted left by 8: (stamp << 8) | cell index is the tie-break key
 static_assert(16 * kCellsPerLane >= (u32)G::NAPPLE && 16 * kCellsPerLane == CE_FEAT_APPLE_SLOTS, "a row covers the list slots");
 
+// The presence maps keep only what a step can touch — padded rows 5 .. 24 (the playable rows plus two on either side), as the
+// bytes [kMapLo, kMapHi) of the padded image — and are addressed through a pointer moved back by kMapLo, so that padded indices
+// work unchanged.  kDump (row 5, column 0: never read) takes the stores of lanes that have nothing to write.
+constexpr u32 kMapLo = 256, kMapHi = 1312, kDump = 260;
+static_assert(kMapLo % 16 == 0 && kMapHi % 16 == 0 && kMapLo <= 5 * G::PW && kMapHi >= 25 * G::PW && kMapHi <= (u32)G::PQUADS * 16, "rows 5 .. 24");
 struct alignas(16) Lds {
-  uint8_t pm[4][G::PQUADS * 16];  // presence map of each row's env
+  uint8_t pm[4][kMapHi - kMapLo];  // presence map of each row's env
   uint16_t L[4][CE_FEAT_APPLE_SLOTS];  // compacted cells to draw for (padded index), then the cells that got an apple
   u32 tw[kMtN];                   // one CPython generator at a time, for a row whose draws run over the generation end
+  uint16_t cell_pad[CE_FEAT_APPLE_SLOTS], cell_rc[CE_FEAT_APPLE_SLOTS];  // the static list of apple cells: padded index, col | row << 8
 };
+DEVINL void put(uint8_t* pm, bool on, u32 idx, u32 val) { pm[on ? idx : kDump] = (uint8_t)(on ? val : 0u); }
 
 template <int K> DEVINL u32 row_bcast(u32 v) { return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (K << 5)); }  // lane K of the row
 template <int CTRL> DEVINL u32 dpp_zero(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
@@ -3719,11 +3731,19 @@ DEVINL u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
 DEVINL void add_i64(CE_GPTR(int64_t) a, long long v) { (void)__hip_atomic_fetch_add((CE_GPTR(long long))a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEVINL void add_f64(CE_GPTR(double) a, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64(a, v); }
 
+// the i-th of the 21 offsets (j, k) with j^2 + k^2 <= 5, row-major, as a padded-index delta (what GridTables::close_off holds:
+// harvest_new.py:326-336; rows of 3, 5, 5, 5, 3 cells)
+DEVINL i32 close_offset(u32 i) {
+  const i32 j = i < 3u ? -2 : i < 8u ? -1 : i < 13u ? 0 : i < 18u ? 1 : 2;
+  const i32 first = i < 3u ? 0 : i < 8u ? 3 : i < 13u ? 8 : i < 18u ? 13 : 18;
+  const i32 k = (i32)i - first - (i < 3u || i >= 18u ? 1 : 2);
+  return j * (i32)G::PW + k;
+}
 // apples within j^2 + k^2 <= 5 of padded cell `c` (row-uniform) in the row's map: 21 offsets over 16 lanes, two rounds
-DEVINL u32 close_count(const uint8_t* pm, const GridTables& T, u32 c, u32 sl, u32 sub) {
-  const i32 o0 = (i32)T.close_off[sl], o1 = (i32)T.close_off[16u + (sl < 5u ? sl : 0u)];
-  const bool v0 = pm[(i32)c + o0] == CE_CELL_APPLE;
-  const bool v1 = sl < 5u && pm[(i32)c + o1] == CE_CELL_APPLE;
+// (co0 / co1: this lane's offsets, close_offset(sl) and close_offset(16 + sl) — the latter only for sl < 5)
+DEVINL u32 close_count(const uint8_t* pm, i32 co0, i32 co1, u32 c, u32 sl, u32 sub) {
+  const bool v0 = pm[(i32)c + co0] == CE_CELL_APPLE;
+  const bool v1 = sl < 5u && pm[(i32)c + co1] == CE_CELL_APPLE;
   return popc32(row_bits(ballot(v0), sub)) + popc32(row_bits(ballot(v1), sub));
 }
 }  // namespace quad
@@ -3735,157 +3755,247 @@ DEVINL u32 close_count(const uint8_t* pm, const GridTables& T, u32 c, u32 sl, u3
     __builtin_amdgcn_s_waitcnt(0);                                                 \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
     __builtin_amdgcn_sched_barrier(0);                                             \
-    if (lane == 0 && p.debug) p.debug[(size_t)e_row0 * 16 + (k)] = t_;             \
+    if (C.lane == 0 && C.pp->debug) C.pp->debug[(size_t)C.e_row0 * 16 + (k)] = t_;     \
   } while (0)
 #else
 #define CE_QSTAMP(k) ((void)0)
 #endif
-__global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, u32 env_first,
-                                                         u32 env_end) {
-  using namespace quad;
-  const GridParams& p = *pp;
-  const GridTables& T = c_tab[CE_KIND_HARVEST];
-  __shared__ union {
-    quad::Lds q;
-    FeatLds<CE_KIND_HARVEST> one;
-  } lds;
-  const u32 lane = lane_id(), sl = lane & 15u, sub = lane >> 4;
-  const u32 e_row0 = env_first + 4u * blockIdx.x;
-  if (e_row0 >= env_end) return;
-  const bool live = e_row0 + sub < env_end;
-  const u32 e = live ? e_row0 + sub : env_end - 1u;  // rows past the end shadow the last env: they load, compute and store nothing
-  CE_QSTAMP(0);
-  uint8_t* pm = lds.q.pm[sub];
-  const u32 below = (1u << sl) - 1u;
+namespace quad {
+union QuadLds {
+  Lds q;
+  FeatLds<CE_KIND_HARVEST> one;  // the one-env code borrows the block while the packed state is in HBM
+};
+// what a row's lanes keep in registers for their env (per-env values replicated over the row's 16 lanes)
+struct Row {
+  u32 AS8[kCellsPerLane];                       // list stamp << 8 of this lane's ten cells (kAbs8 = no apple)
+  u32 P0, P1, O0, O1;                           // the two agents: padded cell, orientation
+  u32 next_a, pos, t;                           // next list stamp, CPython stream position, timestep
+  double theta;
+  bool dirty;                                   // the list changed since it was last in HBM
+};
+struct Ctx {
+  const GridParams* pp;  // (a pointer: a fused rollout re-reads the block through an opaque copy every step)
+  QuadLds* L;
+  u32 lane, sl, sub, below, e_row0, e, q2;
+  bool live, lastl;  // lastl: lane 15 owns cells 150 .. 159, the last five are past the list end
+  uint8_t* pm;       // the row's presence map, indexed by padded cell
+  const uint16_t* pad;  // this lane's ten cells in the static list (LDS): padded index ...
+  const uint16_t* rc;   // ... and col | row << 8
+  i32 co0, co1;         // this lane's two offsets of the 21-cell neighbourhood (close_count)
+};
+// the stream words a step starts with: doubles sl and sl + 16 after the row's position (clamped inside the generation),
+// and — for ONE row of the wave that is within 48 words of the generation end — the whole key, to be parked in LDS
+struct Window {
+  u32 wa0, wb0, wa1, wb1;
+  u32 tw_row;
+  uint4 pf0, pf1, pf2;
+};
+#define CE_QVALID(C_, r) (!((C_).lastl && (r) >= (u32)G::NAPPLE - 150u))
 
-  // ---- loads: actions, clocks, the two agents, the list stamps (20 bytes per lane), the stream window ----
-  const u32 act2 = (u32)GAT((CE_GPTR(const uint16_t))call_actions, e);
-  const u32 ACT0 = act2 & 0xffu, ACT1 = act2 >> 8;
-  const u32 t_old = (u32)GAT(p.timestep, e);
-  const double theta = GAT(p.theta, e);
-  const u32 wbase = e * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID;
-  u32 pos = GAT(p.rng, wbase + (u32)kMtN);
-  // a row whose position is within 48 words of the generation end will probably need the twist below: its key words are
-  // requested now and parked in LDS once the map work is done, instead of being waited for in the middle of the step
-  u32 tw_row = 0xffffffffu;
-  uint4 pf0 = {}, pf1 = {}, pf2 = {};
-  const u32 q2 = min(lane + 128u, (u32)kMtN / 4u - 1u);
-  {
-    const u64 near_end = ballot(live && sl == 0u && pos + 48u > (u32)kMtN);
-    if (near_end != 0) {
-      tw_row = ctz64(near_end) >> 4;
-      const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(e_row0 + tw_row) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
-      pf0 = key4[lane];
-      pf1 = key4[lane + 64u];
-      pf2 = key4[q2];
+DEVINL void derive(Ctx& C, u32 env_end);
+DEVINL void begin(Ctx& C, u32 env_first, u32 env_end, u32 block) {
+  C.lane = lane_id();
+  C.e_row0 = env_first + 4u * block;
+  derive(C, env_end);
+  C.co0 = close_offset(C.sl);
+  C.co1 = close_offset(16u + (C.sl < 5u ? C.sl : 0u));
+}
+// Everything derived from the lane id / env index (address offsets, masks, LDS pointers).  A fused rollout calls this at the
+// top of every step on an opaque copy of the lane id: hoisted out of the step loop these values would live in registers
+// across the whole body (the compiler then spills a hundred of them), recomputed they cost a handful of instructions.
+DEVINL void rederive(Ctx& C, u32 env_end) {
+  asm volatile("" : "+v"(C.lane));
+  C.e_row0 = opaque_u32(C.e_row0);
+  derive(C, env_end);
+}
+DEVINL void derive(Ctx& C, u32 env_end) {
+  C.sl = C.lane & 15u;
+  C.sub = C.lane >> 4;
+  C.below = (1u << C.sl) - 1u;
+  C.live = C.e_row0 + C.sub < env_end;
+  C.e = C.live ? C.e_row0 + C.sub : env_end - 1u;  // rows past the end shadow the last env: they load, compute and store nothing
+  C.q2 = min(C.lane + 128u, (u32)kMtN / 4u - 1u);
+  C.lastl = C.sl == 15u;
+  C.pm = C.L->q.pm[C.sub] - kMapLo;
+  C.pad = C.L->q.cell_pad + kCellsPerLane * C.sl;
+  C.rc = C.L->q.cell_rc + kCellsPerLane * C.sl;
+}
+// the static list of apple cells into LDS, once per wave (the slots past the list end aim at the dump byte and are never valid)
+DEVINL void load_static(const Ctx& C) {
+  const GridTables& T = c_tab[CE_KIND_HARVEST];
+#pragma unroll
+  for (u32 k = 0; k < (CE_FEAT_APPLE_SLOTS + 63u) / 64u; ++k) {
+    const u32 idx = C.lane + 64u * k;
+    const u32 v = T.apple[idx < (u32)G::NAPPLE ? idx : 0u];
+    if (idx < CE_FEAT_APPLE_SLOTS) {
+      C.L->q.cell_pad[idx] = (uint16_t)(idx < (u32)G::NAPPLE ? cell_pad(v) : kDump);
+      C.L->q.cell_rc[idx] = (uint16_t)cell_rc(v);
     }
   }
+}
+DEVINL u32 rng_base(const Ctx& C) { return C.e * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID; }
+DEVINL u32 state_base(const Ctx& C) { return C.e * (CE_FEAT_STATE_BYTES / 4u); }
+DEVINL void fetch_window(Window& W, const Row& R, const Ctx& C) {
+  const GridParams& p = *C.pp;
+  const u32 wbase = rng_base(C);
+  W.tw_row = 0xffffffffu;
+  W.pf0 = W.pf1 = W.pf2 = uint4{};
+  const u64 near_end = ballot(C.live && C.sl == 0u && R.pos + 48u > (u32)kMtN);
+  if (near_end != 0) {
+    W.tw_row = ctz64(near_end) >> 4;
+    const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(C.e_row0 + W.tw_row) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+    W.pf0 = key4[C.lane];
+    W.pf1 = key4[C.lane + 64u];
+    W.pf2 = key4[C.q2];
+  }
+  const u32 q0w = min(R.pos + 2u * C.sl, (u32)kMtN - 2u), q1w = min(R.pos + 2u * C.sl + 32u, (u32)kMtN - 2u);
+  W.wa0 = GAT(p.rng, wbase + q0w);
+  W.wb0 = GAT(p.rng, wbase + q0w + 1u);
+  W.wa1 = GAT(p.rng, wbase + q1w);
+  W.wb1 = GAT(p.rng, wbase + q1w + 1u);
+}
+// HBM -> registers: clocks, stream position, the two agents, the list stamps (20 bytes per lane)
+DEVINL void load_row(Row& R, const Ctx& C) {
+  const GridParams& p = *C.pp;
+  const u32 e = C.e;
+  R.t = (u32)GAT(p.timestep, e);
+  R.theta = GAT(p.theta, e);
+  R.pos = GAT(p.rng, rng_base(C) + (u32)kMtN);
   const auto st32 = (CE_GPTR(u32))p.grid;
-  const u32 stw = e * (CE_FEAT_STATE_BYTES / 4u);
+  const u32 stw = state_base(C);
   u32 sd[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) sd[k] = GAT(st32, stw + 5u * sl + (u32)k);
-  u32 next_a = GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u);
+  for (int k = 0; k < 5; ++k) sd[k] = GAT(st32, stw + 5u * C.sl + (u32)k);
+  R.next_a = GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u);
   const u32 ag0 = GAT((CE_GPTR(const u32))p.agents, 2u * e), ag1 = GAT((CE_GPTR(const u32))p.agents, 2u * e + 1u);
-  u32 APAD[kCellsPerLane], ARC[kCellsPerLane];
 #pragma unroll
   for (u32 r = 0; r < kCellsPerLane; ++r) {
-    const u32 idx = kCellsPerLane * sl + r;
-    const u32 v = T.apple[idx < (u32)G::NAPPLE ? idx : 0u];
-    APAD[r] = idx < (u32)G::NAPPLE ? cell_pad(v) : 0u;  // the slots past the list end aim at byte 0 of the map and are never valid
-    ARC[r] = cell_rc(v);
+    const u32 v = (r & 1u) ? (sd[r >> 1] >> 8) & 0xffff00u : (sd[r >> 1] << 8) & 0xffff00u;
+    R.AS8[r] = CE_QVALID(C, r) ? v : kAbs8;
   }
-  const u32 q0w = min(pos + 2u * sl, (u32)kMtN - 2u), q1w = min(pos + 2u * sl + 32u, (u32)kMtN - 2u);
-  const u32 wa0 = GAT(p.rng, wbase + q0w), wb0 = GAT(p.rng, wbase + q0w + 1u);
-  const u32 wa1 = GAT(p.rng, wbase + q1w), wb1 = GAT(p.rng, wbase + q1w + 1u);
-  CE_QSTAMP(1);
-  {  // the map with every apple present (16-byte copies; the last round's idle lanes repeat the last quad)
-    const uint4* bsrc = (const uint4*)T.base_pmap;
-    uint4* pm128 = (uint4*)pm;
-#pragma unroll
-    for (u32 k = 0; k < ((u32)G::PQUADS + 15u) / 16u; ++k) {
-      const u32 q = min(sl + 16u * k, (u32)G::PQUADS - 1u);
-      pm128[q] = bsrc[q];
-    }
-  }
-  u32 AS8[kCellsPerLane];  // stamp << 8
-#pragma unroll
-  for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = (r & 1u) ? (sd[r >> 1] >> 8) & 0xffff00u : (sd[r >> 1] << 8) & 0xffff00u;
-  u32 P0 = pad_of<CE_KIND_HARVEST>(ag0 & 0xffu, (ag0 >> 8) & 0xffu), O0 = (ag0 >> 16) & 3u;
-  u32 P1 = pad_of<CE_KIND_HARVEST>(ag1 & 0xffu, (ag1 >> 8) & 0xffu), O1 = (ag1 >> 16) & 3u;
-  const bool lastl = sl == 15u;  // lane 15 owns cells 150 .. 159: the last five are past the list end
-#define CE_QVALID(r) (!(lastl && (r) >= (u32)G::NAPPLE - 150u))
-#pragma unroll
-  for (u32 r = 0; r < kCellsPerLane; ++r)
-    if (!CE_QVALID(r)) AS8[r] = kAbs8;
+  R.P0 = pad_of<CE_KIND_HARVEST>(ag0 & 0xffu, (ag0 >> 8) & 0xffu);
+  R.O0 = (ag0 >> 16) & 3u;
+  R.P1 = pad_of<CE_KIND_HARVEST>(ag1 & 0xffu, (ag1 >> 8) & 0xffu);
+  R.O1 = (ag1 >> 16) & 3u;
+  R.dirty = false;
+}
+// the row's presence map: the reset-time map (every apple present) minus the absent cells
+DEVINL void build_map(const Row& R, const Ctx& C) {
+  const GridTables& T = c_tab[CE_KIND_HARVEST];
+  const uint4* bsrc = (const uint4*)(T.base_pmap + kMapLo);
+  uint4* pm128 = (uint4*)C.L->q.pm[C.sub];
+  constexpr u32 kQuads = (kMapHi - kMapLo) / 16u;
   wave_sync();
 #pragma unroll
-  for (u32 r = 0; r < kCellsPerLane; ++r) pm[AS8[r] == kAbs8 ? APAD[r] : 0u] = CE_CELL_EMPTY;  // (byte 0 is the border corner: empty)
+  for (u32 k = 0; k < (kQuads + 15u) / 16u; ++k) {  // 16-byte copies; the last round's idle lanes repeat the last quad
+    const u32 qd = min(C.sl + 16u * k, kQuads - 1u);
+    pm128[qd] = bsrc[qd];
+  }
   wave_sync();
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) C.pm[R.AS8[r] == kAbs8 ? (u32)C.pad[r] : kDump] = CE_CELL_EMPTY;
+  wave_sync();
+}
+// registers -> HBM for the rows in `rows`: what the next launch (or the one-env code) reads
+DEVINL void flush_row(Row& R, const Ctx& C, bool rows) {
+  const GridParams& p = *C.pp;
+  const u32 e = C.e;
+  const auto st32 = (CE_GPTR(u32))p.grid;
+  const u32 stw = state_base(C);
+  if (rows && C.sl < 2u) {
+    const u32 Pm = C.sl == 0u ? R.P0 : R.P1, Om = C.sl == 0u ? R.O0 : R.O1;
+    GAT((CE_GPTR(u32))p.agents, 2u * e + C.sl) = row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 8 | Om << 16;
+  }
+  if (rows && C.sl == 0u) {
+    GAT(p.timestep, e) = (i32)R.t;
+    GAT(p.rng, rng_base(C) + (u32)kMtN) = R.pos;
+    if (R.dirty) GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u) = R.next_a;
+  }
+  if (rows && R.dirty) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) GAT(st32, stw + 5u * C.sl + (u32)k) = (R.AS8[2 * k] >> 8) | (R.AS8[2 * k + 1] << 8);
+  }
+  R.dirty = R.dirty && !rows;
+}
+
+// One step of every row that takes the packed path (returned per row; the others are left exactly as they were).
+// OUT: where the step's outputs go (the handle's buffers or a plane of a fused rollout).
+template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 act2, Window& W) {
+  const GridParams& p = *C.pp;
+  const GridTables& T = c_tab[CE_KIND_HARVEST];
+  const u32 lane = C.lane, sl = C.sl, sub = C.sub, below = C.below, e = C.e, q2 = C.q2;
+  uint8_t* pm = C.pm;
+  // a bad action id, or the horizon (episode metrics + reset): not taken here
+  const bool simple = C.live && (act2 & 0xffu) <= 7u && (act2 >> 8) <= 7u && R.t + 1u != p.horizon;
+  const u32 ACT0 = simple ? act2 & 0xffu : 4u, ACT1 = simple ? act2 >> 8 : 4u;  // (a row that sits the step out: two agents that stay)
+  const u32 t_old = R.t;
+  const u32 wbase = rng_base(C);
 
   CE_QSTAMP(2);
   // ---- move_squares in dict order: stayers first, then the movers by key; a mover is refused by a wall or a claimed square ----
   const bool m0 = ACT0 < 4u, m1 = ACT1 < 4u;
   const i32 d0 = ACT0 == 0 ? -1 : ACT0 == 1 ? 1 : ACT0 == 2 ? -(i32)G::PW : (i32)G::PW;
   const i32 d1 = ACT1 == 0 ? -1 : ACT1 == 1 ? 1 : ACT1 == 2 ? -(i32)G::PW : (i32)G::PW;
-  const u32 tg0 = m0 ? (u32)((i32)P0 + d0) : P0, tg1 = m1 ? (u32)((i32)P1 + d1) : P1;
+  const u32 tg0 = m0 ? (u32)((i32)R.P0 + d0) : R.P0, tg1 = m1 ? (u32)((i32)R.P1 + d1) : R.P1;
   const bool w0 = pm[tg0] == CE_CELL_WALL, w1 = pm[tg1] == CE_CELL_WALL;
-  const u32 N0 = (m0 && !w0 && !(!m1 && tg0 == P1)) ? tg0 : P0;
-  const u32 N1 = (m1 && !w1 && tg1 != N0) ? tg1 : P1;
-  P0 = N0;
-  P1 = N1;
+  const u32 P0 = (m0 && !w0 && !(!m1 && tg0 == R.P1)) ? tg0 : R.P0;
+  const u32 P1 = (m1 && !w1 && tg1 != P0) ? tg1 : R.P1;
+  R.P0 = P0;
+  R.P1 = P1;
 
   // ---- consume in move_squares order (a1 eats first only when it stays and a0 moves) ----
   const bool swap = m0 && !m1;
   const u32 pf = swap ? P1 : P0, ps = swap ? P0 : P1;
-  bool dirty = false;
   u32 eat_f = 0, eat_s = 0, ecl_f = 0, ecl_s = 0;
   {
     const bool ef = pm[pf] == CE_CELL_APPLE;
     if (ballot(ef) != 0) {
-      const u32 close = close_count(pm, T, pf, sl, sub);  // counted before the apple is removed
+      const u32 close = close_count(pm, C.co0, C.co1, pf, sl, sub);  // counted before the apple is removed
       eat_f = ef ? 1u : 0u;
       ecl_f = ef && close < 4u ? 1u : 0u;
       wave_sync();
-      pm_put(pm, ef && sl == 0u, pf, CE_CELL_EMPTY);
+      put(pm, ef && sl == 0u, pf, CE_CELL_EMPTY);
 #pragma unroll
-      for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = ef && APAD[r] == pf ? kAbs8 : AS8[r];
-      dirty = dirty || ef;
+      for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = ef && (u32)C.pad[r] == pf ? kAbs8 : R.AS8[r];
+      R.dirty = R.dirty || ef;
       wave_sync();
     }
     const bool es = pm[ps] == CE_CELL_APPLE;
     if (ballot(es) != 0) {
-      const u32 close = close_count(pm, T, ps, sl, sub);
+      const u32 close = close_count(pm, C.co0, C.co1, ps, sl, sub);
       eat_s = es ? 1u : 0u;
       ecl_s = es && close < 4u ? 1u : 0u;
       wave_sync();
-      pm_put(pm, es && sl == 0u, ps, CE_CELL_EMPTY);
+      put(pm, es && sl == 0u, ps, CE_CELL_EMPTY);
 #pragma unroll
-      for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = es && APAD[r] == ps ? kAbs8 : AS8[r];
-      dirty = dirty || es;
+      for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = es && (u32)C.pad[r] == ps ? kAbs8 : R.AS8[r];
+      R.dirty = R.dirty || es;
       wave_sync();
     }
   }
   const u32 eat0 = swap ? eat_s : eat_f, eat1 = swap ? eat_f : eat_s;
   const u32 ecl0 = swap ? ecl_s : ecl_f, ecl1 = swap ? ecl_f : ecl_s;
   // ---- rotations ----
-  O0 = (O0 + (ACT0 == 5u ? 1u : ACT0 == 6u ? 3u : 0u)) & 3u;
-  O1 = (O1 + (ACT1 == 5u ? 1u : ACT1 == 6u ? 3u : 0u)) & 3u;
+  R.O0 = (R.O0 + (ACT0 == 5u ? 1u : ACT0 == 6u ? 3u : 0u)) & 3u;
+  R.O1 = (R.O1 + (ACT1 == 5u ? 1u : ACT1 == 6u ? 3u : 0u)) & 3u;
 
   CE_QSTAMP(3);
-  if (tw_row != 0xffffffffu) {
-    uint4* tw4 = (uint4*)lds.q.tw;
-    tw4[lane] = pf0;
-    tw4[lane + 64u] = pf1;
-    tw4[q2] = pf2;
+  if (W.tw_row != 0xffffffffu) {  // the key requested with the window: parked now that the map work no longer waits behind it
+    uint4* tw4 = (uint4*)C.L->q.tw;
+    tw4[lane] = W.pf0;
+    tw4[lane + 64u] = W.pf1;
+    tw4[q2] = W.pf2;
   }
   // ---- spawn_apples: one random.random() per absent cell no agent stands on, in list order ----
   bool el[kCellsPerLane];
   u32 cnt = 0, nabs = 0;
+  u32 padv[kCellsPerLane];  // read in one batch: a read inside each of the conditional stores below would be waited for ten times
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) padv[r] = C.pad[r];
 #pragma unroll
   for (u32 r = 0; r < kCellsPerLane; ++r) {
-    const bool ab = CE_QVALID(r) && AS8[r] == kAbs8;
-    el[r] = ab && APAD[r] != P0 && APAD[r] != P1;
+    const bool ab = CE_QVALID(C, r) && R.AS8[r] == kAbs8;
+    el[r] = simple && ab && padv[r] != P0 && padv[r] != P1;
     cnt += el[r] ? 1u : 0u;
     nabs += ab ? 1u : 0u;
   }
@@ -3893,11 +4003,10 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
   const u32 tot = row_bcast<15>(incl);
   const u32 nelig = tot & 0xffffu;
   u32 napples = (u32)G::NAPPLE - (tot >> 16);
-  const bool simple = live && ACT0 <= 7u && ACT1 <= 7u && t_old + 1u != p.horizon;
-  // Draws that cross the generation end get the twist from the whole wave, the row's key passing through lds.q.tw.  The
-  // buffer serves one row at a time: the first pass below takes every row that does not twist plus the first one that does,
+  // Draws that cross the generation end get the twist from the whole wave, the row's key passing through the LDS block.  The
+  // block serves one row at a time: the first pass below takes every row that does not twist plus the first one that does,
   // each further twisting row of the wave (rare) gets a pass of its own.
-  const bool over = simple && pos + 2u * nelig > (u32)kMtN;
+  const bool over = simple && R.pos + 2u * nelig > (u32)kMtN;
 #if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 1  // timing probes (wrong results): 1 = no twist, no one-env rows
   u64 tw_pending = 0;
 #else
@@ -3905,127 +4014,128 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
 #endif
   CE_QSTAMP(4);
   for (bool first_pass = true;; first_pass = false) {
-  const u32 tws = tw_pending ? ctz64(tw_pending) >> 4 : 0xffffffffu;
-  const bool istw = over && sub == tws;
-  const bool inpass = first_pass ? simple && (!over || istw) : istw;
-  u32 c_tw = 0xffffffffu;  // the chunk of 16 draws in which the twisting row passes word 624
-  if (tw_pending != 0) {
-    if (tws != tw_row) {  // (not the row whose key was parked in LDS ahead of time)
-      const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
-      uint4* tw4 = (uint4*)lds.q.tw;
+    const u32 tws = tw_pending ? ctz64(tw_pending) >> 4 : 0xffffffffu;
+    const bool istw = over && sub == tws;
+    const bool inpass = first_pass ? simple && (!over || istw) : istw;
+    u32 c_tw = 0xffffffffu;  // the chunk of 16 draws in which the twisting row passes word 624
+    if (tw_pending != 0) {
+      if (tws != W.tw_row) {  // (not the row whose key was parked in LDS ahead of time)
+        const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(C.e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+        uint4* tw4 = (uint4*)C.L->q.tw;
+        wave_sync();
+        const uint4 r0 = key4[lane], r1 = key4[lane + 64u], r2 = key4[q2];
+        tw4[lane] = r0;
+        tw4[lane + 64u] = r1;
+        tw4[q2] = r2;
+      }
+      W.tw_row = 0xffffffffu;  // the block holds a twisted key after this pass
+      const u32 pos_tw = rdl(R.pos, tws << 4);
+      c_tw = pos_tw >= 593u ? 0u : (593u - pos_tw + 31u) >> 5;  // smallest c with pos + 32 c + 31 >= 624
       wave_sync();
-      const uint4 r0 = key4[lane], r1 = key4[lane + 64u], r2 = key4[q2];
-      tw4[lane] = r0;
-      tw4[lane + 64u] = r1;
-      tw4[q2] = r2;
     }
-    tw_row = 0xffffffffu;  // the buffer holds a twisted key after this pass
-    const u32 pos_tw = rdl(pos, tws << 4);
-    c_tw = pos_tw >= 593u ? 0u : (593u - pos_tw + 31u) >> 5;  // smallest c with pos + 32 c + 31 >= 624
-    wave_sync();
-  }
-  CE_QSTAMP(5);
+    CE_QSTAMP(5);
 #if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 2
-  if (false) {
+    if (false) {
 #else
-  if (ballot(inpass && nelig != 0u) != 0) {
+    if (ballot(inpass && nelig != 0u) != 0) {
 #endif
-    // the cells to draw for, compacted in list order (the q-th one takes double q of the stream)
-    uint16_t* L = lds.q.L[sub];
-    {
-      u32 rk = (incl & 0xffffu) - cnt;  // list rank of this lane's first eligible cell
+      // the cells to draw for, compacted in list order (the q-th one takes double q of the stream)
+      uint16_t* L = C.L->q.L[sub];
+      {
+        u32 rk = (incl & 0xffffu) - cnt;  // list rank of this lane's first eligible cell
 #pragma unroll
-      for (u32 r = 0; r < kCellsPerLane; ++r) {
-        if (inpass && el[r]) L[rk] = (uint16_t)APAD[r];
-        rk += el[r] ? 1u : 0u;
-      }
-    }
-    wave_sync();
-    const u64 th0 = T.apple_thresh[0], th1 = T.apple_thresh[1], th2 = T.apple_thresh[2], th3 = T.apple_thresh[3];
-    const u32* tw = lds.q.tw;
-    u32 nsp = 0, na = 0, nb = 0;
-    // sixteen draws of every row at a time, in list order: a later chunk sees the apples of the earlier ones as 0x42 marks
-    for (u32 c = 0; ballot(inpass && 16u * c < nelig) != 0; ++c) {
-      const u32 q = 16u * c + sl;
-      const bool act = inpass && q < nelig;
-      u32 wa = c == 0 ? wa0 : c == 1 ? wa1 : na, wb = c == 0 ? wb0 : c == 1 ? wb1 : nb;
-      if (ballot(inpass && 16u * (c + 1u) < nelig && c >= 1u) != 0) {  // the words of the next chunk (the first two came with the loads)
-        const u32 i = min(pos + 2u * q + 32u, (u32)kMtN - 2u);
-        na = GAT(p.rng, wbase + i);
-        nb = GAT(p.rng, wbase + i + 1u);
-      }
-      if (tw_pending != 0) {  // the twisting row: words below 624 from the current key, the rest from the twisted one
-        const u32 w = pos + 2u * q;
-        if (c <= c_tw) {
-          if (istw && w < (u32)kMtN) wa = tw[w];
-          if (istw && w + 1u < (u32)kMtN) wb = tw[w + 1u];
+        for (u32 r = 0; r < kCellsPerLane; ++r) {
+          if (inpass && el[r]) L[rk] = (uint16_t)padv[r];
+          rk += el[r] ? 1u : 0u;
         }
-        if (c == c_tw) {
-          wave_sync();
-          mt_twist(lds.q.tw, lane);
-          wave_sync();
-          const auto key4 = (CE_GPTR(uint4))(p.rng + (size_t)(e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
-          const uint4* tw4 = (const uint4*)lds.q.tw;
-          const uint4 r0 = tw4[lane], r1 = tw4[lane + 64u], r2 = tw4[q2];
-          key4[lane] = r0;
-          key4[lane + 64u] = r1;
-          key4[q2] = r2;
-        }
-        if (c >= c_tw) {
-          if (istw && w >= (u32)kMtN && w < 2u * (u32)kMtN) wa = tw[w - (u32)kMtN];
-          if (istw && w + 1u >= (u32)kMtN && w + 1u < 2u * (u32)kMtN) wb = tw[w + 1u - (u32)kMtN];
-        }
-      }
-      const i32 cell = (i32)L[act ? q : 0u];  // idle lanes alias entry 0: a valid interior cell, never written by them
-      const u64 X = (((u64)(mt_temper(wa) >> 5)) << 26) | (u64)(mt_temper(wb) >> 6);
-      bool sp = false;
-      // the neighbour count of a cell includes apples spawned EARLIER in this very pass (harvest_features.py:139-151): iterate the
-      // parallel decision from "none spawned" upwards, as feat_spawn does
-      for (;;) {
-        u32 num = 0;
-#pragma unroll
-        for (int j = -1; j <= 1; ++j)
-#pragma unroll
-          for (int k = -1; k <= 1; ++k) {
-            const bool earlier = j < 0 || (j == 0 && k < 0);
-            const uint8_t x = pm[cell + j * G::PW + k];
-            num += (x == CE_CELL_APPLE || (earlier && x == 0x42)) ? 1u : 0u;
-          }
-        const bool z = act && X < (num == 0 ? th0 : num == 1 ? th1 : num == 2 ? th2 : th3);
-        const bool changed = z != sp;
-        sp = z;
-        if (ballot(changed) == 0) break;
-        wave_sync();
-        pm_put(pm, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
-        wave_sync();
-      }
-      const u32 sb = row_bits(ballot(sp), sub);
-      if (ballot(sp) != 0) {  // the list of this pass's apples grows over the entries already consumed (rank <= q)
-        wave_sync();
-        if (sp) L[nsp + popc32(sb & below)] = (uint16_t)cell;
-        wave_sync();
-      }
-      nsp += popc32(sb);
-    }
-    if (ballot(nsp != 0u) != 0) {  // appended in list order: stamps continue the list; the owners of the cells take theirs
-      for (u32 k = 0; ballot(k < nsp) != 0; ++k) {
-        const bool on = k < nsp;
-        const u32 cellk = L[on ? k : 0u];
-        if (on && sl == 0u) pm[cellk] = CE_CELL_APPLE;
-        const u32 stamp8 = (next_a + k) << 8;
-#pragma unroll
-        for (u32 r = 0; r < kCellsPerLane; ++r) AS8[r] = on && APAD[r] == cellk ? stamp8 : AS8[r];
       }
       wave_sync();
-      next_a += nsp;
-      napples += nsp;
-      dirty = dirty || nsp != 0u;
+      const u64 th0 = T.apple_thresh[0], th1 = T.apple_thresh[1], th2 = T.apple_thresh[2], th3 = T.apple_thresh[3];
+      const u32* tw = C.L->q.tw;
+      u32 nsp = 0, na = 0, nb = 0;
+      // sixteen draws of every row at a time, in list order: a later chunk sees the apples of the earlier ones as 0x42 marks
+      for (u32 c = 0; ballot(inpass && 16u * c < nelig) != 0; ++c) {
+        const u32 q = 16u * c + sl;
+        const bool act = inpass && q < nelig;
+        u32 wa = c == 0 ? W.wa0 : c == 1 ? W.wa1 : na, wb = c == 0 ? W.wb0 : c == 1 ? W.wb1 : nb;
+        if (ballot(inpass && 16u * (c + 1u) < nelig && c >= 1u) != 0) {  // the words of the next chunk (the first two came with the window)
+          const u32 i = min(R.pos + 2u * q + 32u, (u32)kMtN - 2u);
+          na = GAT(p.rng, wbase + i);
+          nb = GAT(p.rng, wbase + i + 1u);
+        }
+        if (tw_pending != 0) {  // the twisting row: words below 624 from the current key, the rest from the twisted one
+          const u32 w = R.pos + 2u * q;
+          if (c <= c_tw) {
+            if (istw && w < (u32)kMtN) wa = tw[w];
+            if (istw && w + 1u < (u32)kMtN) wb = tw[w + 1u];
+          }
+          if (c == c_tw) {
+            wave_sync();
+            mt_twist_inline(C.L->q.tw, lane);
+            wave_sync();
+            const auto key4 = (CE_GPTR(uint4))(p.rng + (size_t)(C.e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+            const uint4* tw4 = (const uint4*)C.L->q.tw;
+            const uint4 r0 = tw4[lane], r1 = tw4[lane + 64u], r2 = tw4[q2];
+            key4[lane] = r0;
+            key4[lane + 64u] = r1;
+            key4[q2] = r2;
+          }
+          if (c >= c_tw) {
+            if (istw && w >= (u32)kMtN && w < 2u * (u32)kMtN) wa = tw[w - (u32)kMtN];
+            if (istw && w + 1u >= (u32)kMtN && w + 1u < 2u * (u32)kMtN) wb = tw[w + 1u - (u32)kMtN];
+          }
+        }
+        const u32 cell_q = L[act ? q : 0u];
+        const i32 cell = (i32)(act ? cell_q : kDump + (u32)G::PW + 1u);  // idle lanes look at a border cell and write nothing
+        const u64 X = (((u64)(mt_temper(wa) >> 5)) << 26) | (u64)(mt_temper(wb) >> 6);
+        bool sp = false;
+        // the neighbour count of a cell includes apples spawned EARLIER in this very pass (harvest_features.py:139-151): iterate
+        // the parallel decision from "none spawned" upwards, as feat_spawn does
+        for (;;) {
+          u32 num = 0;
+#pragma unroll
+          for (int j = -1; j <= 1; ++j)
+#pragma unroll
+            for (int k = -1; k <= 1; ++k) {
+              const bool earlier = j < 0 || (j == 0 && k < 0);
+              const uint8_t x = pm[cell + j * G::PW + k];
+              num += (x == CE_CELL_APPLE || (earlier && x == 0x42)) ? 1u : 0u;
+            }
+          const bool z = act && X < (num == 0 ? th0 : num == 1 ? th1 : num == 2 ? th2 : th3);
+          const bool changed = z != sp;
+          sp = z;
+          if (ballot(changed) == 0) break;
+          wave_sync();
+          put(pm, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
+          wave_sync();
+        }
+        const u32 sb = row_bits(ballot(sp), sub);
+        if (ballot(sp) != 0) {  // the list of this pass's apples grows over the entries already consumed (rank <= q)
+          wave_sync();
+          if (sp) L[nsp + popc32(sb & below)] = (uint16_t)cell;
+          wave_sync();
+        }
+        nsp += popc32(sb);
+      }
+      if (ballot(nsp != 0u) != 0) {  // appended in list order: stamps continue the list; the owners of the cells take theirs
+        for (u32 k = 0; ballot(k < nsp) != 0; ++k) {
+          const bool on = k < nsp;
+          const u32 cellk = on ? (u32)L[k] : 0xffffu;
+          put(pm, on && sl == 0u, cellk, CE_CELL_APPLE);
+          const u32 stamp8 = (R.next_a + k) << 8;
+#pragma unroll
+          for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = on && (u32)C.pad[r] == cellk ? stamp8 : R.AS8[r];
+        }
+        wave_sync();
+        R.next_a += nsp;
+        napples += nsp;
+        R.dirty = R.dirty || nsp != 0u;
+      }
+      R.pos += inpass ? 2u * nelig : 0u;
+      R.pos -= R.pos > (u32)kMtN ? (u32)kMtN : 0u;  // (the twist above)
     }
-    pos += inpass ? 2u * nelig : 0u;
-    pos -= pos > (u32)kMtN ? (u32)kMtN : 0u;  // (the twist above)
-  }
-  tw_pending &= tw_pending - 1;
-  if (tw_pending == 0) break;
+    tw_pending &= tw_pending - 1;
+    if (tw_pending == 0) break;
   }
 
   CE_QSTAMP(6);
@@ -4037,13 +4147,13 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
 #pragma unroll
 #else
 #pragma unroll
-  for (u32 r = 0; r < 1; ++r) best0 = best1 = AS8[r];
+  for (u32 r = 0; r < 1; ++r) best0 = best1 = R.AS8[r];
   if (false)
 #endif
   for (u32 r = 0; r < kCellsPerLane; ++r) {
-    const u32 pen = AS8[r] == kAbs8 ? 128u : 0u;  // absent cells sort behind every present one (distances stay below 64)
-    const u32 kk = AS8[r] | (kCellsPerLane * sl + r);
-    const u32 k0 = __builtin_amdgcn_sad_u8(ARC[r], prc0, pen) << 24 | kk, k1 = __builtin_amdgcn_sad_u8(ARC[r], prc1, pen) << 24 | kk;
+    const u32 pen = R.AS8[r] == kAbs8 ? 128u : 0u;  // absent cells sort behind every present one (distances stay below 64)
+    const u32 kk = R.AS8[r] | (kCellsPerLane * sl + r);
+    const u32 k0 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc0, pen) << 24 | kk, k1 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc1, pen) << 24 | kk;
     best0 = k0 < best0 ? k0 : best0;
     best1 = k1 < best1 ? k1 : best1;
   }
@@ -4051,15 +4161,14 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
   best1 = row_min_all(best1);
   const u32 mine = sl == 0u ? best0 : best1;  // lane a of a row writes agent a's vector
   u32 ca = 0;
-  if ((mine >> 24) < 128u) ca = cell_rc(T.apple[mine & 0xffu]);
-  const u32 cn0 = close_count(pm, T, P0, sl, sub), cn1 = close_count(pm, T, P1, sl, sub);
+  if ((mine >> 24) < 128u) ca = C.L->q.cell_rc[mine & 0xffu];
+  const u32 cn0 = close_count(pm, C.co0, C.co1, P0, sl, sub), cn1 = close_count(pm, C.co0, C.co1, P1, sl, sub);
 
   CE_QSTAMP(7);
   // ---- rewards, infos, transfers (two_stage_train.py:62-121), metrics ----
-  const u32 t = t_old + 1u;
   const bool me0 = sl == 0u, agent = sl < 2u;
   const u32 rew = me0 ? eat0 : eat1, ecl = me0 ? ecl0 : ecl1, cn = me0 ? cn0 : cn1;
-  const bool out = simple && agent;
+  const bool outl = simple && agent;
   double rw = (double)rew;
   const u32 nmi = CE_MI_COUNT(2), nmf = CE_MF_COUNT(2);
   const auto mi = p.int_metrics;
@@ -4071,21 +4180,21 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
     // the wait for the read (bitwise the same sums, integer and double alike)
     if (touched && sl < 4u) {  // lane k < 4 of the row holds global metric k
       const u32 add = sl == CE_MI_TOTAL_APPLES_EATEN || sl == CE_MI_RAW_ENV_REWARDS ? eat0 + eat1 : sl == CE_MI_LOW_DENSITY_APPLES ? ecl0 + ecl1 : 0u;
-      if (add) quad::add_i64(&GAT(mi, mib + sl), (long long)add);
+      if (add) add_i64(&GAT(mi, mib + sl), (long long)add);
     }
     if (touched && agent && rew) {
-      quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_A, sl)), (long long)rew);
-      if (ecl) quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_B, sl)), (long long)ecl);
-      quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_R, sl)), (long long)rew);
-      if (t_old) quad::add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_TR, sl)), (long long)t_old * (long long)rew);
+      add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_A, sl)), (long long)rew);
+      if (ecl) add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_B, sl)), (long long)ecl);
+      add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_R, sl)), (long long)rew);
+      if (t_old) add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_TR, sl)), (long long)t_old * (long long)rew);
     }
   }
   if (p.contract != CE_CONTRACT_NONE) {
     double tr0, tr1;
     if (p.contract == CE_CONTRACT_CLEANUP) tr0 = tr1 = 0.0;  // HarvestFeatures cleans nothing
     else {
-      tr0 = (cn0 < 4u && ecl0 > 0u) ? theta : 0.0;
-      tr1 = (cn1 < 4u && ecl1 > 0u) ? theta : 0.0;
+      tr0 = (cn0 < 4u && ecl0 > 0u) ? R.theta : 0.0;
+      tr1 = (cn1 < 4u && ecl1 > 0u) ? R.theta : 0.0;
     }
     // agents with a zero transfer are skipped, in agent order (n = 2: the other agent's share is the whole transfer)
     double total = 0.0;
@@ -4097,59 +4206,129 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
       rw = me0 ? rw + tr1 : rw - tr1;
       total += tr1;
     }
-    if (simple && total != 0.0 && sl == 0u) quad::add_f64(&GAT(mf, mfb + CE_MF_TRANSFERS), total);
+    if (simple && total != 0.0 && sl == 0u) add_f64(&GAT(mf, mfb + CE_MF_TRANSFERS), total);
     const bool any_rew = row_bits(ballot(agent && rw != 0.0), sub) != 0u;
-    if (out && any_rew) {
-      quad::add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_R, sl)), rw);
-      quad::add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_TR, sl)), (double)t_old * rw);
+    if (outl && any_rew) {
+      add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_R, sl)), rw);
+      add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_TR, sl)), (double)t_old * rw);
     }
   }
   CE_QSTAMP(8);
-  // ---- stores (rows that took the packed step) ----
-  if (out) {
-    GAT(p.base_reward, 2u * e + sl) = (i32)rew;
-    GAT(p.reward, 2u * e + sl) = rw;
-    GAT((CE_GPTR(uint16_t))p.info, 2u * e + sl) = (uint16_t)(rew | ecl << 8);  // info[a][0..1] as one short
-    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const u32 Pm = me0 ? P0 : P1, Om = me0 ? O0 : O1, Pc = me0 ? P1 : P0, Oc = me0 ? O1 : O0;  // compute_closest_pos: a0 -> a1, a1 -> a0
-    const u32x4 head = {row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 16, Om | row_of<CE_KIND_HARVEST>(Pc) << 16,
-                        col_of<CE_KIND_HARVEST>(Pc) | Oc << 16, (ca >> 8) | (ca & 0xffu) << 16};
-    const auto f32 = (CE_GPTR(u32))p.features;
+  // ---- the step's outputs (rows that took the packed step) ----
+  if (outl) {
+    GAT(out.base_reward(), 2u * e + sl) = (i32)rew;
+    GAT(out.reward(), 2u * e + sl) = rw;
+    GAT((CE_GPTR(uint16_t))out.info(), 2u * e + sl) = (uint16_t)(rew | ecl << 8);  // info[a][0..1] as one short
+    const u32 Pm = me0 ? P0 : P1, Om = me0 ? R.O0 : R.O1, Pc = me0 ? P1 : P0, Oc = me0 ? R.O1 : R.O0;  // compute_closest_pos: a0 -> a1, a1 -> a0
+    const auto f32 = (CE_GPTR(u32))out.features();
     const u32 fb = (2u * e + sl) * 7u;  // 14 int16 per agent
-    GAT(f32, fb) = head.x;
-    GAT(f32, fb + 1u) = head.y;
-    GAT(f32, fb + 2u) = head.z;
-    GAT(f32, fb + 3u) = head.w;
+    GAT(f32, fb) = row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 16;
+    GAT(f32, fb + 1u) = Om | row_of<CE_KIND_HARVEST>(Pc) << 16;
+    GAT(f32, fb + 2u) = col_of<CE_KIND_HARVEST>(Pc) | Oc << 16;
+    GAT(f32, fb + 3u) = (ca >> 8) | (ca & 0xffu) << 16;
     GAT(f32, fb + 4u) = cn | napples << 16;
     GAT(f32, fb + 5u) = 0u;
     GAT(f32, fb + 6u) = 0u;
-    GAT((CE_GPTR(u32))p.agents, 2u * e + sl) = row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 8 | Om << 16;
   }
-  if (simple && sl == 0u) {
-    GAT(p.done, e) = 0;
-    GAT(p.timestep, e) = (i32)t;
-    GAT(p.rng, wbase + (u32)kMtN) = pos;
-    if (dirty) GAT(st32, stw + (CE_FEAT_APPLE_SLOTS + CE_FEAT_WASTE_SLOTS) / 2u) = next_a;
+  if (simple && sl == 0u) GAT(out.done(), e) = 0;
+  R.t += simple ? 1u : 0u;
+  return simple;
+}
+// the rows in `rest` (bit 16 r = row r), one env at a time on the whole wave through the one-env code: HBM state in, HBM state out
+template <class OUT> DEVINL void one_env_rows(const Ctx& C, const OUT& out, const uint8_t* __restrict__ actions, u64 rest) {
+  wave_sync();
+  for (; rest; rest &= rest - 1) {
+    feat_step_one<CE_KIND_HARVEST, 2>(*C.pp, actions, &C.L->one, C.e_row0 + (ctz64(rest) >> 4), out);
+    wave_sync();
   }
-  if (simple && dirty) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) GAT(st32, stw + 5u * sl + (u32)k) = (AS8[2 * k] >> 8) | (AS8[2 * k + 1] << 8);
-  }
+}
+// (a real call: the one-env code inlined into the step loop of the rollout costs the loop a hundred spilled registers; as a
+// call it costs a save / restore of the caller's registers on the rare steps that take it)
+__device__ __noinline__ void rollout_rest(const GridParams* pp, QuadLds* L, const RolloutArgs* rap, u32 pl, const uint8_t* actions, u32 e_row0,
+                                          u64 rest) {
+  Ctx C{pp, L};
+  C.lane = lane_id();
+  C.e_row0 = e_row0;
+  one_env_rows(C, StepOutPlane{*rap, pl}, actions, rest);
+}
+__device__ __noinline__ void step_rest(const GridParams* pp, QuadLds* L, const uint8_t* actions, u32 e_row0, u64 rest) {
+  Ctx C{pp, L};
+  C.lane = lane_id();
+  C.e_row0 = e_row0;
+  one_env_rows(C, StepOutDirect{*pp}, actions, rest);
+}
+}  // namespace quad
+
+__global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __restrict__ pp, const uint8_t* __restrict__ call_actions, u32 env_first,
+                                                         u32 env_end) {
+  using namespace quad;
+  __shared__ QuadLds lds;
+  if (env_first + 4u * blockIdx.x >= env_end) return;
+  Ctx C{pp, &lds};
+  begin(C, env_first, env_end, blockIdx.x);
+  CE_QSTAMP(0);
+  const u32 act2 = (u32)GAT((CE_GPTR(const uint16_t))call_actions, C.e);
+  Row R;
+  Window W;
+  load_row(R, C);
+  fetch_window(W, R, C);
+  load_static(C);
+  CE_QSTAMP(1);
+  build_map(R, C);
+  const bool simple = step(R, C, StepOutDirect{*C.pp}, act2, W);
+  flush_row(R, C, simple);
   CE_QSTAMP(9);
-#undef CE_QVALID
-  // ---- the rows left over: one env at a time on the whole wave ----
-  u64 rest = ballot(live && !simple && sl == 0u);
+  u64 rest = ballot(C.live && !simple && C.sl == 0u);
 #if defined(CE_QUAD_ABLATE) && CE_QUAD_ABLATE >= 1
   rest = 0;
 #endif
-  if (rest != 0) {
-    wave_sync();
-    for (; rest; rest &= rest - 1) {
-      feat_step_one<CE_KIND_HARVEST, 2>(p, call_actions, &lds.one, e_row0 + (ctz64(rest) >> 4));
-      wave_sync();
-    }
-  }
+  if (rest != 0) step_rest(C.pp, C.L, call_actions, C.e_row0, rest);
   CE_QSTAMP(10);
+}
+
+// The fused rollout of the same packing: the rows' state stays in registers / LDS for the steps of a launch, the stream
+// window of step s + 1 is requested as soon as step s knows where the stream stands.  A step with a row that cannot take
+// the packed path (horizon, bad action id) parks every row's state in HBM, lets the one-env code take those rows and
+// loads everything back.
+__global__ __launch_bounds__(64, 4) void k_feat_rollout_quad(const GridParams* __restrict__ pp, const RolloutArgs ra_) {
+  using namespace quad;
+  static_assert(alignof(RolloutArgs) == 8, "RolloutArgs sits at kernarg offset 8");
+  const RolloutArgs* rap = (const RolloutArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  __shared__ QuadLds lds;
+  if (rap->env_first + 4u * blockIdx.x >= rap->env_end) return;
+  Ctx C{pp, &lds};
+  begin(C, rap->env_first, rap->env_end, blockIdx.x);
+  Row R;
+  Window W;
+  load_row(R, C);
+  load_static(C);
+  build_map(R, C);
+  u32 pl = rap->plane0;
+  const u32 num_steps = rap->num_steps;
+  u32 act2 = (u32)GAT((CE_GPTR(const uint16_t))rap->actions, C.e);
+  for (u32 s = 0; s < num_steps; ++s) {
+    const RolloutArgs& ra = opaque_block(rap);
+    C.pp = &opaque_block(pp);
+    rederive(C, ra.env_end);
+    const u32 sn = s + 1 < num_steps ? s + 1 : s;  // the next step's actions are in flight while this step runs
+    const auto plane = (CE_GPTR(const uint8_t))ra.actions + (size_t)s * ra.action_plane;
+    const u32 act2n = (u32)GAT((CE_GPTR(const uint16_t))((CE_GPTR(const uint8_t))ra.actions + (size_t)sn * ra.action_plane), C.e);
+    const StepOutPlane out{ra, pl};
+    fetch_window(W, R, C);
+    const bool simple = step(R, C, out, act2, W);
+    const u64 rest = ballot(C.live && !simple && C.sl == 0u);
+    if (rest != 0) {
+      flush_row(R, C, C.live);
+      __threadfence();
+      rollout_rest(C.pp, C.L, rap, pl, (const uint8_t*)plane, C.e_row0, rest);
+      __threadfence();
+      load_row(R, C);
+      build_map(R, C);
+    }
+    act2 = act2n;
+    pl = pl + 1 == ra.num_planes ? 0u : pl + 1;
+  }
+  flush_row(R, C, C.live);
 }
 
 // Fused multi-step rollout of the feature-vector envs (ce_rollout_fused): list stamps, agents and the CPython `random`
@@ -4677,7 +4856,9 @@ void launch_feat_rollout(int kind, u32 num_agents, const GridParams* dp, const R
 #define CE_FEAT_ROLLOUT_LAUNCH(K_, N_) \
   hipLaunchKernelGGL((k_feat_rollout<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra)
   if (kind == CE_KIND_HARVEST_FEATURES) {
-    if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 2);
+    if (num_agents == 2 && feat_quad_on())
+      hipLaunchKernelGGL(k_feat_rollout_quad, dim3((count + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, dp, ra);
+    else if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 2);
     else CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 0);
   } else {
     if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_CLEANUP, 2);

@@ -11,8 +11,11 @@ FIELDS = ["grid", "agents", "rng", "timestep", "theta", "base_reward", "reward",
           "f64_metrics", "final_int_metrics", "final_f64_metrics", "error_flags"]
 
 
-def _same(env, orc, E, tag):
-    for f in FIELDS:
+STATE = ["grid", "agents", "rng", "timestep", "theta", "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics", "error_flags"]
+
+
+def _same(env, orc, E, tag, fields=FIELDS):
+    for f in fields:
         x, y = env.download(f, raw=True) if f == "grid" else env.download(f), getattr(orc, f)
         if f == "rng":
             x, y = x.reshape(E, 2, 628)[:, :, :625], y.reshape(E, 2, 628)[:, :, :625]
@@ -76,5 +79,33 @@ def test_quad_step_slices_and_bad_actions():
         orc.step(a)
         _same(env, orc, E, "at step %d" % t)
         assert (env.download("error_flags")[bad] & 1).all()
+    env.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("E,contract,horizon,T,per", [(203, "harvest_local", 23, 120, 16), (65, None, 1000, 300, 0), (7, "harvest_local", 5, 50, 7)])
+def test_quad_fused_rollout_vs_oracle(E, contract, horizon, T, per):
+    """k_feat_rollout_quad: the packed rows resident across the steps of a launch (episode ends and bad action ids inside a
+    launch park the state in HBM for the one-env code and load it back) — every output plane and the final state"""
+    import torch
+    env, orc = _pair(E, contract=contract, horizon=horizon, auto_reset=True)
+    rs = np.random.RandomState(E * 7 + T)
+    a = rs.randint(0, 8, size=(T, E, 2)).astype(np.uint8)
+    bad = rs.rand(T, E) < 0.01
+    a[bad, 0] = 200
+    acts = torch.from_numpy(a).cuda()
+    traj = env.alloc_trajectory(T)
+    env.rollout_fused(acts.data_ptr(), T, per, traj)
+    env.synchronize()
+    host = {f: traj.tensors[f].cpu().numpy() for f in traj.tensors}
+    for t in range(T):
+        orc.step(a[t])
+        for f in ("features", "base_reward", "reward", "done", "info"):
+            want = getattr(orc, f)
+            took = ~bad[t]  # an env that refuses the step writes nothing into the plane
+            got, want = host[f][t].reshape(want.shape)[took], want[took]
+            ok = np.allclose(got, want, rtol=0, atol=1e-9) if want.dtype.kind == "f" else np.array_equal(got, want)
+            assert ok, "%s plane %d (envs %s)" % (f, t, np.nonzero(took)[0][(got != want).reshape(len(got), -1).any(axis=1)][:8])
+    _same(env, orc, E, "after the rollout", STATE)  # (the outputs went to the planes, not to the handle's per-step buffers)
     env.close()
     orc.close()
