@@ -451,12 +451,12 @@ def counter_rng(group, wl, a, device_index, big_E=262144):
             r = Runner(group, dict(wl, rng=mode), E, a.config_steps, min(a.warmup, 20), a.streams, device_index, fused_T)
             m = r.measure("per_step", min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
             cell = {"value": m["value"], "ms_per_step": m["ms_per_step"], "steps": m["steps"], "repeats": m["repeats"],
-                    "roofline_frac": r.roofline(m, KERNEL[wl["kind"]][0], "-")["frac"]}
+                    "roofline_frac": r.roofline(m, kernel_names(wl["kind"], wl["n"])[0], "-")["frac"]}
             if fused_T:
                 f = r.measure("fused", T=fused_T, min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
                 cell["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps": f["steps"],
                                  "steps_per_launch": f["steps_per_launch"],
-                                 "roofline_frac": r.roofline(f, KERNEL[wl["kind"]][1], "-")["frac"]}
+                                 "roofline_frac": r.roofline(f, kernel_names(wl["kind"], wl["n"])[1], "-")["frac"]}
             row[mode] = cell
             r.close()
         out[label] = row
@@ -543,6 +543,13 @@ KERNEL = {"cleanup": ("k_grid_step<cleanup>", "k_grid_rollout<cleanup>"), "harve
           "cleanup_features": ("k_feat_step<cleanup>", "k_feat_rollout<cleanup>")}
 
 
+def kernel_names(kind, n):
+    """(single-step, fused) kernel of a workload: HarvestFeatures with two agents runs the four-envs-per-wave pair"""
+    if kind == "harvest_features" and n == 2 and os.environ.get("CE_FEAT_QUAD", "1")[:1] != "0":
+        return ("k_feat_step_quad", "k_feat_rollout_quad")
+    return KERNEL[kind]
+
+
 def run_rank(a):
     import torch
     if not torch.cuda.is_available():
@@ -591,7 +598,7 @@ def run_rank(a):
              "ms_per_step_rank_max": head.get("ms_per_step_rank_max", head["ms_per_step"])}
     out = None
     if rank == 0:
-        kstep, kfused = KERNEL[wl["kind"]]
+        kstep, kfused = kernel_names(wl["kind"], wl["n"])
         sfx = "_counter" if wl.get("rng") == "counter" else ""
         roof = r.roofline(head, kstep, "per_step" + sfx) if wl["algo"] else None
         if roof is not None:
@@ -633,12 +640,12 @@ def run_rank(a):
                    "value": m["value"], "value_min": m["value_min"], "value_max": m["value_max"], "unit": "agent-steps/s",
                    "ms_per_step": m["ms_per_step"], "repeats": m["repeats"], "steps": m["steps"],
                    "timed_seconds": m["timed_seconds"], "preroll_steps": rr.preroll,
-                   "roofline": rr.roofline(m, KERNEL[w["kind"]][0], "per_step_" + key)}
+                   "roofline": rr.roofline(m, kernel_names(w["kind"], w["n"])[0], "per_step_" + key)}
             if w_fused:
                 f = rr.measure("fused", T=a.fused_steps, min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
                 row["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps_per_launch": f["steps_per_launch"],
                                 "steps": f["steps"], "repeats": f["repeats"], "launches_per_step": f["launches_per_step"],
-                                "roofline_frac": rr.roofline(f, KERNEL[w["kind"]][1], "fused_" + key)["frac"]}
+                                "roofline_frac": rr.roofline(f, kernel_names(w["kind"], w["n"])[1], "fused_" + key)["frac"]}
             rows.append(row)
             rr.close()
         if out is not None:

@@ -3776,7 +3776,7 @@ struct Row {
 struct Ctx {
   const GridParams* pp;  // (a pointer: a fused rollout re-reads the block through an opaque copy every step)
   QuadLds* L;
-  u32 lane, sl, sub, below, e_row0, e, q2;
+  u32 lane, sl, sub, below, e_row0, env_end, e, q2;
   bool live, lastl;  // lastl: lane 15 owns cells 150 .. 159, the last five are past the list end
   uint8_t* pm;       // the row's presence map, indexed by padded cell
   const uint16_t* pad;  // this lane's ten cells in the static list (LDS): padded index ...
@@ -3809,6 +3809,7 @@ DEVINL void rederive(Ctx& C, u32 env_end) {
   derive(C, env_end);
 }
 DEVINL void derive(Ctx& C, u32 env_end) {
+  C.env_end = env_end;
   C.sl = C.lane & 15u;
   C.sub = C.lane >> 4;
   C.below = (1u << C.sl) - 1u;
@@ -3840,9 +3841,13 @@ DEVINL void fetch_window(Window& W, const Row& R, const Ctx& C) {
   const u32 wbase = rng_base(C);
   W.tw_row = 0xffffffffu;
   W.pf0 = W.pf1 = W.pf2 = uint4{};
-  const u64 near_end = ballot(C.live && C.sl == 0u && R.pos + 48u > (u32)kMtN);
-  if (near_end != 0) {
-    W.tw_row = ctz64(near_end) >> 4;
+  // (the row furthest along its generation: the one most likely to cross its end in this step)
+  const u32 p0 = rdl(R.pos, 0), p1 = C.e_row0 + 1u < C.env_end ? rdl(R.pos, 16) : 0u, p2 = C.e_row0 + 2u < C.env_end ? rdl(R.pos, 32) : 0u,
+            p3 = C.e_row0 + 3u < C.env_end ? rdl(R.pos, 48) : 0u;
+  const u32 m01 = p1 > p0 ? p1 : p0, m23 = p3 > p2 ? p3 : p2;
+  const u32 far_row = m23 > m01 ? (p3 > p2 ? 3u : 2u) : (p1 > p0 ? 1u : 0u);
+  if ((m23 > m01 ? m23 : m01) + 48u > (u32)kMtN) {
+    W.tw_row = far_row;
     const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(C.e_row0 + W.tw_row) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
     W.pf0 = key4[C.lane];
     W.pf1 = key4[C.lane + 64u];
@@ -4087,21 +4092,29 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
         }
         const u32 cell_q = L[act ? q : 0u];
         const i32 cell = (i32)(act ? cell_q : kDump + (u32)G::PW + 1u);  // idle lanes look at a border cell and write nothing
-        const u64 X = (((u64)(mt_temper(wa) >> 5)) << 26) | (u64)(mt_temper(wb) >> 6);
+        // r < p on the 53-bit integer form of random.random(): the upper 27 bits (first word) decide unless they tie with the
+        // threshold's (once in 2^27 draws); only then is the second word tempered and compared
+        const u32 xa = mt_temper(wa) >> 5;
         bool sp = false;
         // the neighbour count of a cell includes apples spawned EARLIER in this very pass (harvest_features.py:139-151): iterate
-        // the parallel decision from "none spawned" upwards, as feat_spawn does
+        // the parallel decision from "none spawned" upwards, as feat_spawn does.  (The cell itself holds no apple: eight reads.)
         for (;;) {
           u32 num = 0;
 #pragma unroll
           for (int j = -1; j <= 1; ++j)
 #pragma unroll
             for (int k = -1; k <= 1; ++k) {
+              if (j == 0 && k == 0) continue;
               const bool earlier = j < 0 || (j == 0 && k < 0);
               const uint8_t x = pm[cell + j * G::PW + k];
               num += (x == CE_CELL_APPLE || (earlier && x == 0x42)) ? 1u : 0u;
             }
-          const bool z = act && X < (num == 0 ? th0 : num == 1 ? th1 : num == 2 ? th2 : th3);
+          const u32 thi = num == 0 ? (u32)(th0 >> 26) : num == 1 ? (u32)(th1 >> 26) : num == 2 ? (u32)(th2 >> 26) : (u32)(th3 >> 26);
+          bool z = act && xa < thi;
+          if (ballot(act && xa == thi) != 0) {
+            const u32 tlo = (u32)(num == 0 ? th0 : num == 1 ? th1 : num == 2 ? th2 : th3) & 0x3ffffffu;
+            z = act && (xa < thi || (xa == thi && (mt_temper(wb) >> 6) < tlo));
+          }
           const bool changed = z != sp;
           sp = z;
           if (ballot(changed) == 0) break;
@@ -4314,8 +4327,11 @@ __global__ __launch_bounds__(64, 4) void k_feat_rollout_quad(const GridParams* _
     const auto plane = (CE_GPTR(const uint8_t))ra.actions + (size_t)s * ra.action_plane;
     const u32 act2n = (u32)GAT((CE_GPTR(const uint16_t))((CE_GPTR(const uint8_t))ra.actions + (size_t)sn * ra.action_plane), C.e);
     const StepOutPlane out{ra, pl};
+    CE_QSTAMP(11);
     fetch_window(W, R, C);
+    CE_QSTAMP(12);
     const bool simple = step(R, C, out, act2, W);
+    CE_QSTAMP(13);
     const u64 rest = ballot(C.live && !simple && C.sl == 0u);
     if (rest != 0) {
       flush_row(R, C, C.live);
