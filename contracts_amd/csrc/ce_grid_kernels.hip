@@ -3698,7 +3698,9 @@ struct alignas(16) Lds {
   uint16_t L[4][CE_FEAT_APPLE_SLOTS];  // compacted cells to draw for (padded index), then the cells that got an apple
   u32 tw[kMtN];                   // one CPython generator at a time, for a row whose draws run over the generation end
   uint16_t cell_pad[CE_FEAT_APPLE_SLOTS], cell_rc[CE_FEAT_APPLE_SLOTS];  // the static list of apple cells: padded index, col | row << 8
+  uint8_t owner[kMapHi - kMapLo];  // padded cell -> its index in that list (0xff: not an apple cell): which lane and slot own a cell
 };
+static_assert(sizeof(Lds) <= 10240, "sixteen waves per CU");
 DEVINL void put(uint8_t* pm, bool on, u32 idx, u32 val) { pm[on ? idx : kDump] = (uint8_t)(on ? val : 0u); }
 
 template <int K> DEVINL u32 row_bcast(u32 v) { return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (K << 5)); }  // lane K of the row
@@ -3757,6 +3759,8 @@ DEVINL u32 close_count(const uint8_t* pm, i32 co0, i32 co1, u32 c, u32 sl, u32 s
     __builtin_amdgcn_sched_barrier(0);                                             \
     if (C.lane == 0 && C.pp->debug) C.pp->debug[(size_t)C.e_row0 * 16 + (k)] = t_;     \
   } while (0)
+#elif defined(CE_DIAGNOSTIC) && defined(CE_ISA_MARKERS)  // static-ISA reading aid (never run): a comment line at every phase boundary
+#define CE_QSTAMP(k) asm volatile("; ==== Q_PHASE " #k)
 #else
 #define CE_QSTAMP(k) ((void)0)
 #endif
@@ -3781,6 +3785,7 @@ struct Ctx {
   uint8_t* pm;       // the row's presence map, indexed by padded cell
   const uint16_t* pad;  // this lane's ten cells in the static list (LDS): padded index ...
   const uint16_t* rc;   // ... and col | row << 8
+  const uint8_t* own;   // owner table, indexed by padded cell
   i32 co0, co1;         // this lane's two offsets of the 21-cell neighbourhood (close_count)
 };
 // the stream words a step starts with: doubles sl and sl + 16 after the row's position (clamped inside the generation),
@@ -3820,10 +3825,16 @@ DEVINL void derive(Ctx& C, u32 env_end) {
   C.pm = C.L->q.pm[C.sub] - kMapLo;
   C.pad = C.L->q.cell_pad + kCellsPerLane * C.sl;
   C.rc = C.L->q.cell_rc + kCellsPerLane * C.sl;
+  C.own = C.L->q.owner - kMapLo;
 }
 // the static list of apple cells into LDS, once per wave (the slots past the list end aim at the dump byte and are never valid)
 DEVINL void load_static(const Ctx& C) {
   const GridTables& T = c_tab[CE_KIND_HARVEST];
+  constexpr u32 kOwnQuads = (kMapHi - kMapLo) / 16u;
+  uint4* o128 = (uint4*)C.L->q.owner;
+#pragma unroll
+  for (u32 k = 0; k < (kOwnQuads + 63u) / 64u; ++k) o128[min(C.lane + 64u * k, kOwnQuads - 1u)] = uint4{~0u, ~0u, ~0u, ~0u};
+  wave_sync();
 #pragma unroll
   for (u32 k = 0; k < (CE_FEAT_APPLE_SLOTS + 63u) / 64u; ++k) {
     const u32 idx = C.lane + 64u * k;
@@ -3832,7 +3843,14 @@ DEVINL void load_static(const Ctx& C) {
       C.L->q.cell_pad[idx] = (uint16_t)(idx < (u32)G::NAPPLE ? cell_pad(v) : kDump);
       C.L->q.cell_rc[idx] = (uint16_t)cell_rc(v);
     }
+    if (idx < (u32)G::NAPPLE) C.L->q.owner[cell_pad(v) - kMapLo] = (uint8_t)idx;
   }
+}
+// list stamp of the cell with list index `idx` (row-uniform; 0xff = none) := v, in the registers of the lane that owns it
+DEVINL void set_stamp(Row& R, const Ctx& C, u32 idx, u32 v) {
+  const u32 d = idx - kCellsPerLane * C.sl;  // this lane's slot, if below ten (anything else — 0xff included — wraps far above)
+#pragma unroll
+  for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = d == r ? v : R.AS8[r];
 }
 DEVINL u32 rng_base(const Ctx& C) { return C.e * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID; }
 DEVINL u32 state_base(const Ctx& C) { return C.e * (CE_FEAT_STATE_BYTES / 4u); }
@@ -3960,8 +3978,7 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       ecl_f = ef && close < 4u ? 1u : 0u;
       wave_sync();
       put(pm, ef && sl == 0u, pf, CE_CELL_EMPTY);
-#pragma unroll
-      for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = ef && (u32)C.pad[r] == pf ? kAbs8 : R.AS8[r];
+      set_stamp(R, C, ef ? (u32)C.own[pf] : 0xffu, kAbs8);
       R.dirty = R.dirty || ef;
       wave_sync();
     }
@@ -3972,8 +3989,7 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       ecl_s = es && close < 4u ? 1u : 0u;
       wave_sync();
       put(pm, es && sl == 0u, ps, CE_CELL_EMPTY);
-#pragma unroll
-      for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = es && (u32)C.pad[r] == ps ? kAbs8 : R.AS8[r];
+      set_stamp(R, C, es ? (u32)C.own[ps] : 0xffu, kAbs8);
       R.dirty = R.dirty || es;
       wave_sync();
     }
@@ -3992,18 +4008,15 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
     tw4[q2] = W.pf2;
   }
   // ---- spawn_apples: one random.random() per absent cell no agent stands on, in list order ----
-  bool el[kCellsPerLane];
-  u32 cnt = 0, nabs = 0;
-  u32 padv[kCellsPerLane];  // read in one batch: a read inside each of the conditional stores below would be waited for ten times
+  // per lane: bit r of absmask = this lane's cell r has no apple; the cells the agents stand on come from the owner table
+  u32 absmask = 0;
 #pragma unroll
-  for (u32 r = 0; r < kCellsPerLane; ++r) padv[r] = C.pad[r];
-#pragma unroll
-  for (u32 r = 0; r < kCellsPerLane; ++r) {
-    const bool ab = CE_QVALID(C, r) && R.AS8[r] == kAbs8;
-    el[r] = simple && ab && padv[r] != P0 && padv[r] != P1;
-    cnt += el[r] ? 1u : 0u;
-    nabs += ab ? 1u : 0u;
-  }
+  for (u32 r = 0; r < kCellsPerLane; ++r) absmask |= R.AS8[r] == kAbs8 ? 1u << r : 0u;
+  absmask &= C.lastl ? (1u << ((u32)G::NAPPLE - 150u)) - 1u : (1u << kCellsPerLane) - 1u;  // (lane 15: the slots past the list end)
+  const u32 s0 = (u32)C.own[P0] - kCellsPerLane * sl, s1 = (u32)C.own[P1] - kCellsPerLane * sl;
+  const u32 under = (s0 < kCellsPerLane ? 1u << s0 : 0u) | (s1 < kCellsPerLane ? 1u << s1 : 0u);
+  const u32 elmask = simple ? absmask & ~under : 0u;
+  const u32 cnt = popc32(elmask), nabs = popc32(absmask);
   const u32 incl = row_scan_incl(cnt | nabs << 16);  // both counts ride one scan
   const u32 tot = row_bcast<15>(incl);
   const u32 nelig = tot & 0xffffu;
@@ -4047,11 +4060,14 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       // the cells to draw for, compacted in list order (the q-th one takes double q of the stream)
       uint16_t* L = C.L->q.L[sub];
       {
-        u32 rk = (incl & 0xffffu) - cnt;  // list rank of this lane's first eligible cell
+        const u32 rk0 = (incl & 0xffffu) - cnt;  // list rank of this lane's first eligible cell
+        u32 padv[kCellsPerLane];
 #pragma unroll
-        for (u32 r = 0; r < kCellsPerLane; ++r) {
-          if (inpass && el[r]) L[rk] = (uint16_t)padv[r];
-          rk += el[r] ? 1u : 0u;
+        for (u32 r = 0; r < kCellsPerLane; ++r) padv[r] = C.pad[r];
+#pragma unroll
+        for (u32 r = 0; r < kCellsPerLane; ++r) {  // (entry 159 is past every rank: it takes the stores of the other cells)
+          const bool e = inpass && (elmask >> r & 1u) != 0u;
+          L[e ? rk0 + popc32(elmask & ((1u << r) - 1u)) : CE_FEAT_APPLE_SLOTS - 1u] = (uint16_t)padv[r];
         }
       }
       wave_sync();
@@ -4133,11 +4149,9 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       if (ballot(nsp != 0u) != 0) {  // appended in list order: stamps continue the list; the owners of the cells take theirs
         for (u32 k = 0; ballot(k < nsp) != 0; ++k) {
           const bool on = k < nsp;
-          const u32 cellk = on ? (u32)L[k] : 0xffffu;
+          const u32 cellk = on ? (u32)L[k] : kDump;
           put(pm, on && sl == 0u, cellk, CE_CELL_APPLE);
-          const u32 stamp8 = (R.next_a + k) << 8;
-#pragma unroll
-          for (u32 r = 0; r < kCellsPerLane; ++r) R.AS8[r] = on && (u32)C.pad[r] == cellk ? stamp8 : R.AS8[r];
+          set_stamp(R, C, on ? (u32)C.own[cellk] : 0xffu, (R.next_a + k) << 8);
         }
         wave_sync();
         R.next_a += nsp;
