@@ -3685,7 +3685,9 @@ template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step
 namespace quad {
 typedef Geo<CE_KIND_HARVEST> G;
 constexpr u32 kCellsPerLane = 10;
-constexpr u32 kAbs8 = kAbsent << 8;  // list stamps are kept shifted left by 8: (stamp << 8) | cell index is the tie-break key
+// list stamps are kept shifted left by 8: distance << 24 | stamp << 8 | cell index is the key of the closest-apple search.
+// "No apple" also carries bit 31, which puts such a cell behind every present one in that search whatever its distance.
+constexpr u32 kAbs8 = kAbsent << 8 | 0x80000000u;
 static_assert(16 * kCellsPerLane >= (u32)G::NAPPLE && 16 * kCellsPerLane == CE_FEAT_APPLE_SLOTS, "a row covers the list slots");
 
 // The presence maps keep only what a step can touch — padded rows 5 .. 24 (the playable rows plus two on either side), as the
@@ -3894,7 +3896,7 @@ DEVINL void load_row(Row& R, const Ctx& C) {
 #pragma unroll
   for (u32 r = 0; r < kCellsPerLane; ++r) {
     const u32 v = (r & 1u) ? (sd[r >> 1] >> 8) & 0xffff00u : (sd[r >> 1] << 8) & 0xffff00u;
-    R.AS8[r] = CE_QVALID(C, r) ? v : kAbs8;
+    R.AS8[r] = CE_QVALID(C, r) && v != kAbsent << 8 ? v : kAbs8;
   }
   R.P0 = pad_of<CE_KIND_HARVEST>(ag0 & 0xffu, (ag0 >> 8) & 0xffu);
   R.O0 = (ag0 >> 16) & 3u;
@@ -3936,7 +3938,7 @@ DEVINL void flush_row(Row& R, const Ctx& C, bool rows) {
   }
   if (rows && R.dirty) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) GAT(st32, stw + 5u * C.sl + (u32)k) = (R.AS8[2 * k] >> 8) | (R.AS8[2 * k + 1] << 8);
+    for (int k = 0; k < 5; ++k) GAT(st32, stw + 5u * C.sl + (u32)k) = ((R.AS8[2 * k] >> 8) & 0xffffu) | ((R.AS8[2 * k + 1] << 8) & 0xffff0000u);
   }
   R.dirty = R.dirty && !rows;
 }
@@ -4167,8 +4169,9 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
 
   CE_QSTAMP(6);
   // ---- feature vectors (the observation): closest apple = min over (manhattan distance, list stamp) ----
-  const u32 prc0 = col_of<CE_KIND_HARVEST>(P0) | row_of<CE_KIND_HARVEST>(P0) << 8;
-  const u32 prc1 = col_of<CE_KIND_HARVEST>(P1) | row_of<CE_KIND_HARVEST>(P1) << 8;
+  const u32 row0 = row_of<CE_KIND_HARVEST>(P0), row1 = row_of<CE_KIND_HARVEST>(P1);
+  const u32 col0 = P0 - __umul24(row0 + kView, (u32)G::PW) - kView, col1 = P1 - __umul24(row1 + kView, (u32)G::PW) - kView;
+  const u32 prc0 = col0 | row0 << 8, prc1 = col1 | row1 << 8;
   u32 best0 = 0xffffffffu, best1 = 0xffffffffu;
 #if !defined(CE_QUAD_ABLATE) || CE_QUAD_ABLATE < 3
 #pragma unroll
@@ -4178,9 +4181,8 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
   if (false)
 #endif
   for (u32 r = 0; r < kCellsPerLane; ++r) {
-    const u32 pen = R.AS8[r] == kAbs8 ? 128u : 0u;  // absent cells sort behind every present one (distances stay below 64)
-    const u32 kk = R.AS8[r] | (kCellsPerLane * sl + r);
-    const u32 k0 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc0, pen) << 24 | kk, k1 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc1, pen) << 24 | kk;
+    const u32 kk = R.AS8[r] | sl << 4 | r;  // (low byte: which lane, which of its cells)
+    const u32 k0 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc0, 0u) << 24 | kk, k1 = __builtin_amdgcn_sad_u8((u32)C.rc[r], prc1, 0u) << 24 | kk;
     best0 = k0 < best0 ? k0 : best0;
     best1 = k1 < best1 ? k1 : best1;
   }
@@ -4188,7 +4190,7 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
   best1 = row_min_all(best1);
   const u32 mine = sl == 0u ? best0 : best1;  // lane a of a row writes agent a's vector
   u32 ca = 0;
-  if ((mine >> 24) < 128u) ca = C.L->q.cell_rc[mine & 0xffu];
+  if ((mine >> 24) < 128u) ca = C.L->q.cell_rc[kCellsPerLane * ((mine >> 4) & 15u) + (mine & 15u)];
   const u32 cn0 = close_count(pm, C.co0, C.co1, P0, sl, sub), cn1 = close_count(pm, C.co0, C.co1, P1, sl, sub);
 
   CE_QSTAMP(7);
@@ -4215,29 +4217,30 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_R, sl)), (long long)rew);
       if (t_old) add_i64(&GAT(mi, mib + CE_MI_AGENT(2, CE_MIA_SUM_TR, sl)), (long long)t_old * (long long)rew);
     }
-  }
-  if (p.contract != CE_CONTRACT_NONE) {
-    double tr0, tr1;
-    if (p.contract == CE_CONTRACT_CLEANUP) tr0 = tr1 = 0.0;  // HarvestFeatures cleans nothing
-    else {
-      tr0 = (cn0 < 4u && ecl0 > 0u) ? R.theta : 0.0;
-      tr1 = (cn1 < 4u && ecl1 > 0u) ? R.theta : 0.0;
-    }
-    // agents with a zero transfer are skipped, in agent order (n = 2: the other agent's share is the whole transfer)
-    double total = 0.0;
-    if (tr0 != 0.0) {
-      rw = me0 ? rw - tr0 : rw + tr0;
-      total += tr0;
-    }
-    if (tr1 != 0.0) {
-      rw = me0 ? rw + tr1 : rw - tr1;
-      total += tr1;
-    }
-    if (simple && total != 0.0 && sl == 0u) add_f64(&GAT(mf, mfb + CE_MF_TRANSFERS), total);
-    const bool any_rew = row_bits(ballot(agent && rw != 0.0), sub) != 0u;
-    if (outl && any_rew) {
-      add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_R, sl)), rw);
-      add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_TR, sl)), (double)t_old * rw);
+    // (a transfer needs a close apple eaten, a non-zero reward an apple eaten: nothing of the wrapper's can change otherwise)
+    if (p.contract != CE_CONTRACT_NONE) {
+      double tr0, tr1;
+      if (p.contract == CE_CONTRACT_CLEANUP) tr0 = tr1 = 0.0;  // HarvestFeatures cleans nothing
+      else {
+        tr0 = (cn0 < 4u && ecl0 > 0u) ? R.theta : 0.0;
+        tr1 = (cn1 < 4u && ecl1 > 0u) ? R.theta : 0.0;
+      }
+      // agents with a zero transfer are skipped, in agent order (n = 2: the other agent's share is the whole transfer)
+      double total = 0.0;
+      if (tr0 != 0.0) {
+        rw = me0 ? rw - tr0 : rw + tr0;
+        total += tr0;
+      }
+      if (tr1 != 0.0) {
+        rw = me0 ? rw + tr1 : rw - tr1;
+        total += tr1;
+      }
+      if (simple && total != 0.0 && sl == 0u) add_f64(&GAT(mf, mfb + CE_MF_TRANSFERS), total);
+      const bool any_rew = row_bits(ballot(agent && rw != 0.0), sub) != 0u;
+      if (outl && any_rew) {
+        add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_R, sl)), rw);
+        add_f64(&GAT(mf, mfb + CE_MF_AGENT(2, CE_MFA_SUM_TR, sl)), (double)t_old * rw);
+      }
     }
   }
   CE_QSTAMP(8);
@@ -4246,15 +4249,15 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
     GAT(out.base_reward(), 2u * e + sl) = (i32)rew;
     GAT(out.reward(), 2u * e + sl) = rw;
     GAT((CE_GPTR(uint16_t))out.info(), 2u * e + sl) = (uint16_t)(rew | ecl << 8);  // info[a][0..1] as one short
-    const u32 Pm = me0 ? P0 : P1, Om = me0 ? R.O0 : R.O1, Pc = me0 ? P1 : P0, Oc = me0 ? R.O1 : R.O0;  // compute_closest_pos: a0 -> a1, a1 -> a0
+    // own position / orientation, then the other agent's (compute_closest_pos: a0 -> a1, a1 -> a0), the closest apple, counts
+    const u32 rowm = me0 ? row0 : row1, colm = me0 ? col0 : col1, Om = me0 ? R.O0 : R.O1;
+    const u32 rowc = me0 ? row1 : row0, colc = me0 ? col1 : col0, Oc = me0 ? R.O1 : R.O0;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
     const auto f32 = (CE_GPTR(u32))out.features();
-    const u32 fb = (2u * e + sl) * 7u;  // 14 int16 per agent
-    GAT(f32, fb) = row_of<CE_KIND_HARVEST>(Pm) | col_of<CE_KIND_HARVEST>(Pm) << 16;
-    GAT(f32, fb + 1u) = Om | row_of<CE_KIND_HARVEST>(Pc) << 16;
-    GAT(f32, fb + 2u) = col_of<CE_KIND_HARVEST>(Pc) | Oc << 16;
-    GAT(f32, fb + 3u) = (ca >> 8) | (ca & 0xffu) << 16;
-    GAT(f32, fb + 4u) = cn | napples << 16;
-    GAT(f32, fb + 5u) = 0u;
+    const u32 fb = (2u * e + sl) * 7u;  // 14 int16 per agent: 28-byte rows, dword aligned
+    *(CE_GPTR(u32x4))&GAT(f32, fb) = u32x4{rowm | colm << 16, Om | rowc << 16, colc | Oc << 16, (ca >> 8) | (ca & 0xffu) << 16};
+    *(CE_GPTR(u32x2))&GAT(f32, fb + 4u) = u32x2{cn | napples << 16, 0u};
     GAT(f32, fb + 6u) = 0u;
   }
   if (simple && sl == 0u) GAT(out.done(), e) = 0;
