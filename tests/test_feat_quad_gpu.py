@@ -109,3 +109,37 @@ def test_quad_fused_rollout_vs_oracle(E, contract, horizon, T, per):
     _same(env, orc, E, "after the rollout", STATE)  # (the outputs went to the planes, not to the handle's per-step buffers)
     env.close()
     orc.close()
+
+
+def test_one_env_kernels_with_the_packing_switched_off():
+    """CE_FEAT_QUAD=0 (read once per process) routes HarvestFeatures n = 2 back through k_feat_step<harvest, 2> /
+    k_feat_rollout<harvest, 2> — the kernels the packed ones fall back to row by row, and the A/B baseline: a child process
+    steps and rolls out against the oracle with the switch off"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "tests")
+from test_feat_quad_gpu import _pair, _same, STATE
+E, T = 70, 90
+env, orc = _pair(E, contract="harvest_local", horizon=29, auto_reset=True)
+rs = np.random.RandomState(4)
+for t in range(T):
+    a = rs.randint(0, 8, size=(E, 2)).astype(np.uint8)
+    env.step(a)
+    orc.step(a)
+    _same(env, orc, E, "at step %d" % t)
+a = rs.randint(0, 8, size=(40, E, 2)).astype(np.uint8)
+env.rollout_fused(torch.from_numpy(a).cuda().data_ptr(), 40)
+for t in range(40):
+    orc.step(a[t])
+_same(env, orc, E, "after the rollout")
+print("one-env kernels ok")
+'''
+    env = dict(os.environ, CE_FEAT_QUAD="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "one-env kernels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
