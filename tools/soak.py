@@ -1,7 +1,8 @@
 """Randomised soak: engine vs CPU oracle over random configurations (family, n, flags, horizon, policy mix),
 every persistent and output field compared after every step — or, for half of the configurations, after every fused
-multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed] [counter]
-(`counter`: the grid kinds run in the counter-RNG mode, engine and oracle alike)"""
+multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed] [counter|quad]
+(`counter`: the grid kinds run in the counter-RNG mode, engine and oracle alike; `quad`: HarvestFeatures with two agents only —
+the four-envs-per-wave kernels — with batch sizes off multiples of four, longer runs and walk-heavy policies)"""
 import sys
 import time
 import numpy as np
@@ -12,20 +13,23 @@ from oracle.pyoracle import Oracle
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 COUNTER = len(sys.argv) > 3 and sys.argv[3] == "counter"
+QUAD = len(sys.argv) > 3 and sys.argv[3] == "quad"
 FIELDS = ["grid", "agents", "spawn_perm", "rng", "timestep", "theta", "obs", "base_reward", "reward", "done", "info", "features",
           "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics"]
 t_end = time.time() + budget
 runs = steps_total = 0
 while time.time() < t_end:
     kind = rs.choice(["cleanup", "harvest"] if COUNTER else ["cleanup", "harvest", "cleanup", "harvest", "cleanup_features", "harvest_features"])
+    if QUAD:
+        kind = "harvest_features"
     feat = kind.endswith("_features")
-    n = int(rs.randint(2 if feat else 1, 10))
+    n = 2 if QUAD else int(rs.randint(2 if feat else 1, 10))
     firing = bool(rs.randint(2)) and not feat
     contract = None if rs.rand() < 0.3 else ("cleanup" if kind.startswith("cleanup") else "harvest_local")
     inequity = n > 1 and rs.rand() < 0.15 and not feat
     collective = (not inequity) and rs.rand() < 0.15 and not feat
     horizon = int(rs.choice([7, 23, 60, 1000]))
-    E = int(rs.choice([65, 128, 300]))
+    E = int(rs.choice([1, 3, 66, 131, 517, 1024]) if QUAD else rs.choice([65, 128, 300]))
     kw = dict(contract=contract, firing=firing, horizon=horizon, auto_reset=True, collective=collective, inequity=inequity,
               alpha=float(rs.rand() * 5), beta=float(rs.rand()))
     if COUNTER:
@@ -52,7 +56,9 @@ while time.time() < t_end:
     fields = FIELDS + (["waste_perm"] if kind == "cleanup" else []) + (["beam_map"] if trace else [])
     if feat:
         fields = [f for f in FIELDS if f not in ("spawn_perm", "obs")]
-    T = int(rs.choice([40, 120]))
+    T = int(rs.choice([120, 400, 1100]) if QUAD else rs.choice([40, 120]))
+    if QUAD and rs.rand() < 0.5:  # mostly walking: more apples eaten, longer draw lists, more generation ends
+        p = rs.dirichlet(np.array([4.0, 4.0, 4.0, 4.0, 0.5, 0.5, 0.5, 0.5][:na]))
     ok = True
     fused = rs.rand() < 0.5
     t = 0
