@@ -143,3 +143,76 @@ print("one-env kernels ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "one-env kernels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _untemper(y):
+    """inverse of MT19937's output tempering"""
+    y ^= y >> 18
+    y ^= (y << 15) & 0xefc60000
+    t = y
+    for _ in range(5):
+        t = y ^ ((t << 7) & 0x9d2c5680)
+    y = t & 0xffffffff
+    t = y
+    for _ in range(3):
+        t = y ^ (t >> 11)
+    return t & 0xffffffff
+
+
+def test_quad_threshold_ties_take_the_second_word():
+    """The packed kernels decide `random.random() < p` on the upper 27 bits of the 53-bit integer form and look at the second
+    stream word only when those tie with the threshold's (once in 2^27 draws: never in a random test).  Here the CPython
+    generator rows of engine and oracle are rewritten before every step so that the coming doubles sit exactly on, just below
+    and just above the four thresholds of SPAWN_PROB (harvest_new.py:34)."""
+    import math
+    assert _untemper(0x12345678) != 0x12345678
+    E, T = 96, 40
+    env, orc = _pair(E, contract="harvest_local", horizon=1000, auto_reset=True)
+    rs = np.random.RandomState(21)
+    thr = [int(math.ceil(math.ldexp(p, 53))) for p in (0.0, 0.005, 0.02, 0.05)]
+    walk = [.2, .2, .2, .2, .05, .05, .05, .05]
+    for t in range(30):  # some apples eaten first, so that there are cells to draw for
+        a = rs.choice(8, size=(E, 2), p=walk).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+    for t in range(T):
+        rng = env.download("rng").reshape(E, 2, 628).copy()
+        for e in range(E):
+            pos = int(rng[e, 1, 624])
+            for q in range((624 - pos) // 2):  # every double left in this generation
+                th = thr[rs.randint(1, 4)] if rs.rand() < 0.8 else thr[0]
+                x = max(0, min((1 << 53) - 1, th + int(rs.choice([-(1 << 26), -1, 0, 1, 1 << 26, 0, -1]))))
+                if rs.rand() < 0.3:
+                    x = (th >> 26 << 26) | int(rs.randint(0, 1 << 26))  # same upper half, any lower half
+                a_t = ((x >> 26) << 5) | int(rs.randint(0, 32))
+                b_t = ((x & ((1 << 26) - 1)) << 6) | int(rs.randint(0, 64))
+                rng[e, 1, pos + 2 * q] = _untemper(a_t)
+                rng[e, 1, pos + 2 * q + 1] = _untemper(b_t)
+        env.upload("rng", rng.reshape(E, -1))
+        orc.rng.reshape(E, 2, 628)[...] = rng
+        orc.import_state()
+        a = rs.choice(8, size=(E, 2), p=walk).astype(np.uint8)
+        env.step(a)
+        orc.step(a)
+        _same(env, orc, E, "at crafted step %d" % t)
+    # ... and the same through the fused kernel: one crafted window per launch
+    import torch
+    for t in range(6):
+        rng = env.download("rng").reshape(E, 2, 628).copy()
+        for e in range(E):
+            pos = int(rng[e, 1, 624])
+            for q in range((624 - pos) // 2):
+                th = thr[rs.randint(1, 4)]
+                x = (th >> 26 << 26) | int(rs.randint(0, 1 << 26)) if rs.rand() < 0.5 else th + int(rs.choice([-1, 0, 1]))
+                rng[e, 1, pos + 2 * q] = _untemper(((x >> 26) << 5) | int(rs.randint(0, 32)))
+                rng[e, 1, pos + 2 * q + 1] = _untemper(((x & ((1 << 26) - 1)) << 6) | int(rs.randint(0, 64)))
+        env.upload("rng", rng.reshape(E, -1))
+        orc.rng.reshape(E, 2, 628)[...] = rng
+        orc.import_state()
+        a = rs.choice(8, size=(5, E, 2), p=walk).astype(np.uint8)
+        env.rollout_fused(torch.from_numpy(a).cuda().data_ptr(), 5)
+        for k in range(5):
+            orc.step(a[k])
+        _same(env, orc, E, "after crafted launch %d" % t)
+    env.close()
+    orc.close()
