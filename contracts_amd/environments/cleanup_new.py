@@ -50,7 +50,8 @@ class CleanupEnv(GridEnvAdapter):
         return self._cells(b"H")
 
     def compute_current_wastes(self):
-        """see compute_current_apples"""
+        """the reference rebuilds its `current_waste_points` attribute here (cleanup_new.py:387-394); the property above reads
+        the engine's map whenever it is asked, so there is nothing to refresh — kept so that callers of the method still work"""
 
     def compute_permitted_area(self):
         return self.POTENTIAL_WASTE_AREA - int((self.world_map == b"H").sum())
