@@ -4861,20 +4861,25 @@ void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error
   } while (0)
 void launch_feat_construct(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_construct); }
 void launch_feat_reset(int kind, const GridParams& p, const GridParams* dp, void* stream) { CE_LAUNCH_FEAT(k_feat_reset); }
-// CE_FEAT_QUAD=0 keeps the one-env-per-wave kernel for HarvestFeatures n = 2 (A/B runs, tests that compare the two)
-static bool feat_quad_on() {
-  static const bool on = [] {
+// Smallest launch (envs) of HarvestFeatures n = 2 that runs four envs per wave.  Below ~2 000 envs a launch is a handful of waves
+// per CU either way and lasts as long as ONE wave's chain, which is shorter with one env per wave (measured, three slices:
+// 1 365 envs per launch 9.5 vs 9.9 us per step, 2 048 equal, 2 730 and up the packed kernels win: 5 461 per launch 11.6 vs
+// 14.4 us, fused 7.4 vs 12.5).  CE_FEAT_QUAD_MIN_ENVS=N moves the threshold, CE_FEAT_QUAD=0 switches the packing off (A/B runs).
+static u32 feat_quad_min() {
+  static const u32 n = [] {
     const char* v = getenv("CE_FEAT_QUAD");
-    return !(v && v[0] == '0');
+    if (v && v[0] == '0') return 0xffffffffu;
+    const char* m = getenv("CE_FEAT_QUAD_MIN_ENVS");
+    return m ? (u32)strtoul(m, nullptr, 10) : 2048u;
   }();
-  return on;
+  return n;
 }
 void launch_feat_step(int kind, const GridParams& p, const GridParams* dp, void* stream) {
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
 #define CE_FEAT_STEP_LAUNCH(K_, N_) \
   hipLaunchKernelGGL((k_feat_step<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, p.actions, p.mask, first, first + count)
   if (kind == CE_KIND_HARVEST_FEATURES) {
-    if (p.n == 2 && feat_quad_on())
+    if (p.n == 2 && count >= feat_quad_min())
       hipLaunchKernelGGL(k_feat_step_quad, dim3((count + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, dp, p.actions, first, first + count);
     else if (p.n == 2) CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 2);
     else CE_FEAT_STEP_LAUNCH(CE_KIND_HARVEST, 0);
@@ -4889,7 +4894,7 @@ void launch_feat_rollout(int kind, u32 num_agents, const GridParams* dp, const R
 #define CE_FEAT_ROLLOUT_LAUNCH(K_, N_) \
   hipLaunchKernelGGL((k_feat_rollout<K_, N_>), dim3(count), dim3(64), 0, (hipStream_t)stream, dp, ra)
   if (kind == CE_KIND_HARVEST_FEATURES) {
-    if (num_agents == 2 && feat_quad_on())
+    if (num_agents == 2 && count >= feat_quad_min())
       hipLaunchKernelGGL(k_feat_rollout_quad, dim3((count + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, dp, ra);
     else if (num_agents == 2) CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 2);
     else CE_FEAT_ROLLOUT_LAUNCH(CE_KIND_HARVEST, 0);

@@ -145,6 +145,40 @@ print("one-env kernels ok")
     assert out.returncode == 0 and "one-env kernels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_default_threshold_mixes_both_kernel_families():
+    """without CE_FEAT_QUAD_MIN_ENVS a launch of fewer than 2 048 envs takes the one-env kernels and a larger one the packed
+    ones: a child process steps one batch through slices on either side of the threshold, then as a whole, against the oracle"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "tests")
+from test_feat_quad_gpu import _pair, _same
+E, T = 2600, 25
+env, orc = _pair(E, contract="harvest_local", horizon=11, auto_reset=True)
+rs = np.random.RandomState(8)
+for t in range(T):
+    a = rs.randint(0, 8, size=(E, 2)).astype(np.uint8)
+    if t % 2:
+        dev = torch.from_numpy(a).cuda()
+        for lo, hi in ((0, 301), (301, 2600)):  # 301 envs: one per wave; 2 299: four per wave
+            env.step_range_device(dev.data_ptr(), lo, hi - lo)
+        torch.cuda.synchronize()
+    else:
+        env.step(a)  # 2 600 envs in one launch: four per wave
+    orc.step(a)
+    _same(env, orc, E, "at step %d" % t)
+print("both families ok")
+'''
+    env = {k: v for k, v in os.environ.items() if k not in ("CE_FEAT_QUAD_MIN_ENVS", "CE_FEAT_QUAD")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "both families ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def _untemper(y):
     """inverse of MT19937's output tempering"""
     y ^= y >> 18

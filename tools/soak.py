@@ -3,10 +3,13 @@ every persistent and output field compared after every step — or, for half of 
 multi-step launch (ce_rollout_fused, chunks of 1..9 steps).  Usage: python tools/soak.py [seconds] [seed] [counter|quad]
 (`counter`: the grid kinds run in the counter-RNG mode, engine and oracle alike; `quad`: HarvestFeatures with two agents only —
 the four-envs-per-wave kernels — with batch sizes off multiples of four, longer runs and walk-heavy policies)"""
+import os
 import sys
 import time
 import numpy as np
 sys.path.insert(0, ".")
+if len(sys.argv) > 3 and sys.argv[3] == "quad":  # the packed kernels at every batch size (the library reads this once)
+    os.environ.setdefault("CE_FEAT_QUAD_MIN_ENVS", "1")
 from contracts_amd.engine import BatchedEnv
 from oracle.pyoracle import Oracle
 
