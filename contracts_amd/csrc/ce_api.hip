@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -987,12 +988,16 @@ class HostPool {
     {
       std::unique_lock<std::mutex> lk(m_);
       while (started_ < T - 1) {
-        std::thread(&HostPool::worker, this, started_).detach();
+        try {
+          std::thread(&HostPool::worker, this, started_).detach();
+        } catch (const std::system_error&) {  // no more threads to be had: the job runs on the ones that exist (+ the caller)
+          break;
+        }
         ++started_;
       }
       fn_ = &fn, total_ = total, grain_ = grain;
       next_.store(0, std::memory_order_relaxed);
-      helpers_ = left_ = T - 1;
+      helpers_ = left_ = std::min(T - 1, started_);
       ++gen_;
     }
     wake_.notify_all();
