@@ -148,6 +148,9 @@ def main():
     S0 = 73907
     jobs = {
         "feat_harvest_n2": dict(kind="harvest_features", n=2, seed=S0 + 40, T=[1000, 80]),          # BASELINE config 0
+        # walk-heavy, no contract: agents eat far more than they turn, so the per-step draw lists grow past 16 and 32 cells
+        "feat_harvest_n2_walk": dict(kind="harvest_features", n=2, seed=S0 + 47, T=[600, 50], horizon=600, contract=False,
+                                     action_p=[.24, .24, .24, .24, .01, .015, .015]),
         "feat_harvest_n5": dict(kind="harvest_features", n=5, seed=S0 + 41, T=[200, 60], horizon=200),
         "feat_harvest_n8_nocontract": dict(kind="harvest_features", n=8, seed=S0 + 42, T=[150, 40], horizon=150, contract=False),
         "feat_cleanup_n2": dict(kind="cleanup_features", n=2, seed=S0 + 43, T=[1000, 80],
