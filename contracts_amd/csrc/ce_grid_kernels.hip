@@ -3675,7 +3675,7 @@ template <int GK, int NFIX> __global__ __launch_bounds__(64, 8) void k_feat_step
 // the row's lanes, counts and ranks come from row scans / the row's 16 bits of a ballot, broadcasts from ds_swizzle.
 // Draws that run over the end of the CPython generator's 624 words (one step in ~30 per env) get the twist from the whole
 // wave: the row's key words pass through LDS, the row takes its words from both generations, the new key goes back to HBM.
-// The draws are taken sixteen per row at a time, in list order, however many there are.
+// The draws of the four rows share the wave's 64 lanes, row after row in list order, in as many rounds as it takes.
 // A step that is not the common case otherwise — a bad action id, the horizon (metrics of the episode + reset), a second row
 // of the same wave crossing the generation end in the same step — is left untouched by the packed pass and taken afterwards
 // by the whole wave through the one-env code above, env by env (a launch lasts as long as its slowest wave: this has to
@@ -3948,13 +3948,12 @@ DEVINL void flush_row(Row& R, const Ctx& C, bool rows) {
 template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 act2, Window& W) {
   const GridParams& p = *C.pp;
   const GridTables& T = c_tab[CE_KIND_HARVEST];
-  const u32 lane = C.lane, sl = C.sl, sub = C.sub, below = C.below, e = C.e, q2 = C.q2;
+  const u32 lane = C.lane, sl = C.sl, sub = C.sub, e = C.e, q2 = C.q2;
   uint8_t* pm = C.pm;
   // a bad action id, or the horizon (episode metrics + reset): not taken here
   const bool simple = C.live && (act2 & 0xffu) <= 7u && (act2 >> 8) <= 7u && R.t + 1u != p.horizon;
   const u32 ACT0 = simple ? act2 & 0xffu : 4u, ACT1 = simple ? act2 >> 8 : 4u;  // (a row that sits the step out: two agents that stay)
   const u32 t_old = R.t;
-  const u32 wbase = rng_base(C);
 
   CE_QSTAMP(2);
   // ---- move_squares in dict order: stayers first, then the movers by key; a mover is refused by a wall or a claimed square ----
@@ -4037,7 +4036,6 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
     const u32 tws = tw_pending ? ctz64(tw_pending) >> 4 : 0xffffffffu;
     const bool istw = over && sub == tws;
     const bool inpass = first_pass ? simple && (!over || istw) : istw;
-    u32 c_tw = 0xffffffffu;  // the chunk of 16 draws in which the twisting row passes word 624
     if (tw_pending != 0) {
       if (tws != W.tw_row) {  // (not the row whose key was parked in LDS ahead of time)
         const auto key4 = (CE_GPTR(const uint4))(p.rng + (size_t)(C.e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
@@ -4049,8 +4047,6 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
         tw4[q2] = r2;
       }
       W.tw_row = 0xffffffffu;  // the block holds a twisted key after this pass
-      const u32 pos_tw = rdl(R.pos, tws << 4);
-      c_tw = pos_tw >= 593u ? 0u : (593u - pos_tw + 31u) >> 5;  // smallest c with pos + 32 c + 31 >= 624
       wave_sync();
     }
     CE_QSTAMP(5);
@@ -4075,40 +4071,61 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
       wave_sync();
       const u64 th0 = T.apple_thresh[0], th1 = T.apple_thresh[1], th2 = T.apple_thresh[2], th3 = T.apple_thresh[3];
       const u32* tw = C.L->q.tw;
-      u32 nsp = 0, na = 0, nb = 0;
-      // sixteen draws of every row at a time, in list order: a later chunk sees the apples of the earlier ones as 0x42 marks
-      for (u32 c = 0; ballot(inpass && 16u * c < nelig) != 0; ++c) {
-        const u32 q = 16u * c + sl;
-        const bool act = inpass && q < nelig;
-        u32 wa = c == 0 ? W.wa0 : c == 1 ? W.wa1 : na, wb = c == 0 ? W.wb0 : c == 1 ? W.wb1 : nb;
-        if (ballot(inpass && 16u * (c + 1u) < nelig && c >= 1u) != 0) {  // the words of the next chunk (the first two came with the window)
-          const u32 i = min(R.pos + 2u * q + 32u, (u32)kMtN - 2u);
-          na = GAT(p.rng, wbase + i);
-          nb = GAT(p.rng, wbase + i + 1u);
+      // The draws of the four rows are dealt to the wave's 64 lanes together, row after row: slot = (draws of the rows before)
+      // + q.  Four rows of 12-18 draws are one round of 64 slots where a round per row of 16 lanes would be two.
+      const u32 ne = inpass ? nelig : 0u;
+      const u32 n0 = rdl(ne, 0), n1 = rdl(ne, 16), n2 = rdl(ne, 32), n3 = rdl(ne, 48);
+      const u32 b1 = n0, b2 = b1 + n1, b3 = b2 + n2, total = b3 + n3;
+      const u32 pos0 = rdl(R.pos, 0), pos1 = rdl(R.pos, 16), pos2 = rdl(R.pos, 32), pos3 = rdl(R.pos, 48);
+      const u32 pos_tw = tws == 0u ? pos0 : tws == 1u ? pos1 : tws == 2u ? pos2 : pos3;
+      u32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // apples of this pass so far, per row
+      bool twisted = false;
+      const u64 lt = (1ull << lane) - 1ull;
+      for (u32 c = 0; 64u * c < total; ++c) {
+        const u32 slot = 64u * c + lane;
+        const bool act = slot < total;
+        const u32 rho = (slot >= b1 ? 1u : 0u) + (slot >= b2 ? 1u : 0u) + (slot >= b3 ? 1u : 0u);  // the row this slot draws for
+        const u32 q = slot - (rho == 0u ? 0u : rho == 1u ? b1 : rho == 2u ? b2 : b3);            // ... and which of its draws
+        // the two words of double q of that row's stream: from the lane of the row that holds them (the window: q < 32) ...
+        const u32 holder = rho << 4 | (q & 15u);
+        const u32 la = bperm(W.wa0, holder), lb = bperm(W.wb0, holder), ha = bperm(W.wa1, holder), hb = bperm(W.wb1, holder);
+        u32 wa = (q & 16u) ? ha : la, wb = (q & 16u) ? hb : lb;
+        const u32 posr = rho == 0u ? pos0 : rho == 1u ? pos1 : rho == 2u ? pos2 : pos3;
+        if (ballot(act && q >= 32u) != 0) {  // ... or, past the window, from the row's key in HBM
+          const u32 i = min(posr + 2u * q, (u32)kMtN - 2u);
+          const u32 kb = (C.e_row0 + rho) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID;
+          if (act && q >= 32u) {
+            wa = GAT(p.rng, kb + i);
+            wb = GAT(p.rng, kb + i + 1u);
+          }
         }
         if (tw_pending != 0) {  // the twisting row: words below 624 from the current key, the rest from the twisted one
-          const u32 w = R.pos + 2u * q;
-          if (c <= c_tw) {
-            if (istw && w < (u32)kMtN) wa = tw[w];
-            if (istw && w + 1u < (u32)kMtN) wb = tw[w + 1u];
+          const bool mine = act && rho == tws;
+          const u32 w = pos_tw + 2u * q;
+          if (!twisted) {
+            if (mine && w < (u32)kMtN) wa = tw[w];
+            if (mine && w + 1u < (u32)kMtN) wb = tw[w + 1u];
+            if (ballot(mine && w + 1u >= (u32)kMtN) != 0) {  // this round passes word 624
+              wave_sync();
+              mt_twist_inline(C.L->q.tw, lane);
+              wave_sync();
+              const auto key4 = (CE_GPTR(uint4))(p.rng + (size_t)(C.e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
+              const uint4* tw4 = (const uint4*)C.L->q.tw;
+              const uint4 r0 = tw4[lane], r1 = tw4[lane + 64u], r2 = tw4[q2];
+              key4[lane] = r0;
+              key4[lane + 64u] = r1;
+              key4[q2] = r2;
+              twisted = true;
+            }
           }
-          if (c == c_tw) {
-            wave_sync();
-            mt_twist_inline(C.L->q.tw, lane);
-            wave_sync();
-            const auto key4 = (CE_GPTR(uint4))(p.rng + (size_t)(C.e_row0 + tws) * CE_RNG_WORDS_SELFDRIVE + CE_RNG_WORDS_GRID);
-            const uint4* tw4 = (const uint4*)C.L->q.tw;
-            const uint4 r0 = tw4[lane], r1 = tw4[lane + 64u], r2 = tw4[q2];
-            key4[lane] = r0;
-            key4[lane + 64u] = r1;
-            key4[q2] = r2;
-          }
-          if (c >= c_tw) {
-            if (istw && w >= (u32)kMtN && w < 2u * (u32)kMtN) wa = tw[w - (u32)kMtN];
-            if (istw && w + 1u >= (u32)kMtN && w + 1u < 2u * (u32)kMtN) wb = tw[w + 1u - (u32)kMtN];
+          if (twisted) {
+            if (mine && w >= (u32)kMtN && w < 2u * (u32)kMtN) wa = tw[w - (u32)kMtN];
+            if (mine && w + 1u >= (u32)kMtN && w + 1u < 2u * (u32)kMtN) wb = tw[w + 1u - (u32)kMtN];
           }
         }
-        const u32 cell_q = L[act ? q : 0u];
+        uint16_t* Lr = C.L->q.L[0] + rho * CE_FEAT_APPLE_SLOTS;
+        uint8_t* pmr = C.L->q.pm[0] + rho * (kMapHi - kMapLo) - kMapLo;
+        const u32 cell_q = Lr[act ? q : 0u];
         const i32 cell = (i32)(act ? cell_q : kDump + (u32)G::PW + 1u);  // idle lanes look at a border cell and write nothing
         // r < p on the 53-bit integer form of random.random(): the upper 27 bits (first word) decide unless they tie with the
         // threshold's (once in 2^27 draws); only then is the second word tempered and compared
@@ -4124,7 +4141,7 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
             for (int k = -1; k <= 1; ++k) {
               if (j == 0 && k == 0) continue;
               const bool earlier = j < 0 || (j == 0 && k < 0);
-              const uint8_t x = pm[cell + j * G::PW + k];
+              const uint8_t x = pmr[cell + j * G::PW + k];
               num += (x == CE_CELL_APPLE || (earlier && x == 0x42)) ? 1u : 0u;
             }
           const u32 thi = num == 0 ? (u32)(th0 >> 26) : num == 1 ? (u32)(th1 >> 26) : num == 2 ? (u32)(th2 >> 26) : (u32)(th3 >> 26);
@@ -4137,17 +4154,24 @@ template <class OUT> DEVINL bool step(Row& R, const Ctx& C, const OUT& out, u32 
           sp = z;
           if (ballot(changed) == 0) break;
           wave_sync();
-          put(pm, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
+          put(pmr, act, (u32)cell, sp ? 0x42u : (u32)CE_CELL_EMPTY);  // 0x42 = spawned in this pass
           wave_sync();
         }
-        const u32 sb = row_bits(ballot(sp), sub);
-        if (ballot(sp) != 0) {  // the list of this pass's apples grows over the entries already consumed (rank <= q)
+        const u64 sb = ballot(sp);
+        if (sb != 0) {  // each row's list of this pass's apples grows over the entries already consumed (rank <= q)
+          const u64 m0 = ballot(act && rho == 0u), m1 = ballot(act && rho == 1u), m2 = ballot(act && rho == 2u), m3 = ballot(act && rho == 3u);
+          const u64 mine_row = rho == 0u ? m0 : rho == 1u ? m1 : rho == 2u ? m2 : m3;
+          const u32 before = rho == 0u ? s0 : rho == 1u ? s1 : rho == 2u ? s2 : s3;
           wave_sync();
-          if (sp) L[nsp + popc32(sb & below)] = (uint16_t)cell;
+          if (sp) Lr[before + popc64(sb & mine_row & lt)] = (uint16_t)cell;
           wave_sync();
+          s0 += popc64(sb & m0);
+          s1 += popc64(sb & m1);
+          s2 += popc64(sb & m2);
+          s3 += popc64(sb & m3);
         }
-        nsp += popc32(sb);
       }
+      const u32 nsp = sub == 0u ? s0 : sub == 1u ? s1 : sub == 2u ? s2 : s3;
       if (ballot(nsp != 0u) != 0) {  // appended in list order: stamps continue the list; the owners of the cells take theirs
         for (u32 k = 0; ballot(k < nsp) != 0; ++k) {
           const bool on = k < nsp;
