@@ -512,13 +512,20 @@ def boundary(wl, E, device_index):
 
     for t in range(3):  # the first two ticks build the two dictionary generations
         dict_tick(t)
-    t0, steps = time.perf_counter(), 0
+    t0, steps, ticks = time.perf_counter(), 0, []
     while time.perf_counter() - t0 < 1.0 or steps < 4:
+        ta = time.perf_counter()
         dict_tick(steps + 3)
+        ticks.append(time.perf_counter() - ta)
         steps += 1
     dt = time.perf_counter() - t0
+    ticks.sort()
+    # `value` is the mean over the sample; this leg is host work (sixteen to thirty-two threads beside other tenants of the box), so
+    # the spread of the single ticks is carried too
     out["dict_protocol"] = {"value": E * n * steps / dt, "unit": "agent-steps/s", "env_steps_per_s": E * steps / dt,
                             "ms_per_step": dt / steps * 1e3, "steps": steps, "host_threads": venv._host_threads(),
+                            "ms_per_tick_min": ticks[0] * 1e3, "ms_per_tick_median": ticks[len(ticks) // 2] * 1e3,
+                            "ms_per_tick_max": ticks[-1] * 1e3,
                             "ms_building_action_dicts_not_timed": ms_build, "last_tick_ms": dict(venv.tick_timing),
                             "what": "send_actions(pre-built {env: {agent: action}}) + poll with every env's obs (float64 image views) / "
                                     "reward / done / info dictionaries in hand and walked; recycled dictionary trees over page-locked "
