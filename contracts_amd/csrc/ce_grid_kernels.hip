@@ -4325,10 +4325,10 @@ __global__ __launch_bounds__(64, 4) void k_feat_step_quad(const GridParams* __re
   Row R;
   Window W;
   load_row(R, C);
-  fetch_window(W, R, C);
-  load_static(C);
+  load_static(C);  // (the table and map loads below do not wait for the stream position the window does)
   CE_QSTAMP(1);
   build_map(R, C);
+  fetch_window(W, R, C);
   const bool simple = step(R, C, StepOutDirect{*C.pp}, act2, W);
   flush_row(R, C, simple);
   CE_QSTAMP(9);
