@@ -130,6 +130,7 @@ def cpu_baseline(wl, target_s, single_thread_s=4.0):
     indices 0.., seeds SEED0 + b), the same counter-hash actions (contracts_amd.synth mirrors the device generator), the
     same horizon / auto-reset, from t = 0; all threads (the reported value) and, when single_thread_s > 0, one thread."""
     import ctypes
+    import numpy as np
     from contracts_amd import synth
     from oracle.pyoracle import Oracle
     kind, n, contract = wl["kind"], wl["n"], wl["contract"]
@@ -138,7 +139,7 @@ def cpu_baseline(wl, target_s, single_thread_s=4.0):
     na = {"cleanup": 8, "harvest": 7, "harvest_features": 7, "cleanup_features": 8}.get(kind)
     CH = 32
 
-    def run(nthreads, E, seconds):
+    def run(nthreads, E, seconds, keep_state=False):
         gomp.omp_set_num_threads(nthreads)
         orc = Oracle(kind, E, n, contract=contract, horizon=1000, auto_reset=True)
         orc.seed(seed0=SEED0)
@@ -154,22 +155,102 @@ def cpu_baseline(wl, target_s, single_thread_s=4.0):
                 orc.step(acts[t])
             spent += time.perf_counter() - t0
             steps += CH
+        state = None
+        if keep_state:  # what parity_in_run() holds the engine to: every persistent field and the last step's outputs
+            state = {f: np.array(getattr(orc, f)) for f in PARITY_FIELDS[kind]}
         orc.close()
-        return E * n * steps / spent, steps, spent
+        return E * n * steps / spent, steps, spent, state
 
-    v_all, steps, dt = run(threads, 256 * threads, target_s)
+    E_all = min(256 * threads, wl["E"])
+    v_all, steps, dt, state = run(threads, E_all, target_s, keep_state=True)
     out = {"value": v_all, "unit": "agent-steps/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+           "_oracle_state": {"envs": E_all, "steps": steps, "fields": state},  # consumed (and removed) by parity_in_run()
            "sample": "envs 0..%d of the same batch (seeds %d + b, the same counter-hash actions, horizon 1000, auto-reset), "
                      "steps 0..%d, %s n=%d + contract, OpenMP over envs on %d threads, %.1f s of stepping"
-                     % (256 * threads - 1, SEED0, steps - 1, kind, n, threads, dt)}
+                     % (E_all - 1, SEED0, steps - 1, kind, n, threads, dt)}
     if single_thread_s > 0:
-        v_one, steps1, dt1 = run(1, 256, min(single_thread_s, target_s))
+        v_one, steps1, dt1, _ = run(1, 256, min(single_thread_s, target_s))
         out["single_thread_value"] = v_one
         out["sample"] += " (+ envs 0..255 x %d steps on 1 thread, %.1f s)" % (steps1, dt1)
     ref = PYTHON_REFERENCE_PER_CORE.get((kind, n))
     if ref is not None:
         out["python_reference_per_core"] = ref  # the reference itself (1 process), measured by the survey
     return out
+
+
+_GRID_FIELDS = ("grid", "agents", "spawn_perm", "rng", "timestep", "theta", "obs", "base_reward", "reward", "done", "info", "features",
+                "int_metrics", "f64_metrics", "final_int_metrics", "final_f64_metrics")
+_FEAT_FIELDS = tuple(f for f in _GRID_FIELDS if f not in ("spawn_perm", "obs"))
+PARITY_FIELDS = {"cleanup": _GRID_FIELDS + ("waste_perm",), "harvest": _GRID_FIELDS, "harvest_features": _FEAT_FIELDS,
+                 "cleanup_features": _FEAT_FIELDS,
+                 "selfdrive": ("sd_state", "rng", "theta", "obs_f64", "base_reward", "reward", "done", "done_agents", "info", "sd_info",
+                               "f64_metrics")}
+
+
+def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
+    """The bench line checks its own kernels: a second engine handle steps the SAME envs the cpu_baseline
+    leg just stepped on the oracle (global indices 0.., seeds SEED0 + b, the same counter-hash actions, horizon 1000 with
+    in-launch auto-reset, from t = 0) to the same step count — the first part as per-step launches, the rest as fused rollouts,
+    i.e. through both kernels the row times — and every persistent field plus the last step's outputs is compared with the
+    oracle's: bit-exact for integers / bytes / stream state, <= 1e-9 for the float64 rewards and metrics.  Outside every timed
+    span; the oracle is the checker here, never the thing measured."""
+    import hashlib
+    import numpy as np
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    kind, n = wl["kind"], wl["n"]
+    E, K, ref = oracle_state["envs"], oracle_state["steps"], oracle_state["fields"]
+    # same launch shapes as the timed row where the sample is the row's whole batch; a smaller sample runs as one slice so that
+    # its launches stay above the size thresholds that pick the row's kernel instances
+    S = max(1, min(streams, E)) if E == wl["E"] else 1
+    env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
+                     env_index_base=0, rng=wl.get("rng", "mt19937"))
+    try:
+        env.seed(seed0=SEED0)
+        env.reset()
+        sts = [torch.cuda.Stream() for _ in range(S)] if S > 1 else None
+        handles = [st.cuda_stream for st in sts] if sts else None
+        do_fused = bool(fused_T) and kind in FUSED_KINDS
+        k_fused = (K // 2) // fused_T * fused_T if do_fused else 0
+        k_step = K - k_fused
+        dt = torch.float32 if kind == "selfdrive" else torch.uint8
+        CH = 512
+        buf = torch.empty((CH, E, n), dtype=dt, device="cuda")
+        t = 0
+        while t < K:
+            fused = t >= k_step
+            c = min(CH, (K if fused else k_step) - t)
+            if fused:
+                c = c // fused_T * fused_T or c
+            env.synth_actions(SEED0 + 1, t, c, buf.data_ptr())
+            env.synchronize()
+            if fused:
+                env.rollout_fused(buf.data_ptr(), c, fused_T, None, handles)
+            else:
+                env.rollout_device(buf.data_ptr(), c, handles)
+            torch.cuda.synchronize()
+            t += c
+        env.check_faults()
+        bad, digest = {}, hashlib.sha256()
+        for f, y in ref.items():
+            x = env.download(f, raw=True) if kind in ("harvest_features", "cleanup_features") and f == "grid" else env.download(f)
+            if f == "rng" and wl.get("rng", "mt19937") == "mt19937":  # key[624] + position of each MT19937 block (pad words are free)
+                x, y = x.reshape(E, -1, 628)[:, :, :625], y.reshape(E, -1, 628)[:, :, :625]
+            digest.update(np.ascontiguousarray(x).tobytes())
+            same = (np.allclose(x, y, rtol=0, atol=1e-9, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y))
+            if not same:
+                rows = np.nonzero((np.asarray(x) != np.asarray(y)).reshape(E, -1).any(axis=1))[0]
+                bad[f] = {"envs_differing": int(rows.size), "first": [int(r) for r in rows[:4]]}
+        out = {"ok": not bad, "envs": E, "steps": K, "per_step_steps": k_step, "fused_steps": k_fused, "slices": S,
+               "episode_ends_crossed": K // 1000 if kind != "selfdrive" else "at each env's own pace",
+               "fields": list(ref), "engine_sha256_16": digest.hexdigest()[:16],
+               "checker": "oracle/oracle.c (the cpu_baseline leg's final state: same envs, seeds, actions, step count)",
+               "tolerance": "bit-exact (integers, bytes, generator state); float64 rewards / metrics <= 1e-9"}
+        if bad:
+            out["mismatches"] = bad
+        return out
+    finally:
+        env.close()
 
 
 def stream_ceiling():
@@ -296,16 +377,21 @@ class Runner:
         achieved = algo * E / (ms * 1e-3) / 1e9
         envs_per_launch = E / float(self.S)
         steps_per_launch = res.get("steps_per_launch", 1)
-        traffic = None
+        traffic = ratio = source = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             row = tj.get(traffic_key)
             if row and row.get("kind") == self.wl["kind"] and row.get("agents") == self.wl["n"]:
                 traffic = int(round(row["hbm_bytes_per_env_step"] * envs_per_launch * steps_per_launch))
+                ratio = round(row["hbm_bytes_per_env_step"] / float(algo), 3)  # PMC bytes over algorithmic bytes
+                prov = tj.get("_provenance", {})
+                # NOT measured in this run: a constant from the committed PMC passes, with where it came from
+                source = "profiles/traffic.json @ %s (kernel sources %s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % (
+                    prov.get("git_head", "unknown commit"), prov.get("kernels_sha16", "unrecorded"))
         except (OSError, ValueError):
             traffic = None
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": kernel,
+                "traffic": traffic, "traffic_ratio": ratio, "traffic_source": source, "kernel": kernel,
                 "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE (PMC): requests served by the 256 MB Infinity Cache count like HBM "
                         "accesses, and this batch largely lives there — an upper bound of the HBM bytes; counter_rng.large_batch "
                         "(262144 envs) is the beyond-cache figure",
@@ -375,6 +461,16 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
         torch.add(ahead[b0:b1], noise[b0:b1], out=noise[b0:b1])
         env.step_policy_device(noise.data_ptr(), "bytes", b0, b1 - b0, stream=st.cuda_stream)
 
+    def slice_tick_inkernel(st, b0, b1):
+        # CE_POLICY_AHEAD_NOISE: the same policy evaluated INSIDE the step kernel's action load (the noise byte moves on by the
+        # green channel of the pixel ahead in the previous view, action = byte mod |A|): ONE launch per slice and tick
+        env.step_policy_device(noise.data_ptr(), "ahead_noise", b0, b1 - b0, stream=st.cuda_stream)
+
+    handles = [st.cuda_stream for st in streams]
+
+    def sliced_tick_inkernel():  # all slices of a tick in ONE host call (the launch loop in C: ce_step_policy_sliced)
+        env.step_policy_sliced(noise.data_ptr(), "ahead_noise", handles)
+
     def eager_tick(tick_fn=slice_tick):
         for st, (b0, b1) in zip(streams, bounds):
             with torch.cuda.stream(st):
@@ -403,6 +499,35 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
     if only is None or "policy_eager" in only:
         modes["policy_eager"] = dict(timed(lambda: eager_tick(slice_tick_policy)), host_calls_per_step=2 * S,
                                      host_iterations_per_step=1, launches_per_slice_and_step=2)
+    if only is None or "inkernel_eager" in only:
+        modes["inkernel_eager"] = dict(timed(lambda: eager_tick(slice_tick_inkernel)), host_calls_per_step=S,
+                                       host_iterations_per_step=1, launches_per_slice_and_step=1)
+    if only is None or "inkernel_sliced" in only:
+        modes["inkernel_sliced"] = dict(timed(sliced_tick_inkernel), host_calls_per_step=1, host_iterations_per_step=1,
+                                        launches_per_slice_and_step=1)
+    # ONE graph over all slices (cross-stream fork / join inside the capture): one replay per tick whatever the slice count
+    for name, tick_fn, per_slice in (("policy_graph_all", slice_tick_policy, 2), ("inkernel_graph_all", slice_tick_inkernel, 1)):
+        if only is not None and name not in only:
+            continue
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=streams[0]):
+                for st in streams[1:]:
+                    st.wait_stream(streams[0])  # fork
+                for st, (b0, b1) in zip(streams, bounds):
+                    with torch.cuda.stream(st):
+                        tick_fn(st, b0, b1)
+                for st in streams[1:]:
+                    streams[0].wait_stream(st)  # join
+            torch.cuda.synchronize()
+
+            def all_tick(gr=gr):
+                with torch.cuda.stream(streams[0]):
+                    gr.replay()
+
+            modes[name] = dict(timed(all_tick), host_calls_per_step=1, host_iterations_per_step=1, launches_per_slice_and_step=per_slice)
+        except Exception as exc:
+            modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     for name, ticks, tick_fn in (("graph", 1, slice_tick), ("graph16", 16, slice_tick), ("policy_graph", 1, slice_tick_policy),
                                  ("policy_graph16", 16, slice_tick_policy)):
         if only is not None and name not in only:
@@ -427,11 +552,21 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
                                launches_per_slice_and_step=2 if tick_fn is slice_tick_policy else 3)
         except Exception as exc:  # capture support differs between ROCm builds: the eager figure stands
             modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    best = max((m for m in ("eager", "graph", "policy_eager", "policy_graph") if "value" in modes.get(m, {})), key=lambda m: modes[m]["value"])
+    one_iter = ("eager", "graph", "policy_eager", "policy_graph", "policy_graph_all", "inkernel_eager", "inkernel_sliced", "inkernel_graph_all")
+    best = max((m for m in one_iter if "value" in modes.get(m, {})), key=lambda m: modes[m]["value"])
+    separate = [m for m in one_iter if not m.startswith("inkernel") and "value" in modes.get(m, {})]
+    best_sep = max(separate, key=lambda m: modes[m]["value"]) if separate else None
     out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
+               # the best row whose policy is a kernel of its OWN (what a policy network needs): the inkernel_* rows evaluate the
+               # benchmark's policy inside the step kernel's action load (ce_step_policy CE_POLICY_AHEAD_NOISE)
+               best_with_separate_policy_kernel=None if best_sep is None else dict(
+                   {k: modes[best_sep][k] for k in ("value", "ms_per_step", "host_calls_per_step")}, issue=best_sep),
                policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
                       "byte, accumulated) mod %d — eager / graph: two elementwise kernels + the step per slice and tick; policy_*: "
-                      "one elementwise kernel + ce_step_policy (the modulo happens in the step kernel's action load)" % A,
+                      "one elementwise kernel + ce_step_policy (the modulo happens in the step kernel's action load); inkernel_*: the whole "
+                      "policy inside the step kernel (CE_POLICY_AHEAD_NOISE: it reads the pixel ahead from the previous view itself), one "
+                      "launch per slice and tick; *_sliced = the launch loop in C (one host call per tick), *_graph_all = ONE hipGraph over "
+                      "all slices (fork / join inside the capture)" % A,
                workload=wl["name"])
     env.close()
     return out
@@ -519,6 +654,25 @@ def boundary(wl, E, device_index):
         ticks.append(time.perf_counter() - ta)
         steps += 1
     dt = time.perf_counter() - t0
+    # the same tick with the policy side's action dictionaries built INSIDE it (Python's dict constructor over E x n entries),
+    # and with a consumer that copies every observation it is handed (what a collector must do with anything it keeps
+    # beyond the next tick — vector_env.py's recycling contract; RLlib's Dict-space preprocessor does it by flattening)
+    t1, k_incl = time.perf_counter(), 0
+    while time.perf_counter() - t1 < 0.4 or k_incl < 3:
+        pl = planes[k_incl % 8]
+        venv.send_actions({e: dict(zip(keys, row)) for e, row in enumerate(pl.tolist())})
+        obs, rew, dones, infos, _ = venv.poll()
+        for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
+            pass
+        k_incl += 1
+    dt_incl = (time.perf_counter() - t1) / k_incl
+    t1 = time.perf_counter()
+    for k in range(2):
+        venv.send_actions(action_dicts[k % 8])
+        obs, rew, dones, infos, _ = venv.poll()
+        kept = [np.concatenate([v.ravel() for v in ao.values()]) for o in obs.values() for ao in o.values()]  # flatten = copy
+    dt_copy = (time.perf_counter() - t1) / 2
+    del kept
     ticks.sort()
     # `value` is the mean over the sample; this leg is host work (sixteen to thirty-two threads beside other tenants of the box), so
     # the spread of the single ticks is carried too
@@ -527,6 +681,13 @@ def boundary(wl, E, device_index):
                             "ms_per_tick_min": ticks[0] * 1e3, "ms_per_tick_median": ticks[len(ticks) // 2] * 1e3,
                             "ms_per_tick_max": ticks[-1] * 1e3,
                             "ms_building_action_dicts_not_timed": ms_build, "last_tick_ms": dict(venv.tick_timing),
+                            "value_incl_action_dicts": E * n / dt_incl, "ms_per_step_incl_action_dicts": dt_incl * 1e3,
+                            "value_with_consumer_copies": E * n / dt_copy, "ms_per_step_with_consumer_copies": dt_copy * 1e3,
+                            "recycle_dicts": venv.recycle_dicts,
+                            "contract": "what poll() returned at tick t is intact through t + 1 and rewritten in place by t + 2; "
+                                        "`value` excludes building the action dictionaries (the policy side's product) and any copy the "
+                                        "consumer makes; value_incl_action_dicts / value_with_consumer_copies (a Python-level flatten of "
+                                        "every agent's observation, as RLlib's Dict preprocessor does) include them",
                             "what": "send_actions(pre-built {env: {agent: action}}) + poll with every env's obs (float64 image views) / "
                                     "reward / done / info dictionaries in hand and walked; recycled dictionary trees over page-locked "
                                     "snapshots (vector_env.py), observations converted to float64 on the host threads every tick"}
@@ -650,9 +811,12 @@ def run_rank(a):
                    "roofline": rr.roofline(m, kernel_names(w["kind"], w["n"])[0], "per_step_" + key)}
             if w_fused:
                 f = rr.measure("fused", T=a.fused_steps, min_repeats=3, min_seconds=a.config_seconds, max_repeats=100000)
+                froof = rr.roofline(f, kernel_names(w["kind"], w["n"])[1], "fused_" + key)
                 row["fused"] = {"value": f["value"], "ms_per_step": f["ms_per_step"], "steps_per_launch": f["steps_per_launch"],
                                 "steps": f["steps"], "repeats": f["repeats"], "launches_per_step": f["launches_per_step"],
-                                "roofline_frac": rr.roofline(f, kernel_names(w["kind"], w["n"])[1], "fused_" + key)["frac"]}
+                                "roofline_frac": froof["frac"], "traffic_ratio": froof["traffic_ratio"],
+                                "roofline_frac_is": "algorithmic bytes / time: a throughput index for a resident-state kernel, which "
+                                                    "moves traffic_ratio x those bytes (the state stays on chip between the steps of a launch)"}
             rows.append(row)
             rr.close()
         if out is not None:
@@ -674,12 +838,16 @@ def run_rank(a):
             for S2 in (2, 4):
                 if S2 == a.streams or "error" in cl:
                     continue
-                r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5, ("policy_eager", "policy_graph", "policy_graph16"))
+                r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5,
+                           ("policy_eager", "policy_graph", "policy_graph16", "policy_graph_all", "inkernel_eager", "inkernel_sliced", "inkernel_graph_all"))
                 sweep[str(S2)] = {m: {k: v[k] for k in ("value", "ms_per_step", "host_calls_per_step") if k in v}
                                   for m, v in r2.get("modes", {}).items()} if "error" not in r2 else r2
                 if "error" not in r2 and r2["value"] > cl["value"]:
                     cl.update({k: r2[k] for k in ("value", "ms_per_step", "steps", "repeats", "timed_seconds", "host_calls_per_step",
                                                   "host_iterations_per_step", "issue", "slices")})
+                if "error" not in r2 and (r2.get("best_with_separate_policy_kernel") or {}).get("value", 0) > \
+                        (cl.get("best_with_separate_policy_kernel") or {}).get("value", 0):
+                    cl["best_with_separate_policy_kernel"] = dict(r2["best_with_separate_policy_kernel"], slices=S2)
             cl["slices_sweep"] = sweep
         if not a.no_boundary:
             out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
@@ -687,11 +855,57 @@ def run_rank(a):
             out["counter_rng"] = extra(counter_rng, group, WORKLOADS["C4"], a, local_rank)
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = extra(cpu_baseline, wl, a.cpu_seconds)
+            def with_parity(target, w, seconds, **kw):
+                cb = extra(cpu_baseline, w, seconds, **kw)
+                st = cb.pop("_oracle_state", None)
+                if st is not None and st["fields"] is not None:
+                    target["parity_in_run"] = extra(parity_in_run, w, st, local_rank, a.streams, a.fused_steps)
+                target["cpu_baseline"] = cb
+
+            with_parity(out, wl, a.cpu_seconds)
             for row in out.get("configs", []):  # the CPU path beside every GPU config, same E rule / seeds / actions
-                row["cpu_baseline"] = extra(cpu_baseline, WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
+                with_parity(row, WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
+        out["summary"] = summary(out)  # LAST key: the tail of the line holds every row (the driver keeps the last 8 KB)
         print(json.dumps(out), flush=True)
     group.close()
+
+
+def summary(out):
+    """compact digest of the line, emitted as its last key: [value in G agent-steps/s, roofline frac, fused frac] per config"""
+    def g(x):
+        return None if x is None else round(x / 1e9, 4)
+
+    def f3(x):
+        return None if x is None else round(x, 4)
+
+    def row(r, fused):
+        roof = r.get("roofline") or {}
+        par = r.get("parity_in_run")
+        return {"G": g(r.get("value")), "frac": f3(roof.get("frac")), "traffic_ratio": roof.get("traffic_ratio"),
+                "fused_G": g((fused or {}).get("value")),
+                "fused_frac": f3(((fused or {}).get("roofline") or {}).get("frac", (fused or {}).get("roofline_frac"))),
+                "cpu_G": g((r.get("cpu_baseline") or {}).get("value")),
+                "parity_ok": None if par is None else par.get("ok", False)}
+
+    sm = {"C4": row(out, out.get("fused"))}
+    for r in out.get("configs", []):
+        sm[r["config"]] = row(r, r.get("fused"))
+    cl, bd, cr = out.get("closed_loop") or {}, out.get("boundary") or {}, out.get("counter_rng") or {}
+    sm["closed_loop_G"] = g(cl.get("value"))
+    sm["closed_loop_issue"] = cl.get("issue")
+    sm["closed_loop_host_calls_per_step"] = cl.get("host_calls_per_step")
+    sm["closed_loop_separate_policy_kernel_G"] = g((cl.get("best_with_separate_policy_kernel") or {}).get("value"))
+    sm["dict_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"]["value"] / 1e6, 2)
+    sm["dict_incl_action_dicts_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"].get("value_incl_action_dicts", 0) / 1e6, 2)
+    sm["tensor_G"] = g((bd.get("tensor_path") or {}).get("value"))
+    hb, lb = cr.get("headline_batch") or {}, cr.get("large_batch") or {}
+    sm["counter_G"] = g((hb.get("counter") or {}).get("value"))
+    sm["counter_frac"] = f3((hb.get("counter") or {}).get("roofline_frac"))
+    sm["counter_fused_G"] = g(((hb.get("counter") or {}).get("fused") or {}).get("value"))
+    sm["beyond_cache_frac"] = f3((lb.get("mt19937") or {}).get("roofline_frac"))
+    sm["beyond_cache_counter_frac"] = f3((lb.get("counter") or {}).get("roofline_frac"))
+    sm["parity_all_ok"] = all(v.get("parity_ok") for k, v in sm.items() if isinstance(v, dict) and v.get("parity_ok") is not None)
+    return sm
 
 
 def main():

@@ -18,7 +18,7 @@ FLAG_FIRING, FLAG_AUTO_RESET, FLAG_COLLECTIVE, FLAG_INEQUITY, FLAG_COLLISION, FL
 FLAG_BEAM_TRACE = 64
 FLAG_RNG_COUNTER = 128
 BEAM_NONE, BEAM_FIRE, BEAM_CLEAN = 0, 1, 2
-POLICY_BYTES_MOD, POLICY_ARGMAX_F32 = 1, 2
+POLICY_BYTES_MOD, POLICY_ARGMAX_F32, POLICY_AHEAD_NOISE = 1, 2, 3
 FAULT_BAD_ACTION, FAULT_NO_SPAWN, FAULT_STEP_AFTER_DONE = 1, 2, 4
 ERRORS = {-22: "CE_EINVAL", -12: "CE_ENOMEM", -19: "CE_ENODEV", -5: "CE_EIO", -34: "CE_ERANGE"}
 
@@ -77,6 +77,7 @@ EXPORTS = {
     "ce_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ce_step_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_step_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "ce_step_policy_sliced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "ce_rollout_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeTraj), C.c_uint32, C.c_void_p]),
     "ce_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -4,7 +4,10 @@
 // state besides the per-process constant tables (idempotent uploads).
 #include <hip/hip_runtime.h>
 
-#include <immintrin.h>
+#if defined(__x86_64__)
+#include <immintrin.h>  // streaming stores of the host-side conversions; other hosts take the plain-store loops below
+#define CE_HOST_X86 1
+#endif
 
 #include <pthread.h>
 
@@ -18,6 +21,7 @@
 #include <functional>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -266,9 +270,21 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   *out = h;  // handed out even on failure so ce_last_error works; caller must ce_destroy
   if (cfg->ascii_map) {  // a caller's layout: checked (and its tables built) before the device is touched
     if (!is_grid(*cfg)) return fail(h, CE_EINVAL, "ascii_map belongs to the grid kinds (cleanup_new / harvest_new)");
+    // the caller's dimensions are checked against the kind's frame BEFORE anything is read through the pointer (a C caller
+    // with garbage dimensions gets CE_EINVAL, not an out-of-bounds read or an exception through the C boundary)
+    const uint32_t fh = cfg->kind == CE_KIND_CLEANUP ? Geo<CE_KIND_CLEANUP>::H : Geo<CE_KIND_HARVEST>::H;
+    const uint32_t fw = cfg->kind == CE_KIND_CLEANUP ? Geo<CE_KIND_CLEANUP>::W : Geo<CE_KIND_HARVEST>::W;
+    if (cfg->map_rows < 1 || cfg->map_cols < 1 || cfg->map_rows > fh || cfg->map_cols > fw)
+      return fail(h, CE_EINVAL, "ascii_map: the layout does not fit the kind's frame (25 x 18 cleanup, 16 x 38 harvest)");
     h->h_tab = new (std::nothrow) GridTables();
     if (!h->h_tab) return fail(h, CE_ENOMEM, "layout tables");
-    h->map_text.assign(cfg->ascii_map, (size_t)cfg->map_rows * cfg->map_cols);
+    try {
+      h->map_text.assign(cfg->ascii_map, (size_t)cfg->map_rows * cfg->map_cols);
+    } catch (const std::bad_alloc&) {
+      return fail(h, CE_ENOMEM, "layout text");
+    } catch (const std::length_error&) {
+      return fail(h, CE_EINVAL, "ascii_map: dimensions out of range");
+    }
     const char* why = cfg->kind == CE_KIND_CLEANUP
                           ? build_tables<CE_KIND_CLEANUP>(*h->h_tab, h->map_text.data(), (int)cfg->map_rows, (int)cfg->map_cols, cfg->num_agents, h->map_counts)
                           : build_tables<CE_KIND_HARVEST>(*h->h_tab, h->map_text.data(), (int)cfg->map_rows, (int)cfg->map_cols, cfg->num_agents, h->map_counts);
@@ -434,6 +450,23 @@ extern "C" int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
   return sync_device_params(h);
 }
 
+// Single-step launches write their observations through the L2 (GridParams.obs_wt / SdParams.obs_wt, see write_obs) when the
+// handle's device memory — state, outputs, generator rows — fits the 256 MB Infinity Cache with some room to spare: a
+// write-through store that lands in that cache is cheap and shortens the launch's end (no dirty lines left to write back), one
+// that goes on to HBM is not (round 5, interleaved A/B, agent-steps/s: cleanup n = 8 x 16 384 envs = 174 MB: +3.7 %; C3 +2.6 %;
+// selfdrive n = 4 x 32 768 = 217 MB: +5-8 %; cleanup n = 8 x 32 768 = 348 MB: -30 %; selfdrive x 131 072: -5 %).
+// CE_OBS_WT_MAX_BYTES overrides the limit (0 = never) for A/B runs.
+static bool obs_write_through(const ce_engine* h) {
+  static long long limit = -1;
+  if (limit < 0) {
+    const char* e = getenv("CE_OBS_WT_MAX_BYTES");
+    limit = e ? atoll(e) : (224ll << 20);
+  }
+  unsigned long long total = 0;
+  for (const auto& a : h->allocs) total += a.second;
+  return total <= (unsigned long long)limit;
+}
+
 static GridParams grid_params(ce_engine* h) {
   GridParams p;
   std::memset(&p, 0, sizeof(p));
@@ -466,6 +499,7 @@ static GridParams grid_params(ce_engine* h) {
   p.nspawn = h->map_counts[2];
   p.map_h = h->map_h;
   p.map_w = h->map_w;
+  p.obs_wt = obs_write_through(h) ? 1u : 0u;
   p.E = h->cfg.num_envs;
   p.n = h->cfg.num_agents;
   p.horizon = h->cfg.horizon;
@@ -514,6 +548,7 @@ static SdParams sd_params(ce_engine* h) {
   p.n = h->cfg.num_agents;
   p.contract = h->cfg.contract;
   p.flags = h->cfg.flags;
+  p.obs_wt = obs_write_through(h) ? 1u : 0u;
   p.contract_low = h->cfg.contract_low;
   p.contract_high = h->cfg.contract_high;
   p.null_prob = h->cfg.null_prob;
@@ -686,7 +721,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
 extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream) {
   if (!h || !policy_out) return CE_EINVAL;
   if (!is_grid(h->cfg)) return fail(h, CE_EINVAL, "ce_step_policy belongs to the grid kinds");
-  if (mode != CE_POLICY_BYTES_MOD && mode != CE_POLICY_ARGMAX_F32) return fail(h, CE_EINVAL, "unknown CE_POLICY_* mode");
+  if (mode != CE_POLICY_BYTES_MOD && mode != CE_POLICY_ARGMAX_F32 && mode != CE_POLICY_AHEAD_NOISE) return fail(h, CE_EINVAL, "unknown CE_POLICY_* mode");
   if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
   begin_call(h);
   if (hipError_t e = order_after_reset(h, stream); e != hipSuccess)
@@ -698,6 +733,17 @@ extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode
   (counter_rng(h->cfg) ? launch_grid_step_policy_ctr : launch_grid_step_policy)((int)h->cfg.kind, (int)mode, p, h->d_gparams, stream);
   if (h->timing_armed) h->timed_launches++;
   return check_launch(h, "policy step kernel");
+}
+
+extern "C" int ce_step_policy_sliced(ce_handle h, const void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams) {
+  if (!h || !policy_out || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
+  const uint32_t E = h->cfg.num_envs;
+  for (uint32_t s = 0; s < num_slices; ++s) {
+    const uint32_t b0 = (uint32_t)((uint64_t)E * s / num_slices), b1 = (uint32_t)((uint64_t)E * (s + 1) / num_slices);
+    const int rc = ce_step_policy(h, policy_out, mode, b0, b1 - b0, streams ? streams[s] : nullptr);
+    if (rc != CE_OK) return rc;
+  }
+  return CE_OK;
 }
 
 extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
@@ -950,6 +996,8 @@ extern "C" int ce_download_async(ce_handle h, const char* field, uint32_t env_be
   if (!find_field(h, field, &f)) return fail(h, CE_EINVAL, "unknown or absent field");
   if (is_grid(h->cfg) && std::strcmp(field, "grid") == 0) return fail(h, CE_EINVAL, "ce_download_async: fetch \"grid\" with ce_download");
   if ((uint64_t)env_begin + env_count > h->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) return fail(h, CE_EINVAL, "slice out of range");
+  if (hipError_t eo = order_after_reset(h, stream); eo != hipSuccess)  // a copy on a stream other than the last reset's reads after it
+    return fail(h, CE_ENODEV, "download: the stream could not be ordered after the last ce_reset", eo);
   const hipError_t e = hipMemcpyAsync(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes,
                                       hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "asynchronous download", e);
@@ -1049,12 +1097,14 @@ HostPool& host_pool() {
 
 // one view (675 doubles) from a buffer that shares dst's alignment modulo 32 bytes: scalar head up to the first 32-byte boundary,
 // 32-byte streaming stores, scalar tail
+#ifdef CE_HOST_X86
 __attribute__((target("avx"))) void stream_view_avx(double* dst, const double* t, int head) {
   int i = 0;
   for (; i < head; ++i) dst[i] = t[i];
   for (; i + 3 < 15 * 45; i += 4) _mm256_stream_pd(dst + i, _mm256_load_pd(t + i));
   for (; i < 15 * 45; ++i) dst[i] = t[i];
 }
+#endif
 
 // uint8 pitched observation views -> float64 value / 255, dense [envs][n][15][15][3], on the pool.  A 256-entry table of the
 // same double division numpy performs.
@@ -1072,7 +1122,9 @@ void convert_views(const uint8_t* pitched, double* out, uint32_t num_envs, uint3
   // (a view is assembled in a cache-resident buffer first: its rows start 8 bytes off a 16-byte boundary every other time, and
   // an ordinary store into a line that streaming stores are filling stalls the write-combining buffers — measured 4 x slower)
   // 32-byte streaming stores where the host has them (half the store instructions); CE_HOST_SSE_ONLY=1 keeps the 16-byte form for A/B
+#ifdef CE_HOST_X86
   static const bool wide = __builtin_cpu_supports("avx") && !getenv("CE_HOST_SSE_ONLY");
+#endif
   const std::function<void(size_t, size_t)> work = [=](size_t v0, size_t v1) {
     alignas(32) double tmp[15 * 45 + 4];
     for (size_t v = v0; v < v1; ++v) {
@@ -1087,6 +1139,7 @@ void convert_views(const uint8_t* pitched, double* out, uint32_t num_envs, uint3
         double* d = t + r * 45;
         for (int k = 0; k < 45; ++k) d[k] = lut[s[k]];
       }
+#ifdef CE_HOST_X86
       if (wide) stream_view_avx(dst, t, head);
       else {
         int i = 0;
@@ -1094,8 +1147,14 @@ void convert_views(const uint8_t* pitched, double* out, uint32_t num_envs, uint3
         for (; i + 1 < 15 * 45; i += 2) _mm_stream_pd(dst + i, _mm_loadu_pd(t + i));
         if (i < 15 * 45) dst[i] = t[i];
       }
+#else
+      std::memcpy(dst, t, sizeof(double) * 15 * 45);  // hosts without the x86 streaming stores: ordinary stores
+      (void)head;
+#endif
     }
+#ifdef CE_HOST_X86
     _mm_sfence();
+#endif
   };
   // pieces a few times smaller than a thread's share: the threads that start late or share a core take fewer of them
   host_pool().run(threads, views, std::max<size_t>(64, views / ((size_t)threads * 4 + 1)), work);
@@ -1130,17 +1189,31 @@ extern "C" int ce_download_obs_f64(ce_handle h, uint32_t env_begin, uint32_t env
     if (e != hipSuccess) return fail(h, CE_ENODEV, "event for the observation copy", e);
     h->obs_events.push_back(ev);
   }
+  if (hipError_t eo = order_after_reset(h, stream); eo != hipSuccess)
+    return fail(h, CE_ENODEV, "observation copy: the stream could not be ordered after the last ce_reset", eo);
   auto cut = [&](uint32_t i) { return (uint32_t)((uint64_t)env_count * i / parts); };
+  // on a failure the copies already issued are waited for before returning: none is still writing `staging` when the caller
+  // gets the error (and frees or reuses the block)
+  auto settle = [&](uint32_t issued) {
+    for (uint32_t j = 0; j < issued; ++j) (void)hipEventSynchronize(h->obs_events[j]);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+  };
   for (uint32_t i = 0; i < parts; ++i) {
     const size_t off = (size_t)cut(i) * b.obs_env_stride, len = (size_t)(cut(i + 1) - cut(i)) * b.obs_env_stride;
     hipError_t e = hipMemcpyAsync((char*)staging + off, (const char*)b.obs + (size_t)env_begin * b.obs_env_stride + off, len,
                                   hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipEventRecord(h->obs_events[i], (hipStream_t)stream);
-    if (e != hipSuccess) return fail(h, CE_ENODEV, "observation copy", e);
+    if (e != hipSuccess) {
+      settle(i);
+      return fail(h, CE_ENODEV, "observation copy", e);
+    }
   }
   for (uint32_t i = 0; i < parts; ++i) {
     const hipError_t e = hipEventSynchronize(h->obs_events[i]);
-    if (e != hipSuccess) return fail(h, CE_ENODEV, "observation copy", e);
+    if (e != hipSuccess) {
+      settle(parts);
+      return fail(h, CE_ENODEV, "observation copy", e);
+    }
     convert_views((const uint8_t*)staging + (size_t)cut(i) * b.obs_env_stride, out + (size_t)cut(i) * n * (15 * 45), cut(i + 1) - cut(i), n,
                   b.obs_env_stride, b.obs_agent_stride, b.obs_row_stride, threads);
   }

@@ -110,6 +110,7 @@ struct GridParams {
   uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
   uint32_t custom_map;            // 1 = the kernels' CM instances run: tables from `tab`, list lengths below
   uint32_t napple, nwaste, nspawn, map_h, map_w;
+  uint32_t obs_wt;                // single-step launches write the views through the L2 (sc1) instead of nontemporal (write_obs)
   double contract_low, contract_high, null_prob, alpha, beta;
 };
 
@@ -154,6 +155,7 @@ struct SdParams {
   CE_GPTR(const uint8_t) mask;
   uint32_t E, n, contract, flags, replay_constructor;
   uint32_t env_first, env_count;  // host-side launch range (count 0 = through the last env)
+  uint32_t obs_wt;                // single-step launches write the observation rows through the L2 (sc1), see GridParams
   double contract_low, contract_high, null_prob, low_bound, high_bound, start_vel, start_vel_ambulance;
 };
 

@@ -41,22 +41,9 @@ namespace ce {
 namespace diag {
 constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = false, ablate_obsstore = false,
                ablate_gridstore = false, ablate_rngstore = false, seq_shuffle = false, serial_apply = false,
-               serial_small_shuffle = false, ablate_twist = false;
+               serial_small_shuffle = false, ablate_twist = false, ablate_half_narrow = false;
 }
 }  // namespace ce
-#endif
-
-// -DCE_DUO_STAMPS (tools/duo_profile.py, never shipped): s_memtime stamps of the two waves of k_grid_step_duo into GridParams.debug
-#ifdef CE_DUO_STAMPS
-#define CE_DSTAMP(dbg_, k_)                                          \
-  do {                                                               \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    if (lane == 0 && (dbg_)) (dbg_)[(k_)] = t_;                      \
-  } while (0)
-#else
-#define CE_DSTAMP(dbg_, k_) ((void)0)
 #endif
 
 namespace ce {
@@ -550,14 +537,11 @@ DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
 // index i0 - a; draws are scattered to J[index] in LDS.  The short segments below 32 cost a whole vector round
 // each, so they take the one-draw-per-ballot walk instead (3 VALU per draw), collecting J[i] in lane i.
 // Returns with r advanced past every consumed word.
-// `cancel` (duo helper only): an LDS word that turns 2 when the caller's speculative work is known to be unwanted — polled once
-// per batch of cached words, the walk is abandoned (its results are never read then).
-DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane, const volatile u32* cancel = nullptr) {
+DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
   constexpr u32 kVecMin = 8;
   rng_assert_uniform(r);
   u32 i0 = len - 1;
   while (i0 >= kVecMin) {
-    if (cancel != nullptr && rfl(*cancel) == 2u) return;
     const u32 lo = 1u << (31 - __builtin_clz(i0));  // segment [lo, i0] shares mask 2*lo - 1
     const u32 mask = 2 * lo - 1;
     u32 off = r.pos - r.cbase;
@@ -687,14 +671,6 @@ DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
   shuffle_small<0>(r, L0, len, lane);
 }
 
-// hand-over words of a two-wave workgroup (k_grid_step_duo), in LDS
-struct alignas(16) DuoX {
-  u32 agents[12];           // main -> helper: padded cell | orientation << 16 of agent a (after update_moves)
-  u32 rng_pos, rng_twists;  // helper -> main: its copy of the stream after the waste shuffle
-  u32 need;                 // main -> helper: 0 = not known yet, 1 = the waste list is shuffled this step, 2 = it is not
-  u32 pad;
-};
-
 // ----------------------------------------------------------------------------------------
 // per-wave LDS
 // ----------------------------------------------------------------------------------------
@@ -748,9 +724,6 @@ template <int KIND> struct Env {
   u32 WS[2];
   unsigned long long* dbg;  // diagnostic builds only
   bool waste_perm_dirty;    // the persistent waste list was shuffled in this launch
-  // two-wave workgroups (k_grid_step_duo): the helper wave's LDS block and the hand-over words; null otherwise
-  WaveLds<KIND>* LH;
-  struct DuoX* X;
   // The layout the env is built from (env_geometry): the static tables and the lengths of its cell lists.  For the shipped layout
   // these are literals — everything is inlined into the kernel, so they fold exactly like the Geo<KIND> constants they stand
   // for; a kernel instance for a caller's layout (ce_config.ascii_map, CM = true) reads them from the parameter block.
@@ -861,7 +834,7 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
   }
   if (rfl(E.rng.twists) != 0 && !diag::ablate_twist) {  // the key words only change at a twist; otherwise just the position moves
     uint4* dst = (uint4*)(p.rng + (size_t)E.e * kRngRow);
-    const uint4* src = (const uint4*)E.rng.mt;  // (a duo workgroup may have adopted the helper wave's copy of the stream)
+    const uint4* src = (const uint4*)E.rng.mt;
     const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
     const uint4 r0 = src[E.lane], r1 = src[E.lane + 64], r2 = src[q2];
     dst[E.lane] = r0;
@@ -1300,10 +1273,7 @@ DEVINL bool below_hi(u32 a_tempered, u64 thr, bool& tie) {
 }
 DEVINL bool below_lo(u32 b_raw, u64 thr) { return (mt_temper(b_raw) >> 6) < ((u32)thr & 0x3ffffffu); }
 
-// DUO (k_grid_step_duo): the waste-list shuffle — draws and list update, the longest stretch of a step that shuffles — has
-// been computed by the workgroup's helper wave on its own copy of the stream while this wave ran moves / beams / the apple
-// scan; here it is only adopted (list, stream position, the helper's stream copy) behind one workgroup barrier.
-template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E) {
+template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
   typedef Geo<KIND> G;
   const GridTables& T = *E.T;
   const u32 lane = E.lane;
@@ -1329,7 +1299,6 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
     }
     const u64 th = T.apple_thresh[nH];
     waste_on = (th & kWasteOnBit) != 0;
-    if (DUO && lane == 0) *(volatile u32*)&E.X->need = waste_on ? 1u : 2u;  // lets the helper skip the list update it will not be asked for
     // waste density >= 0.4 (cleanup_new.py:357-359): both probabilities are zero, so nothing can spawn and the rand(222)
     // call only moves the stream — about half the steps of a steady-state episode (the density hovers at the threshold:
     // a spawned waste switches the model off until the next one is cleaned).  The per-cell work below is skipped then;
@@ -1409,9 +1378,6 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
     }
   }
   window_close(E.rng, W, E.randw);
-  if (DUO) CE_DSTAMP(E.dbg, 4);
-  if (DUO) __syncthreads();  // hand-over 1: the helper's shuffle results are in its LDS block (every step passes here)
-  if (DUO) CE_DSTAMP(E.dbg, 5);
   if (!scan) return;
   bool spawnA[AR], tie[AR];
   bool any_tie = false;
@@ -1439,20 +1405,7 @@ template <int KIND, bool DUO = false> DEVINL void custom_map_update(Env<KIND>& E
         const u64 sb = ballot(needw[r] && (__builtin_popcount(ww[r] & 0x89010000u) & 1) == 0);
         if (tstar == 0xffffffffu && sb) tstar = ctz64(sb) + 64 * r;
       }
-      if (DUO) {
-        // the helper consumed exactly the words this wave consumed up to here (mover shuffle, id shuffle, the rand() window)
-        // on its copy, then drew and applied the shuffle: its list, its stream position and its copy of the state are the env's
-        E.waste_perm_dirty = true;
-        const u32* wp = E.LH->U;
-        E.WP0 = wp[lane];
-        E.WP1 = lane + 64 < E.nwaste ? wp[64 + lane] : 0u;
-        E.rng.mt = E.LH->mt;
-        E.rng.pos = rfl(E.X->rng_pos);
-        E.rng.twists = rfl(E.X->rng_twists);
-        E.rng.cbase = 0;
-        E.rng.ccount = 0;
-        E.rng.cvalid = 0;
-      } else if (diag::seq_shuffle) {
+      if (diag::seq_shuffle) {
         shuffle_core<true>(E.rng, E.WP0, E.WP1, E.nwaste, lane);
       } else if (E.nwaste <= 64u) {  // a caller's small layout (never the shipped one: 119): the list lives in one register
         E.waste_perm_dirty = true;
@@ -1582,14 +1535,25 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
   auto put_unit = [&](u32 a, const u32x3& dv) {
     // the agent's view starts a * 720 bytes into the env's block: folded into the wave-uniform base (scalar add), the
     // per-lane part of the address stays lane * 12 for every agent
-    const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
     if (diag::ablate_obsstore) {  // traffic experiment: the pixels are computed but not written
       asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
       return;
     }
-    // streaming (nontemporal) store: the observation is write-once output and the bulk of the step's bytes; keeping it
-    // out of L2 / Infinity Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536)
-    if (lane < 60) __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
+    // Two cache policies for the same bytes (one wave-uniform branch per view):
+    //  * nontemporal: the observation is write-once output and the bulk of the step's bytes; keeping it out of L2 / Infinity
+    //    Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536 over plain stores)
+    //  * write-through (sc1), single-step launches of handles that fit the Infinity Cache (GridParams.obs_wt, set by the host:
+    //    ce_api.hip obs_write_through): the bytes leave the XCD's L2 as they are produced instead of at the kernel's end, when
+    //    the launch's release writes every dirty line back at once — round 5, interleaved A/B: C4 +3.7 %, C3 +2.6 %, C2 +1.5 %;
+    //    a fused rollout LOSES 40 % with it and a 32 768-env batch 30 % (sustained write bandwidth past the cache), hence the switch.
+    //    Written as asm: the compiler has no 12-byte sc1 store but the buffer form, and that one (SGPR soffset) it follows
+    //    with a write to the data registers without the wait state gfx950 needs — corrupted view rows in 2 % of the envs
+    //    (tools/dbg_wt.py); the s_nop inside the string is that wait state.
+    const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
+    if (lane < 60) {
+      if (!RESTORE && p.obs_wt) asm volatile("global_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(dv), "s"(dst_a));
+      else __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
+    }
   };
   // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
   // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
@@ -1949,8 +1913,6 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   E.n = p.n;
   E.is_agent = E.lane < E.n;
   E.L = lds + wave;
-  E.LH = nullptr;
-  E.X = nullptr;
 #ifdef CE_INSTRUMENTED
   E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
 #else
@@ -2060,7 +2022,7 @@ struct StepOutPlane {
 // One env-step on the state held in E / LDS: MapEnv.step, infos, contract transfer, metrics, observation, in-launch
 // auto-reset.  FUSED = false: the step is its own launch and the state is written back to HBM at the end.
 // FUSED = true (k_grid_rollout): the state stays resident for the next step; only the per-step outputs leave.
-template <int KIND, bool FUSED, class OUT, bool DUO = false>
+template <int KIND, bool FUSED, class OUT>
 DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u32 ACT, u32& t, double& theta, u32& fault,
                            bool& did_reset) {
   const GridTables& T = *E.T;
@@ -2080,9 +2042,11 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   if (p.flags & CE_FLAG_BEAM_TRACE) clear_beam_map(E, p);  // self.beam_pos = [] (map_env.py:231)
   CE_PROBE_POINT(t, &p, lane, n);
   CE_STAMP(1);
-  if (!diag::ablate_moves) update_moves(E, ACT);
+  // -DCE_ABLATE_HALF_NARROW (timing only, wrong results): every other env skips the phases that keep <= 16 lanes busy — moves,
+  // consume / id shuffle / beams, reward and metric bookkeeping — i.e. what two envs packed into one wave could at best share
+  const bool narrow_skip = diag::ablate_half_narrow && (E.e & 1u) != 0;
+  if (!diag::ablate_moves && !narrow_skip) update_moves(E, ACT);
   CE_STAMP(2);
-  if (DUO) CE_DSTAMP(E.dbg, 2);
   if (!E.is_agent) E.P = 0xffffu;
 
   // eaten_apples: final position held an apple when the step was entered (nothing has touched
@@ -2098,7 +2062,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       if (lane == a && cnt < 4) eaten_close = 1;
     }
   }
-  {  // consume in agent order: the first agent on the cell gets the apple
+  if (!narrow_skip) {  // consume in agent order: the first agent on the cell gets the apple
     bool first = true;
     const u64 onm = ballot(onA);
     if (onm & (onm - 1)) {  // two or more agents on apples: only then can a cell be shared
@@ -2113,7 +2077,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     pm_put(pm, onA, E.P, kEmpty);
     mark_agents(E);
   }
-  {  // update_custom_moves: always shuffles the n ids, then fires in that order
+  if (!narrow_skip) {  // update_custom_moves: always shuffles the n ids, then fires in that order
     u32 IDS = lane;
     const u64 firing = ballot(E.is_agent && ACT >= 7);
     if (firing & (firing - 1)) {  // the shuffled order only matters between two or more beams
@@ -2140,18 +2104,9 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     }
   }
   CE_STAMP(3);
-  if (DUO) CE_DSTAMP(E.dbg, 3);
-  custom_map_update<KIND, DUO>(E);
+  custom_map_update<KIND>(E);
   CE_TRUNCATE_SPAWN_RETURN();
   CE_STAMP(4);
-  if (DUO && t != p.horizon) {
-    // hand-over 2: the map is final and the agents stand where the step left them — the helper wave copies the map, paints
-    // the agents on ITS copy and writes every view while this wave goes on with features, rewards and metrics
-    if (E.is_agent) E.X->agents[lane] = E.P | (E.O << 16);
-    CE_DSTAMP(E.dbg, 6);
-    __syncthreads();
-    CE_DSTAMP(E.dbg, 7);
-  }
 
   // ---------------- rewards ----------------
   i32 base_rew = E.is_agent ? E.RW : 0;
@@ -2187,14 +2142,14 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       if (diag::ablate_features) store_grid(E, p);
       else store_grid_bits(E, p, presA, presW);  // the feature pass has just taken the map's presence ballots
     }
-    if (!DUO) write_obs<KIND, FUSED>(E, p, out.obs(), true);
+    write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
   // A quiet step — nobody ate, cleaned, fired or was hit: every reward, transfer and metric increment is zero — skips the
   // contract arithmetic and the whole metric bookkeeping behind ONE wave-uniform test (two thirds of the steps of the
   // benchmark; it was half a dozen separate tests, each a ballot, a scalar compare and a branch).
   const bool done = t == p.horizon;
-  const bool busy = ballot(E.is_agent && (eaten | eaten_close | cleaned | (u32)base_rew) != 0) != 0 || done;
+  const bool busy = (ballot(E.is_agent && (eaten | eaten_close | cleaned | (u32)base_rew) != 0) != 0 || done) && !narrow_skip;
   // ---------------- contract transfer (two_stage_train.py:69-92) ----------------
   double transfers_total = 0.0;
   if (busy && p.contract != CE_CONTRACT_NONE) {
@@ -2356,7 +2311,6 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     if (fault) p.error_flags[E.e] |= fault;
   }
   CE_STAMP(8);
-  if (DUO) CE_DSTAMP(E.dbg, 8);
   if (!obs_early) write_obs(E, p, out.obs(), !did_reset);
   CE_STAMP(9);
   CE_REALSTAMP(15);
@@ -2377,7 +2331,19 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 // other entry point); CE_POLICY_BYTES_MOD = one policy byte per agent, action = byte mod |A|; CE_POLICY_ARGMAX_F32 = |A| float
 // scores per agent, action = index of the first maximum (Gumbel-max sampling when the policy adds the noise).  The action a
 // policy step took is written to `actions_taken`.  Separate instances: the plain step kernel sits exactly at its 64 VGPRs.
-template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, size_t ea, u32 lane, bool is_agent, u32 A) {
+template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, size_t ea, u32 lane, bool is_agent, u32 A,
+                                                CE_GPTR(const uint8_t) prev_view) {
+  if (POLICY == CE_POLICY_AHEAD_NOISE) {
+    // the benchmark's closed-loop policy evaluated here: the env's noise byte moves on by the green channel of the cell in front
+    // of the agent in the view the previous step (or reset) wrote — view pixel (6, 7) of a 15 x 15 egocentric crop — and the
+    // action is the new byte mod |A|.  `prev_view` = this env's block of the observation buffer: read here, at entry, long
+    // before this step's own views are written to the same place.
+    const auto nz = (CE_GPTR(uint8_t))src + ea;
+    const u32 l = is_agent ? lane : 0u;
+    const u32 b = ((u32)GAT(nz, l) + (u32)GAT(prev_view, __umul24(l, (u32)kObsAgentStride) + 6u * kObsRowStride + 7u * 3u + 1u)) & 0xffu;
+    if (is_agent) GAT(nz, lane) = (uint8_t)b;
+    return !is_agent ? 4u : A == 8u ? (b & 7u) : A == 7u ? b % 7u : A == 9u ? b % 9u : b % A;
+  }
   if (POLICY == CE_POLICY_BYTES_MOD) {
     const u32 b = is_agent ? (u32)GAT((CE_GPTR(const uint8_t))src + ea, lane) : 4u;
     return A == 8u ? (b & 7u) : A == 7u ? b % 7u : A == 9u ? b % 9u : b % A;
@@ -2431,7 +2397,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
     ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
   } else {
     const u32 A = (KIND == CE_KIND_CLEANUP ? 8u : 7u) + ((p.flags & CE_FLAG_FIRING_ENABLED) ? 1u : 0u);
-    ACT = policy_action<POLICY>(call_actions, ea, lane, E.is_agent, A);
+    ACT = policy_action<POLICY>(call_actions, ea, lane, E.is_agent, A, (CE_GPTR(const uint8_t))p.obs + (size_t)E.e * p.obs_env_stride);
     if (E.is_agent) GAT(p.actions_taken + ea, lane) = (uint8_t)ACT;
   }
   CE_STAMP(0);
@@ -2442,176 +2408,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
   u32 fault = 0;
   bool did_reset = false;
   grid_step_core<KIND, false>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
-}
-
-// ----------------------------------------------------------------------------------------
-// Two waves per env for launches that leave wave slots free.  With every wave resident a step of the
-// batch lasts ONE wave's dependent chain (~22 k cycles alone on its SIMD), and two stretches of that chain
-// do not depend on what precedes them:
-//   * the waste-list shuffle (119 masked-rejection draws + the list update: ~9 k cycles on the steps that take it) depends
-//     only on the stream — the words consumed before it (mover shuffle, id shuffle, the rand(222) window) are a function of
-//     the ACTIONS and the stream, not of the map;
-//   * the observation pass only reads the final map and the agent table.
-// The workgroup's second wave (the helper) owns a second LDS block: it loads its own copy of the MT19937 row and the waste
-// list, walks the stream exactly as the main wave will (consume-only shuffles, the window), draws and applies the shuffle,
-// and parks list + stream position in LDS; the main wave adopts them behind one barrier (custom_map_update<DUO>) if the
-// step does shuffle, and drops them otherwise (the helper's work was speculative).  After the second barrier the helper
-// copies the final map, paints the agents on its copy and writes all n views while the main wave runs features, rewards,
-// metrics and the state stores.  Results are those of k_grid_step, bit for bit (tests/test_gpu_parity.py).
-// MT19937 build, cleanup kind; launch_grid_step picks it by launch size.
-// ----------------------------------------------------------------------------------------
-template <int KIND> DEVINL void duo_helper(const GridParams& p, WaveLds<KIND>* lds, DuoX* X, CE_GPTR(const uint8_t) acts, u32 env_first,
-                                           u32 n, CE_GPTR(u32) rng_base, CE_GPTR(uint8_t) waste_perm_base) {
-  typedef Geo<KIND> G;
-  Env<KIND> H;
-  H.lane = lane_id();
-  H.e = rfl(env_first + blockIdx.x);
-  H.n = n;
-  H.is_agent = H.lane < n;
-  H.L = lds + 1;
-  H.LH = nullptr;
-  H.X = nullptr;
-  H.dbg = nullptr;
-  H.waste_perm_dirty = false;
-  env_geometry<KIND, false>(H, p);
-  const u32 lane = H.lane;
-  const size_t ea = (size_t)H.e * n;
-#ifdef CE_DUO_STAMPS
-  H.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)H.e * 16 : nullptr;
-#endif
-  CE_DSTAMP(H.dbg, 9);
-  const u32 ACT = H.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
-  // own copy of the stream row and of the persistent waste list
-  const uint4* rsrc = (const uint4*)(rng_base + (size_t)H.e * kRngRow);
-  const u32 q2 = min(lane + 128u, (u32)kMtN / 4 - 1);
-  const uint4 r0 = rsrc[lane], r1 = rsrc[lane + 64], r2 = rsrc[q2];
-  const u32 rpos = rng_base[(size_t)H.e * kRngRow + kMtN];
-  const auto wp = waste_perm_base + (size_t)H.e * 119;
-  u32 WP0 = GAT(wp, lane);
-  const u32 w1 = GAT(wp, min(lane + 64u, 118u));
-  u32 WP1 = lane + 64 < 119 ? w1 : 0;
-  const u32 t1 = (u32)p.timestep[H.e] + 1u;
-  const bool obs_early = t1 != p.horizon;
-  const u32 rgbv = c_rgb[lane & 15];
-  uint4* mt4 = (uint4*)H.L->mt;
-  mt4[lane] = r0;
-  mt4[lane + 64] = r1;
-  mt4[q2] = r2;
-  H.L->rgb[lane & 15] = rgbv;
-  CE_DSTAMP(H.dbg, 10);
-  __syncthreads();  // start line: the main wave has cleared X->need
-  const u32 max_action = KIND == CE_KIND_CLEANUP ? 8u : 7u;
-  if (ballot(H.is_agent && ACT > max_action) != 0) return;  // the step is not taken (grid_step_core returns before any hand-over)
-  Rng& r = H.rng;
-  r.mt = H.L->mt;
-  r.pos = rfl(rpos);
-  r.cbase = 0;
-  r.ccount = 0;
-  r.cvalid = 0;
-  r.cache = 0;
-  r.twists = 0;
-  wave_sync();
-  {  // the words update_moves and update_custom_moves consume: np.random.shuffle of the m mover slots, then of the n ids
-    const u64 M = ballot(H.is_agent && ACT <= 4);
-    u32 d0 = 0;
-    if (M != 0) shuffle_small<2>(r, d0, popc64(M), lane);
-    shuffle_small<2>(r, d0, n, lane);
-  }
-  {  // rand(222): the window only moves the stream here
-    const StreamWindow W = window_open(r, lane, (u32)G::RANDW);
-    if (W.alen < (u32)G::RANDW) rng_advance(r, lane);
-    window_close(r, W, (u32)G::RANDW);
-  }
-  CE_DSTAMP(H.dbg, 11);
-  if (*(volatile u32*)&X->need != 2u) shuffle_draws(r, (u32)G::NWASTE, H.L->U, lane, (const volatile u32*)&X->need);
-  CE_DSTAMP(H.dbg, 12);
-  if (*(volatile u32*)&X->need != 2u) {  // (not known yet counts as wanted)
-    shuffle_apply_par(WP0, WP1, (u32)G::NWASTE, H.L->U, lane);
-    wave_sync();
-    H.L->U[lane] = WP0;
-    H.L->U[64 + lane] = WP1;
-  }
-  if (lane == 0) {
-    X->rng_pos = r.pos;
-    X->rng_twists = r.twists;
-  }
-  CE_DSTAMP(H.dbg, 13);
-  __syncthreads();  // hand-over 1
-  if (!obs_early) return;  // a done step writes its (reset) observation late, on the main wave
-  __syncthreads();  // hand-over 2: final map in the main wave's block, agents in X
-  CE_DSTAMP(H.dbg, 14);
-  {
-    const uint4* src = (const uint4*)lds[0].pmap;
-    uint4* dst = (uint4*)H.L->pmap;
-    constexpr u32 kLastMapQuad = (u32)G::PQUADS - 1;
-    const u32 q1 = min(lane + 64u, kLastMapQuad);
-    const uint4 m0 = src[lane], m1 = src[q1];
-    dst[lane] = m0;
-    dst[q1] = m1;
-    const u32 aw = X->agents[min(lane, n - 1u)];
-    H.P = H.is_agent ? (aw & 0xffffu) : 0xffffu;
-    H.O = (aw >> 16) & 3u;
-    H.RW = 0;
-  }
-  wave_sync();
-  write_obs<KIND, false>(H, p, p.obs, true);
-  CE_DSTAMP(H.dbg, 15);
-}
-
-template <int KIND, int NFIX>
-__global__ __launch_bounds__(128, CE_CLEANUP_WAVES) void k_grid_step_duo(
-    const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
-    uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
-  static_assert(KIND == CE_KIND_CLEANUP && !kCounterRng, "the helper wave mirrors the MT19937 walk of the cleanup step");
-  const GridParams& p = *pp;
-  __shared__ WaveLds<KIND> lds[2];
-  __shared__ DuoX dx;
-  const auto acts = (CE_GPTR(const uint8_t))call_actions;
-  const u32 nn = NFIX ? (u32)NFIX : num_agents;
-  if (rfl(threadIdx.x >> 6) != 0) {
-    duo_helper<KIND>(p, lds, &dx, acts, env_first, nn, (CE_GPTR(u32))rng_base, (CE_GPTR(uint8_t))waste_perm_base);
-    return;
-  }
-  Env<KIND> E;
-  GridParams ph;
-  ph.rng = (decltype(ph.rng))rng_base;
-  ph.grid = (decltype(ph.grid))grid_base;
-  ph.agents = (decltype(ph.agents))agents_base;
-  ph.waste_perm = (decltype(ph.waste_perm))waste_perm_base;
-  ph.debug = nullptr;
-  ph.n = nn;
-  env_begin(E, ph, lds, env_first, 0xffffffffu);
-  env_geometry<KIND, false>(E, p);
-  E.LH = lds + 1;
-  E.X = &dx;
-  const u32 lane = E.lane, n = E.n;
-  const size_t ea = (size_t)E.e * n;
-#ifdef CE_DUO_STAMPS
-  E.dbg = p.debug ? (unsigned long long*)p.debug + (size_t)E.e * 16 : nullptr;
-#endif
-  CE_DSTAMP(E.dbg, 0);
-  const u32 ACT = E.is_agent ? (u32)GAT(acts + ea, lane) : 4u;
-  load_env_state(E, ph);
-  CE_DSTAMP(E.dbg, 1);
-  u32 t = (u32)p.timestep[E.e];
-  double theta = p.theta[E.e];
-  u32 fault = 0;
-  bool did_reset = false;
-  {
-    // What can be said about "does this step shuffle the waste list" before the step has run: the spawn model looks at the
-    // waste count AFTER the step's CLEAN beams, which can only lower it, and the waste probability is non-zero exactly below
-    // a density threshold (monotone in the count: checked when the tables are uploaded).  So: already on -> stays on; off and
-    // nobody cleans -> stays off; off and somebody cleans -> not known until the beams are done (custom_map_update says so).
-    u32 nH0 = 0;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      nH0 += popc64(ballot(both(lane + 64 * r < E.nwaste, (E.L->pmap[cell_pad(E.WS[r])] & kCodeMask) == kWaste)));
-    const bool on0 = (E.T->apple_thresh[nH0] & kWasteOnBit) != 0;
-    const bool cleans = ballot(E.is_agent && ACT == 7) != 0;
-    if (lane == 0) *(volatile u32*)&dx.need = on0 ? 1u : cleans ? 0u : 2u;
-  }
-  __syncthreads();  // start line (see duo_helper)
-  grid_step_core<KIND, false, StepOutDirect, true>(E, p, StepOutDirect{p}, ACT, t, theta, fault, did_reset);
 }
 
 // Fused multi-step rollout (ce_rollout_fused): the env's state — map, agent table, persistent lists, MT19937 — is loaded
@@ -4695,11 +4491,7 @@ __global__ void k_ctr_selftest(u32* out) {
 // ----------------------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------------------
-static bool g_waste_on_monotone = true;  // the duo kernel's early "this step shuffles" rule rests on it (see k_grid_step_duo)
 int CE_LAUNCHER(upload_grid_tables)(int kind, const GridTables& t, const u32* rgb16) {
-  if (kind == CE_KIND_CLEANUP)
-    for (int k = 1; k < 120; ++k)
-      if (t.waste_on[k] && !t.waste_on[k - 1]) g_waste_on_monotone = false;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(GridTables), sizeof(GridTables) * kind) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_rgb), rgb16, sizeof(u32) * 16) != hipSuccess) return -1;
   return 0;
@@ -4727,15 +4519,6 @@ static unsigned extra_lds() {
   if (v < 0) {
     const char* e = getenv("CE_EXTRA_LDS");
     v = e ? atoi(e) : 0;
-  }
-  return (unsigned)v;
-}
-// CE_DUO_MAX_ENVS: largest launch (envs) stepped by two-wave workgroups; 0 switches them off (A/B runs)
-static unsigned duo_max_envs() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CE_DUO_MAX_ENVS");
-    v = e ? atoi(e) : 1366;
   }
   return (unsigned)v;
 }
@@ -4776,18 +4559,6 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
     return;
   }
   if (kind == CE_KIND_CLEANUP) {
-#ifndef CE_RNG_COUNTER
-    // launches that leave wave slots free step each env with a two-wave workgroup (k_grid_step_duo): three slices of at most
-    // this many envs are 8 192 waves, the machine's wave slots
-    if (count <= duo_max_envs() && g_waste_on_monotone) {
-      dim3 block2(128);
-      if (p.n == 4) hipLaunchKernelGGL((k_grid_step_duo<CE_KIND_CLEANUP, 4>), grid, block2, extra_lds(), (hipStream_t)stream, p.actions, first,
-                                       p.n, (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
-      else hipLaunchKernelGGL((k_grid_step_duo<CE_KIND_CLEANUP, 0>), grid, block2, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
-                              (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
-      return;
-    }
-#endif
     if (p.n == 8) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 8);
     else if (p.n == 4) CE_STEP_LAUNCH(CE_KIND_CLEANUP, 4);  // BASELINE config 1
     else CE_STEP_LAUNCH(CE_KIND_CLEANUP, 0);
@@ -4820,12 +4591,15 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
   if (p.custom_map) {
     if (kind == CE_KIND_CLEANUP) {
       if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY_CM(CE_KIND_CLEANUP, CE_POLICY_BYTES_MOD);
+      else if (policy == CE_POLICY_AHEAD_NOISE) CE_STEP_POLICY_CM(CE_KIND_CLEANUP, CE_POLICY_AHEAD_NOISE);
       else CE_STEP_POLICY_CM(CE_KIND_CLEANUP, CE_POLICY_ARGMAX_F32);
     } else {
       if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY_CM(CE_KIND_HARVEST, CE_POLICY_BYTES_MOD);
+      else if (policy == CE_POLICY_AHEAD_NOISE) CE_STEP_POLICY_CM(CE_KIND_HARVEST, CE_POLICY_AHEAD_NOISE);
       else CE_STEP_POLICY_CM(CE_KIND_HARVEST, CE_POLICY_ARGMAX_F32);
     }
   } else if (policy == CE_POLICY_BYTES_MOD) CE_STEP_POLICY(CE_POLICY_BYTES_MOD);
+  else if (policy == CE_POLICY_AHEAD_NOISE) CE_STEP_POLICY(CE_POLICY_AHEAD_NOISE);
   else CE_STEP_POLICY(CE_POLICY_ARGMAX_F32);
 #undef CE_STEP_POLICY_CM
 #undef CE_STEP_POLICY

@@ -227,12 +227,24 @@ class BatchedEnv:
 
     def step_policy_device(self, policy_ptr, mode, env_begin=0, env_count=None, stream=None):
         """ce_step_policy: step envs [env_begin, env_begin + env_count) with the action selection fused into the step kernel —
-        mode "bytes" (uint8 [E, n], action = byte mod |A|) or "argmax" (float32 [E, n, |A|] scores, first maximum); the
-        ids taken land in `actions_taken`"""
+        mode "bytes" (uint8 [E, n], action = byte mod |A|), "argmax" (float32 [E, n, |A|] scores, first maximum) or "ahead_noise"
+        (uint8 [E, n] noise plane, read and written: += green of the pixel ahead in the previous view, action = byte mod |A|);
+        the ids taken land in `actions_taken`"""
         self._dirty()
-        m = {"bytes": _lib.POLICY_BYTES_MOD, "argmax": _lib.POLICY_ARGMAX_F32}[mode]
+        m = self._POLICY_MODES[mode]
         cnt = self.E - env_begin if env_count is None else env_count
         check(self._L.ce_step_policy(self._h, policy_ptr, m, int(env_begin), int(cnt), stream), self._h, "ce_step_policy")
+
+    _POLICY_MODES = {"bytes": _lib.POLICY_BYTES_MOD, "argmax": _lib.POLICY_ARGMAX_F32, "ahead_noise": _lib.POLICY_AHEAD_NOISE}
+
+    def step_policy_sliced(self, policy_ptr, mode, streams=None, num_slices=None):
+        """ce_step_policy_sliced: one policy step of ALL envs as env slices on `streams` (raw hipStream_t handles), the launch
+        loop in C — one host call per sampler tick.  mode "ahead_noise": `policy_ptr` is a uint8 [E, n] noise plane the
+        launch reads AND writes (the benchmark policy evaluated inside the step kernel, contracts_engine.h)"""
+        self._dirty()
+        S = len(streams) if streams else (num_slices or 1)
+        arr = (C.c_void_p * S)(*streams) if streams else None
+        check(self._L.ce_step_policy_sliced(self._h, policy_ptr, self._POLICY_MODES[mode], S, arr), self._h, "ce_step_policy_sliced")
 
     # ---- host boundary helpers (page-locked staging, asynchronous copies, threaded format conversion) ------------
     def host_alloc(self, shape, dtype):

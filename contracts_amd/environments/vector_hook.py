@@ -83,21 +83,33 @@ def _engine_config(base):
     return None
 
 
+_TWIN = {"state": None, "rs": None}  # private generator behind the default seeds (see vector_seed0)
+
+
 def vector_seed0(env):
-    """seed of replica 0 (replica i gets seed0 + i): the value last passed to `env.seed()`, else what the process-global
-    np.random WOULD draw next — taken from a copy of its state, so that seeded scripts stay reproducible while the global
-    stream, which the rng="global" adapters mirror for reference parity, does not move"""
+    """seed of replica 0 (replica i gets seed0 + i): the value last passed to `env.seed()`, else the next draw of a PRIVATE
+    generator started from a copy of the process-global np.random state — seeded scripts stay reproducible, the global stream
+    (which the rng="global" adapters mirror for reference parity) does not move, and two unseeded hooks of one process (a
+    train and an eval vector env, two env kinds) draw DIFFERENT seeds: the private generator advances from call to call.  It is
+    restarted from the global state whenever that has changed since the last call (np.random.seed(), or draws in between)."""
     s = getattr(env, "_vector_seed0", None)
     if s is None:
-        twin = np.random.RandomState()
-        twin.set_state(np.random.get_state())
-        s = int(twin.randint(0, 2 ** 31 - 1))
+        st = np.random.get_state()
+        key = (st[0], st[1].tobytes(), st[2], st[3], st[4])
+        if _TWIN["state"] != key:
+            _TWIN["state"] = key
+            _TWIN["rs"] = np.random.RandomState()
+            _TWIN["rs"].set_state(st)
+        s = int(_TWIN["rs"].randint(0, 2 ** 31 - 1))
     return int(s)
 
 
 def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_batch_wait_ms=0,
-                restart_failed_sub_environments=False, seed0=None):
-    """see the module docstring; `env` is a base adapter or a SeparateContractSubgameStage around one"""
+                restart_failed_sub_environments=False, seed0=None, recycle_dicts=None):
+    """see the module docstring; `env` is a base adapter or a SeparateContractSubgameStage around one.
+    `recycle_dicts` (BatchedBaseEnv's knob, vector_env.py module docstring): None = the env's `vector_recycle_dicts`
+    attribute / constructor kwarg, else CONTRACTS_AMD_VECTOR_RECYCLE (auto | on | off | checked), else "auto" — recycled
+    dictionary trees only where RLlib copies every observation at once (Dict spaces: the grid kinds); Box-space kinds rebuild."""
     from .two_stage_train import SeparateContractSubgameStage
     num_envs = int(num_envs)
     base, contract_kw, convolutional = env, {}, True
@@ -128,12 +140,29 @@ def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_ba
         # np.random.seed() takes 32 bits: replica i is seeded seed0 + i, and none of them may leave that range
         raise ValueError("to_base_env: seed %d + %d sub-envs runs past 2**32 - 1 (np.random.seed's range); seed the env lower "
                          "or use vector_rng='counter' (64-bit seeds)" % (seed0, num_envs))
+    if recycle_dicts is None:
+        recycle_dicts = getattr(env, "vector_recycle_dicts", None)
+    if recycle_dicts is None:
+        recycle_dicts = getattr(base, "vector_recycle_dicts", None)
+    if recycle_dicts is None:
+        import os
+        recycle_dicts = os.environ.get("CONTRACTS_AMD_VECTOR_RECYCLE", "auto")
+    if isinstance(recycle_dicts, str):
+        word = recycle_dicts.strip().lower()
+        if word not in _RECYCLE_WORDS:
+            raise ValueError("recycle_dicts / CONTRACTS_AMD_VECTOR_RECYCLE: %r is not one of %s" % (recycle_dicts, sorted(_RECYCLE_WORDS)))
+        recycle_dicts = _RECYCLE_WORDS[word]
     return BatchedBaseEnv(kind, num_envs, base.num_agents, seed0=seed0, convolutional=convolutional,
-                          device=getattr(base, "_device", 0), **kw)
+                          device=getattr(base, "_device", 0), recycle_dicts=recycle_dicts, **kw)
+
+
+_RECYCLE_WORDS = {"auto": "auto", "checked": "checked", "on": True, "true": True, "1": True, "off": False, "false": False, "0": False}
 
 
 class VectorHookMixin:
     """gives an env class RLlib's `to_base_env` entry point (same signature), resolved by `to_base_env` above"""
+
+    vector_recycle_dicts = None  # None = CONTRACTS_AMD_VECTOR_RECYCLE / "auto"; set on the instance (or class) to force a mode
 
     def to_base_env(self, make_env=None, num_envs=1, remote_envs=False, remote_env_batch_wait_ms=0,
                     restart_failed_sub_environments=False):

@@ -17,13 +17,25 @@ Built to stay usable at E = 16 384:
     caller never asks about is reset as well (RLlib's sampler resets every done sub-env, so it never notices);
     `batch_done_resets=False` resets exactly the env asked for;
   * `poll_tensors()` / `send_actions_array()` skip Python containers altogether (observations stay in HBM);
-  * grid and feature-vector kinds, `recycle_dicts=True` (the default): the dictionaries of a tick are not rebuilt but RECYCLED.  Two generations
+  * `recycle_dicts` (grid and feature-vector kinds): the dictionaries of a tick are not rebuilt but RECYCLED.  Two generations
     of complete dictionary trees ({env: {agent: {"image": ..}}}, rewards, dones, infos) are kept over page-locked snapshot
     buffers; a tick copies the step's results into the older generation asynchronously (one DMA per field), converts the
     observations to the reference's float64 on worker threads, and rewrites only the dictionary entries whose values
-    changed (C loops, `csrc/ce_pydict.c`) — ~10 ms per tick at E = 16 384 instead of ~290 ms.  CONTRACT: what `poll()`
-    returned at tick t stays intact through tick t + 1 and is overwritten by tick t + 2 (RLlib copies observations into
-    its sample batches at once; a caller that keeps them longer copies them, or passes `recycle_dicts=False`).
+    changed (C loops, `csrc/ce_pydict.c`) — ~8 ms per tick at E = 16 384 instead of ~290 ms.  CONTRACT: everything `poll()`
+    returned at tick t — observation arrays, the info dictionaries and their `feature_obs` arrays, reward and done
+    dictionaries — stays intact through tick t + 1 and is REWRITTEN IN PLACE by tick t + 2.  A consumer may therefore keep a
+    reference for one tick at most; anything it wants longer it must copy.
+      - `"auto"` (the default): recycled for the grid kinds, whose observation space is a Dict — RLlib's
+        DictFlatteningPreprocessor copies every observation into a fresh flat array before its collectors see it — and
+        REBUILT per tick (`False`) for the feature-vector kinds, whose Box observations RLlib's NoPreprocessor / NoFilter pass
+        through by reference into the rollout fragment (a recycled buffer would alias every row of it).  Under "auto" the grid
+        kinds' info dictionaries are still recycled: a consumer that keeps `infos` beyond one tick (SampleBatch.INFOS does)
+        and reads them later wants `False`.
+      - `True` / `False`: force either path.
+      - `"checked"` (debug): the recycled data path with the contract ENFORCED — the generation about to be rewritten is
+        poisoned first (NaN fill of its observation / feature blocks), and every array / info dictionary handed out is
+        stamped with its generation's epoch and raises `StaleDictError` when it is read after that generation moved on.  Run
+        a new sampler under it once; it costs the per-tick construction of the stamped wrappers (as slow as `False`).
 
 When `ray` is importable the class derives from `ray.rllib.env.BaseEnv`, otherwise it is duck-typed; nothing else in it
 depends on RLlib.  Each sub-env keeps a private RNG stream seeded `seed0 + env_index_base + i` (the batched API's
@@ -145,6 +157,119 @@ class _SubEnvs:
         return (self[e] for e in range(len(self)))
 
 
+class StaleDictError(RuntimeError):
+    """recycle_dicts="checked": something poll() handed out two or more ticks ago was read after its buffers were rewritten"""
+
+
+def _stale(owner, epoch):
+    if owner is not None and owner.epoch != epoch:
+        raise StaleDictError("an object handed out by poll() %d tick(s) of its generation ago was read after that generation's "
+                             "buffers were rewritten (recycle_dicts contract: keep references for one tick at most, copy what "
+                             "must live longer, or pass recycle_dicts=False)" % (owner.epoch - epoch))
+
+
+class _EpochArray(np.ndarray):
+    """recycle_dicts="checked": a view of a recycled buffer that remembers the epoch of its generation and refuses to be read
+    once the generation has moved on (indexing, ufuncs, numpy functions, copies, conversions; np.asarray() of it bypasses every
+    hook and reads the poison instead)"""
+    _ce_owner, _ce_epoch = None, 0
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._ce_owner, self._ce_epoch = getattr(obj, "_ce_owner", None), getattr(obj, "_ce_epoch", 0)
+
+    def _ce_plain(self):
+        _stale(self._ce_owner, self._ce_epoch)
+        return self.view(np.ndarray)
+
+    def __getitem__(self, k):
+        return self._ce_plain()[k]
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        ins = tuple(x._ce_plain() if isinstance(x, _EpochArray) else x for x in inputs)
+        if "out" in kw:
+            kw["out"] = tuple(x._ce_plain() if isinstance(x, _EpochArray) else x for x in kw["out"])
+        return getattr(ufunc, method)(*ins, **kw)
+
+    def __array_function__(self, func, types, args, kwargs):
+        def plain(x):
+            if isinstance(x, _EpochArray):
+                return x._ce_plain()
+            if isinstance(x, (list, tuple)):
+                return type(x)(plain(y) for y in x)
+            return x
+        return func(*plain(args), **{k: plain(v) for k, v in kwargs.items()})
+
+    def copy(self, *a, **kw):
+        return self._ce_plain().copy(*a, **kw)
+
+    def astype(self, *a, **kw):
+        return self._ce_plain().astype(*a, **kw)
+
+    def tolist(self):
+        return self._ce_plain().tolist()
+
+    def __iter__(self):
+        return iter(self._ce_plain())
+
+    def __repr__(self):
+        return repr(self._ce_plain())
+
+    __str__ = __repr__
+
+
+def _stamp(arr, owner):
+    v = arr.view(_EpochArray)
+    v._ce_owner, v._ce_epoch = owner, owner.epoch
+    return v
+
+
+class _EpochDict(dict):
+    """recycle_dicts="checked": an info / observation dictionary stamped like _EpochArray (reads raise once stale)"""
+    __slots__ = ("_ce_owner", "_ce_epoch")
+
+    def __init__(self, owner, items):
+        dict.__init__(self, items)
+        self._ce_owner, self._ce_epoch = owner, owner.epoch
+
+    def _ok(self):
+        _stale(self._ce_owner, self._ce_epoch)
+
+    def __getitem__(self, k):
+        self._ok()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._ok()
+        return dict.get(self, k, d)
+
+    def items(self):
+        self._ok()
+        return dict.items(self)
+
+    def values(self):
+        self._ok()
+        return dict.values(self)
+
+    def keys(self):
+        self._ok()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._ok()
+        return dict.__iter__(self)
+
+    def __contains__(self, k):
+        self._ok()
+        return dict.__contains__(self, k)
+
+    def __eq__(self, other):
+        self._ok()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+
 def _pydict():
     """the C loops of the recycled dict protocol (built by contracts_amd.build next to the engine library)"""
     from . import _ce_pydict
@@ -155,10 +280,11 @@ class _DictGeneration:
     """one generation of a tick's results on the host: page-locked snapshot buffers, the float64 arrays the dictionaries
     hand out views of, and the dictionary trees themselves (built once, refreshed in place every second tick)"""
 
-    def __init__(self, venv):
+    def __init__(self, venv, build_trees=True):
         eng, E, n, keys = venv.engine, venv.num_envs, venv.num_agents, venv._keys
         b = eng.b
         F = b.num_features
+        self.epoch = 0  # recycle_dicts="checked": bumped every time this generation's buffers are about to be rewritten
         self.grid = venv.kind in _GRID
         self.float_rewards = venv._float_rewards
         self.rew = eng.host_alloc((E, n), np.float64 if self.float_rewards else np.int32)
@@ -190,6 +316,9 @@ class _DictGeneration:
         self.key0 = None if venv.kind == "cleanup_features" else "eaten_apples"  # CleanupFeatures' infos carry the second counter only
         self.obs, self.rewards, self.dones, self.infos = {}, {}, {}, {}
         self.agent_infos = []
+        self.second = second
+        if not build_trees:  # "checked": stamped per-tick wrappers instead of persistent trees (BatchedBaseEnv._checked_maps)
+            return
         for e in range(E):
             fe = feat_f64[e]
             c, cp = cobs[e], cparam[e]
@@ -214,12 +343,18 @@ class _DictGeneration:
             self.dones[e] = {"__all__": False, "a0": False, "a1": False}  # the reference's dones dict (cleanup_new.py:242)
         self.reward_list = [self.rewards[e] for e in range(E)]
         self.done_list = [self.dones[e] for e in range(E)]
-        self.second = second
+
+    def poison(self):
+        """"checked": what a holder of this generation's previous hand-out would read from now on is NaN, not plausible data"""
+        self.epoch += 1
+        for a in (self.obs_f64, self.feat_f64, self.obs_vec, self.cobs, self.cparam):
+            if a is not None:
+                a.fill(np.nan)
 
 
 class BatchedBaseEnv(_RLlibBaseEnv):
     def __init__(self, kind, num_envs, num_agents, contract=None, seed0=73907, convolutional=True, batch_done_resets=True,
-                 recycle_dicts=True, **engine_kwargs):
+                 recycle_dicts="auto", **engine_kwargs):
         self.kind, self.num_envs, self.num_agents = kind, int(num_envs), int(num_agents)
         self.contract = contract
         self.convolutional = convolutional
@@ -237,7 +372,14 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         self._reset_obs = {}                       # env_id -> reset observation (or the lazy map of its reset batch)
         self._acted = None                         # selfdrive: [E, n] which agents acted in the last step
         # recycled dict protocol (grid kinds): two generations of dictionary trees over page-locked snapshots
-        self._recycle = bool(recycle_dicts) and kind != "selfdrive"  # (selfdrive's dictionaries change their key sets with the acting cars)
+        # (selfdrive's dictionaries change their key sets with the acting cars: always rebuilt)
+        if recycle_dicts not in ("auto", "checked", True, False):
+            raise ValueError("recycle_dicts must be 'auto', 'checked', True or False, not %r" % (recycle_dicts,))
+        if recycle_dicts == "auto":  # see the module docstring: Dict observation spaces are copied by RLlib's preprocessor
+            recycle_dicts = kind in _GRID
+        self._checked = recycle_dicts == "checked" and kind != "selfdrive"
+        self._recycle = bool(recycle_dicts) and kind != "selfdrive"
+        self.recycle_dicts = "checked" if self._checked else self._recycle
         self._gens, self._gen = [None, None], 0
         self._act_planes, self._act_turn = None, 0
         self._keys_t = tuple(self._keys)
@@ -429,7 +571,9 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         g = self._gen = self._gen ^ 1
         G = self._gens[g]
         if G is None:
-            G = self._gens[g] = _DictGeneration(self)
+            G = self._gens[g] = _DictGeneration(self, build_trees=not self._checked)
+        if self._checked:
+            G.poison()
         # small fields first: one asynchronous copy each behind the step on its stream, ONE synchronize for all of them
         eng.download_async("reward" if G.float_rewards else "base_reward", G.rew)
         eng.download_async("done", G.done)
@@ -454,6 +598,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
                 F = G.feat_f64.shape[2]
                 G.obs_vec[:, :, :F] = G.feat_f64
                 G.obs_vec[:, :, F] = G.theta[:, None]
+                G.obs_vec[:, :, F + 1] = 0.0  # (constant, but "checked" poisons the whole block before every rewrite)
             tm["obs_copy_and_convert_ms"] = (time.perf_counter() - ta) * 1e3
 
         job = _pool().submit(finish_obs)
@@ -465,12 +610,15 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             if G.theta is not None:
                 G.cobs[:, 0] = G.theta
                 G.cparam[:, 0] = G.theta
-            if G.float_rewards:
+            if self._checked:
+                pass  # the stamped wrappers are built per env on access (_checked_maps)
+            elif G.float_rewards:
                 pd.refresh_floats(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
             else:
                 pd.refresh_ints(G.reward_list, self._keys_t, G.rew, G.rew_shadow)
-            pd.refresh_infos(G.agent_infos, G.key0, G.second, G.info, G.info_shadow)
-            pd.refresh_dones(G.done_list, ("__all__", "a0", "a1"), G.done, G.done_shadow)
+            if not self._checked:
+                pd.refresh_infos(G.agent_infos, G.key0, G.second, G.info, G.info_shadow)
+                pd.refresh_dones(G.done_list, ("__all__", "a0", "a1"), G.done, G.done_shadow)
             self._done_ids = {int(e) for e in np.nonzero(G.done)[0]}
             self._episode_over = set(self._done_ids)
             self._reset_obs = {}
@@ -480,7 +628,46 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         t3 = time.perf_counter()
         tm["step_and_small_fields_ms"], tm["refresh_dicts_ms"], tm["wait_for_obs_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
         tm["poll_ms"] = (t3 - t0) * 1e3
+        if self._checked:
+            return self._checked_maps(G)
         return G.obs, G.rewards, G.dones, G.infos, {}
+
+    def _checked_maps(self, G):
+        """recycle_dicts="checked": this tick's results as per-env dictionaries built on access from generation G's buffers, every
+        array an _EpochArray view and every observation / info dictionary an _EpochDict stamped with G's current epoch — equal,
+        value for value, to what the recycled trees hold, but a read after G has moved on raises StaleDictError"""
+        keys, contract, second, key0 = self._keys, bool(self.contract), G.second, G.key0
+        ids = self._env_keys
+        rew, info, done = G.rew.tolist(), G.info.tolist(), G.done.tolist()
+
+        def obs(e):
+            if G.grid:
+                img = G.obs_f64[e]
+                if contract:
+                    c = _stamp(G.cobs[e], G)
+                    return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G)), ("contract", c)))) for i, k in enumerate(keys)))
+                return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G)),))) for i, k in enumerate(keys)))
+            ov = G.obs_vec[e]
+            return _EpochDict(G, ((k, _stamp(ov[i], G)) for i, k in enumerate(keys)))
+
+        def infos(e):
+            fe = G.feat_f64[e]
+            out = {}
+            for i, k in enumerate(keys):
+                it = [(second, info[e][i][1])]
+                if key0 is not None:
+                    it += [("eaten_apples", info[e][i][0]), ("feature_obs", _stamp(fe[i], G))]
+                if contract:
+                    it.append(("contract_param", _stamp(G.cparam[e], G)))
+                out[k] = _EpochDict(G, it)
+            return out
+
+        def dones(e):
+            d = bool(done[e])
+            return {"__all__": d, "a0": d, "a1": d}
+
+        return (_LazyEnvMap(ids, obs), _LazyEnvMap(ids, lambda e: dict(zip(keys, rew[e]))), _LazyEnvMap(ids, dones),
+                _LazyEnvMap(ids, infos), {})
 
     def send_actions_array(self, actions, active=None):
         """the same tick from a dense [E, n] array (uint8 action ids / float32 accelerations): no per-env containers"""

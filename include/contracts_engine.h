@@ -328,7 +328,17 @@ int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint3
  * (CE_EINVAL otherwise); slices, streams and graph capture exactly as ce_step_range. */
 #define CE_POLICY_BYTES_MOD 1
 #define CE_POLICY_ARGMAX_F32 2
+/*   CE_POLICY_AHEAD_NOISE uint8 [E][n] noise plane, READ AND WRITTEN by the launch (round 5; an addition, no layout changed: ABI 3): noise[e][a] += green channel of view
+ *                         pixel (6, 7) — the cell in front of the agent — of the observation the previous step or reset left in
+ *                         ce_buffers.obs, modulo 256; action = the new byte mod |A|.  This is bench.py's closed-loop policy
+ *                         evaluated inside the step kernel's action load: the loop observation -> action -> step closes on the
+ *                         device with ONE launch per env slice and tick.  A policy that is a network keeps its own kernel and
+ *                         hands its output over with one of the two modes above. */
+#define CE_POLICY_AHEAD_NOISE 3
 int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream);
+/* ce_step_policy over all envs as `num_slices` contiguous env slices, slice i launched on streams[i] (NULL = the null stream): the
+ * launch loop of a sampler tick in C — ONE host call per tick (ce_rollout's slicing rule; round 5 addition). */
+int ce_step_policy_sliced(ce_handle h, const void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams);
 
 /* Launch loop in C for pre-supplied actions (benchmarks, random-policy rollouts): `num_steps` consecutive
  * steps over all envs, each issued as `num_slices` ce_step_range launches on streams[0..num_slices-1] (NULL =

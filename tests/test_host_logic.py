@@ -290,6 +290,9 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
         def download(self, field, *a, **k):
             return np.zeros((1, 628 * 2), np.uint32) if field == "rng" else np.zeros((1, 8), np.float64)
 
+        def prefetch(self, *a, **k):
+            pass
+
         def close(self):
             pass
 
@@ -380,7 +383,40 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     fresh.to_base_env(num_envs=4)
     after = np.random.get_state()
     assert np.array_equal(after[1], before[0]) and after[2] == before[1]
-    assert made[-1].seeded == int(np.random.RandomState(4242).randint(0, 2 ** 31 - 1))
+    twin = np.random.RandomState(4242)
+    first = int(twin.randint(0, 2 ** 31 - 1))
+    assert made[-1].seeded == first
+    # a second unseeded hook of the same process (train + eval vector envs, two env kinds) gets a DIFFERENT seed — the private
+    # generator moves on — while the global stream still has not moved; re-seeding the script reproduces the sequence
+    made.clear()
+    HarvestEnv(num_agents=3, horizon=50, rng="private").to_base_env(num_envs=4)
+    assert made[-1].seeded == int(twin.randint(0, 2 ** 31 - 1)) != first
+    assert np.array_equal(np.random.get_state()[1], before[0]) and np.random.get_state()[2] == before[1]
+    np.random.seed(4243)  # the global state changed: the private generator restarts from it
+    made.clear()
+    HarvestEnv(num_agents=3, horizon=50, rng="private").to_base_env(num_envs=4)
+    assert made[-1].seeded == int(np.random.RandomState(4243).randint(0, 2 ** 31 - 1))
+
+    # recycle_dicts: "auto" recycles the dictionary trees only where RLlib copies every observation at once (Dict spaces: the
+    # grid kinds); the Box-space feature kinds rebuild per tick; the env attribute / the environment variable force a mode
+    from contracts_amd.environments.feature_envs import HarvestFeatures
+    assert plain.to_base_env(num_envs=4).recycle_dicts is True
+    hf = HarvestFeatures(num_agents=2, horizon=50, rng="private")
+    assert hf.to_base_env(num_envs=4).recycle_dicts is False
+    hf.vector_recycle_dicts = True
+    assert hf.to_base_env(num_envs=4).recycle_dicts is True
+    hf.vector_recycle_dicts = None
+    monkeypatch.setenv("CONTRACTS_AMD_VECTOR_RECYCLE", "checked")
+    assert hf.to_base_env(num_envs=4).recycle_dicts == "checked" and plain.to_base_env(num_envs=4).recycle_dicts == "checked"
+    monkeypatch.setenv("CONTRACTS_AMD_VECTOR_RECYCLE", "off")
+    assert plain.to_base_env(num_envs=4).recycle_dicts is False
+    monkeypatch.setenv("CONTRACTS_AMD_VECTOR_RECYCLE", "sometimes")
+    with pytest.raises(ValueError, match="CONTRACTS_AMD_VECTOR_RECYCLE"):
+        plain.to_base_env(num_envs=4)
+    monkeypatch.delenv("CONTRACTS_AMD_VECTOR_RECYCLE")
+    assert car.to_base_env(num_envs=4).recycle_dicts is False  # selfdrive: key sets change with the acting cars, always rebuilt
+    with pytest.raises(ValueError):
+        vector_env.BatchedBaseEnv("cleanup", 4, 2, recycle_dicts="maybe")
     # np.random.seed's range: seed0 + index must stay within 32 bits on the reference's stream; the counter stream takes 64
     big = HarvestEnv(num_agents=3, horizon=50, rng="private")
     big.seed(0xffffffff - 2)
@@ -408,3 +444,35 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     assert SeparateContractSubgameStage(CleanupEnv(num_agents=4, rng="private"), RenamedCleanup(4), 4, True)._host_contract is False
     assert isinstance(SeparateContractSubgameStage(b2, DoubleCleanup(4), 4, True).to_base_env(make_env=lambda i: b2, num_envs=2),
                       SubEnvBaseEnv)
+
+
+def test_checked_recycling_wrappers_refuse_stale_reads():
+    """recycle_dicts="checked" (vector_env.py): arrays / dictionaries stamped with their generation's epoch read normally while
+    the generation stands and raise StaleDictError once it has moved on, through every ordinary way of reading them"""
+    from contracts_amd.vector_env import StaleDictError, _EpochArray, _EpochDict, _stamp
+
+    class Gen:
+        epoch = 3
+
+    g = Gen()
+    buf = np.arange(12.0).reshape(3, 4)
+    row = _stamp(buf[1], g)
+    d = _EpochDict(g, (("image", row), ("n", 5)))
+    assert isinstance(row, _EpochArray) and row.base is not None and np.shares_memory(row, buf)
+    assert row[2] == 6.0 and float((row + 1).sum()) == 26.0 and type(row + 1) is np.ndarray
+    assert np.array_equal(np.concatenate((row, row)), np.r_[buf[1], buf[1]]) and row.copy().tolist() == [4.0, 5.0, 6.0, 7.0]
+    assert d["n"] == 5 and list(d) == ["image", "n"] and d.get("image") is row and "n" in d and len(d) == 2
+    sub = row[1:]  # plain from here on: a value already read is the consumer's
+    assert type(sub) is np.ndarray
+    g.epoch += 1  # the generation's buffers are about to be rewritten
+    buf.fill(np.nan)
+    for read in (lambda: row[0], lambda: row + 1, lambda: np.concatenate((row, row)), lambda: row.copy(), lambda: row.tolist(),
+                 lambda: list(row), lambda: repr(row), lambda: np.add(1.0, row), lambda: row.astype(np.float32), lambda: d["n"],
+                 lambda: d.get("n"), lambda: list(d.items()), lambda: list(d), lambda: "n" in d, lambda: row.sum(),
+                 lambda: np.copy(row), lambda: np.mean(row)):
+        with pytest.raises(StaleDictError):
+            read()
+    assert np.isnan(np.asarray(row)).all()  # the one path no hook sees reads the poison, not plausible data
+    fresh = _stamp(buf[0], g)  # the generation's next hand-out is valid again
+    buf[0] = 1.0
+    assert fresh.sum() == 4.0

@@ -98,3 +98,43 @@ def test_policy_step_misuse():
     with pytest.raises(EngineError):
         env.step_policy_device(0, "bytes")
     env.close()
+
+
+@pytest.mark.parametrize("kind,n,firing,rng,sliced", [("cleanup", 8, False, "mt19937", True), ("cleanup", 3, True, "mt19937", False),
+                                                      ("harvest", 8, False, "mt19937", True), ("harvest", 5, True, "counter", False),
+                                                      ("cleanup", 8, False, "counter", True)])
+def test_policy_ahead_noise_closes_the_loop_in_the_kernel(kind, n, firing, rng, sliced):
+    """CE_POLICY_AHEAD_NOISE: the benchmark's closed-loop policy inside the step kernel — the env's noise byte moves on by the
+    green channel of view pixel (6, 7) of the PREVIOUS observation (the one a reset or the last step left in `obs`), the action is
+    the new byte mod |A|.  A host restatement of that rule over the oracle's observations + the oracle stepped with the resulting
+    actions must reproduce every field, the noise plane and `actions_taken`, across in-launch auto-resets (the reset observation
+    is the next tick's input), as single launches, explicit slices and ce_step_policy_sliced on three streams."""
+    import torch
+    E, T = 101, 60
+    contract = "cleanup" if kind == "cleanup" else "harvest_local"
+    env, orc = _pair(kind, E, n, contract=contract, firing=firing, horizon=13, auto_reset=True, rng=rng)
+    A = env.num_actions
+    rs = np.random.RandomState(5)
+    noise = rs.randint(0, 256, size=(E, n)).astype(np.uint8)
+    dev = torch.from_numpy(noise.copy()).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    for t in range(T):
+        ahead = np.asarray(orc.obs)[:, :, 6, 7, 1]
+        noise = (noise.astype(np.uint32) + ahead).astype(np.uint8)  # modulo 256
+        want = (noise % A).astype(np.uint8)
+        if sliced and t % 3 == 0:
+            env.step_policy_sliced(dev.data_ptr(), "ahead_noise", [s.cuda_stream for s in streams])
+        elif t % 3 == 1:
+            env.step_policy_device(dev.data_ptr(), "ahead_noise", 0, 37)
+            env.step_policy_device(dev.data_ptr(), "ahead_noise", 37, E - 37)
+        else:
+            env.step_policy_device(dev.data_ptr(), "ahead_noise")
+        torch.cuda.synchronize()
+        assert np.array_equal(env.download("actions_taken"), want), "actions step %d" % t
+        assert np.array_equal(dev.cpu().numpy(), noise), "noise plane step %d" % t
+        orc.step(want)
+        _same(env, orc, "step %d" % t)
+    assert len(np.unique(env.download("actions_taken"))) == A  # the loop wanders over the whole action space
+    env.check_faults()
+    env.close()

@@ -514,3 +514,79 @@ def test_recycled_dict_protocol_equals_the_rebuilt_one(kind, n, contract):
         fast.poll()
     fast.stop()
     slow.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,contract", [("harvest_features", 2, "harvest_local"), ("harvest_features", 2, None), ("cleanup", 3, "cleanup"),
+                                             ("cleanup_features", 2, None)])
+def test_a_sampler_that_holds_observations_for_several_ticks(kind, n, contract):
+    """What RLlib's collectors do with a Box observation space (NoPreprocessor / NoFilter hand the env's ndarray through by
+    reference, the rollout fragment keeps it): a fake sampler keeps every obs / info object poll() returned for 1, 2 and 3 ticks
+    and then reads it.  The DEFAULT hook of the Box-space feature kinds (recycle_dicts="auto" -> rebuilt per tick) and every
+    hook with recycle_dicts=False must give it back unchanged; recycle_dicts="checked" gives it back unchanged after one tick
+    — the documented contract of the recycled trees — and raises StaleDictError after two or three, with the raw buffers
+    poisoned (NaN), instead of handing out a later tick's values; tick for tick its values equal the rebuilt path's."""
+    import copy
+    from contracts_amd.vector_env import BatchedBaseEnv, StaleDictError
+    E, T = 40, 9
+    kw = dict(contract=contract, seed0=55, horizon=50)
+    keys = ["a%d" % i for i in range(n)]
+    box_space = kind in ("harvest_features", "cleanup_features")
+    default = BatchedBaseEnv(kind, E, n, **kw)
+    assert default.recycle_dicts is (not box_space)
+    rebuilt = default if box_space else BatchedBaseEnv(kind, E, n, recycle_dicts=False, **kw)
+    checked = BatchedBaseEnv(kind, E, n, recycle_dicts="checked", **kw)
+    assert checked.recycle_dicts == "checked"
+    rs = np.random.RandomState(8)
+    na = default.engine.num_actions
+    sample = (0, E // 3, E - 1)
+
+    def equal(a, b):
+        if isinstance(a, dict):
+            return list(a) == list(b) and all(equal(a[k], b[k]) for k in a)
+        if isinstance(a, np.ndarray):
+            return a.shape == b.shape and np.array_equal(np.asarray(a), np.asarray(b))
+        return a == b
+
+    for v in {id(default): default, id(rebuilt): rebuilt, id(checked): checked}.values():
+        v.poll()
+    held = {"rebuilt": [], "checked": []}
+    stale_seen = 0
+    for t in range(T):
+        a = rs.randint(na, size=(E, n))
+        ad = {e: {k: int(a[e, i]) for i, k in enumerate(keys)} for e in range(E)}
+        out = {}
+        for name, v in (("rebuilt", rebuilt), ("checked", checked)):
+            v.send_actions(ad)
+            o, r, d, i, _ = v.poll()
+            out[name] = (o, i)
+            held[name].append(({e: o[e] for e in sample}, {e: i[e] for e in sample},
+                               copy.deepcopy({e: {k: (np.array(x) if isinstance(x, np.ndarray) else {kk: np.array(xx) for kk, xx in x.items()})
+                                                   for k, x in o[e].items()} for e in sample}),
+                               copy.deepcopy({e: {k: {kk: (np.array(xx) if isinstance(xx, np.ndarray) else xx) for kk, xx in inf.items()}
+                                                   for k, inf in i[e].items()} for e in sample})))
+        for e in sample:  # the stamped hand-out holds the same values as the rebuilt one, this tick
+            assert equal(out["checked"][0][e], out["rebuilt"][0][e]) and equal(out["checked"][1][e], out["rebuilt"][1][e]), (t, e)
+        for age in (1, 2, 3):
+            if t - age < 0:
+                continue
+            ho, hi, co, ci = held["rebuilt"][t - age]
+            for e in sample:  # rebuilt per tick: what the sampler kept is what it was given
+                assert equal(ho[e], co[e]) and equal(hi[e], ci[e]), ("rebuilt", t, age, e)
+            ho, hi, co, ci = held["checked"][t - age]
+            if age == 1:
+                for e in sample:
+                    assert equal(ho[e], co[e]) and equal(hi[e], ci[e]), ("checked", t, age, e)
+            else:
+                for e in sample:
+                    with pytest.raises(StaleDictError):
+                        equal(ho[e], co[e])
+                    with pytest.raises(StaleDictError):
+                        equal(hi[e], ci[e])
+                    stale_seen += 1
+                # the raw memory behind an array kept from that tick was poisoned before it was rewritten... and has been
+                # rewritten since (age 2: by this very tick); what np.asarray() of the stale wrapper reads is never the kept value's
+                # owner any more — the wrapper's hooks are what protects the consumer
+    assert stale_seen > 0
+    for v in {id(default): default, id(rebuilt): rebuilt, id(checked): checked}.values():
+        v.stop()

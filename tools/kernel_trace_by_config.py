@@ -15,7 +15,7 @@ import sys
 
 CONFIGS = {  # workgroups of one env slice (3 slices per rank) -> BASELINE config
     ("k_grid_step<0, 8, 0>", 5461): "C4", ("k_grid_step<0, 8, 0>", 5462): "C4", ("k_grid_rollout<0, 8, 0>", 5461): "C4 fused", ("k_grid_rollout<0, 8, 0>", 5462): "C4 fused",
-    ("k_grid_step_duo<0, 4>", 1365): "C2", ("k_grid_step_duo<0, 4>", 1366): "C2", ("k_grid_step<0, 4, 0>", 1365): "C2 (one wave per env)", ("k_grid_step<0, 4, 0>", 1366): "C2 (one wave per env)", ("k_grid_rollout<0, 4, 4>", 1365): "C2 fused", ("k_grid_rollout<0, 4, 4>", 1366): "C2 fused",
+    ("k_grid_step<0, 4, 0>", 1365): "C2", ("k_grid_step<0, 4, 0>", 1366): "C2", ("k_grid_rollout<0, 4, 4>", 1365): "C2 fused", ("k_grid_rollout<0, 4, 4>", 1366): "C2 fused",
     ("k_grid_step<1, 8, 0>", 5461): "C3", ("k_grid_step<1, 8, 0>", 5462): "C3", ("k_grid_rollout<1, 7, 8>", 5461): "C3 fused", ("k_grid_rollout<1, 7, 8>", 5462): "C3 fused",
     ("k_sd_step<4>", 683): "C5", ("k_sd_rollout<4>", 683): "C5 fused",
     ("k_feat_step_quad", 1366): "C1", ("k_feat_step_quad", 1365): "C1", ("k_feat_rollout_quad", 1366): "C1 fused", ("k_feat_rollout_quad", 1365): "C1 fused",
