@@ -68,6 +68,26 @@ def fingerprint():
     return {"files": files, "flags": FLAGS}
 
 
+def kernels_sha16(fp=None):
+    """one hash for "the kernel sources this library was built from": every source / header by content + the flags"""
+    fp = fp or fingerprint()
+    blob = json.dumps(fp, sort_keys=True).encode()
+    return hashlib.sha256(blob).hexdigest()[:16]
+
+
+def git_state():
+    """(HEAD, sources differ from HEAD) of the repository the sources sit in; (None, None) outside a work tree (the GPU box
+    receives a snapshot without .git: the record written at build time on the build box travels with the library)"""
+    root = os.path.dirname(HERE)
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "contracts_amd/csrc", "include"],
+                               capture_output=True, text=True, check=True).stdout.strip() != ""
+        return head, dirty
+    except (OSError, subprocess.CalledProcessError):
+        return None, None
+
+
 def last_build():
     try:
         with open(INFO) as f:
@@ -118,11 +138,31 @@ def build(force=False, verbose=False):
         build_pydict(verbose)
         ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
         with open(INFO, "w") as f:
-            json.dump({"fingerprint": fingerprint(), "lib_sha16": _sha16(LIB), "compile_seconds": round(time.time() - t0, 1),
+            head, dirty = git_state()
+            json.dump({"fingerprint": fingerprint(), "kernels_sha16": kernels_sha16(), "git_head": head, "git_dirty_sources": dirty,
+                       "lib_sha16": _sha16(LIB), "compile_seconds": round(time.time() - t0, 1),
                        "hipcc": ver[0] if ver else "", "translation_units": SOURCES, "offload_arch": "gfx950",
                        "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}, f, indent=1)
     return lib
 
 
+def provenance():
+    """What a measurement taken with the in-tree library may be attributed to, or the reason it may not be attributed at all:
+    the library must be the one the record describes, built from the sources that lie here, and those sources must have been
+    a committed state (tools/collect_profiles.sh refuses to write profile sets otherwise; bench.py quotes it beside `traffic`)"""
+    rec = last_build()
+    if rec is None or needs_build():
+        return None, "the in-tree library is not a build of the sources that lie here (python -m contracts_amd.build)"
+    if rec.get("git_head") is None:
+        return None, "the build record carries no git HEAD (built outside a work tree)"
+    if rec.get("git_dirty_sources"):
+        return None, "the library was built from kernel sources that differ from HEAD %s (commit, rebuild, collect)" % rec["git_head"][:12]
+    return {"git_head": rec["git_head"], "kernels_sha16": rec.get("kernels_sha16"), "lib_sha16": rec["lib_sha16"], "built_at": rec["built_at"]}, None
+
+
 if __name__ == "__main__":
+    if "--provenance" in sys.argv:  # exit code 0 + JSON when measurements may be attributed to a commit, else 3 + the reason
+        prov, why = provenance()
+        print(json.dumps(prov) if prov else why)
+        sys.exit(0 if prov else 3)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -609,6 +609,7 @@ class BatchedBaseEnv(_RLlibBaseEnv):
                 raise _lib.EngineError("env faults: %s" % {int(i): int(G.err[i]) for i in bad[:8]})
             if G.theta is not None:
                 G.cobs[:, 0] = G.theta
+                G.cobs[:, 1] = 0.0  # (constant, but "checked" poisons the block before every rewrite)
                 G.cparam[:, 0] = G.theta
             if self._checked:
                 pass  # the stamped wrappers are built per env on access (_checked_maps)

@@ -476,3 +476,27 @@ def test_checked_recycling_wrappers_refuse_stale_reads():
     fresh = _stamp(buf[0], g)  # the generation's next hand-out is valid again
     buf[0] = 1.0
     assert fresh.sum() == 4.0
+
+
+def test_profile_provenance_rules(monkeypatch):
+    """contracts_amd.build.provenance(): a measurement may be attributed to a commit only when the in-tree library is a build of
+    the sources that lie here and those sources were a committed state when it was built (tools/collect_profiles.sh refuses to
+    write a profile set otherwise; bench.py quotes git_head / kernels_sha16 beside `roofline.traffic`)"""
+    from contracts_amd import build as b
+    rec = {"git_head": "a" * 40, "git_dirty_sources": False, "kernels_sha16": "k" * 16, "lib_sha16": "l" * 16, "built_at": "now"}
+    monkeypatch.setattr(b, "last_build", lambda: dict(rec))
+    monkeypatch.setattr(b, "needs_build", lambda: False)
+    prov, why = b.provenance()
+    assert why is None and prov["git_head"] == "a" * 40 and prov["kernels_sha16"] == "k" * 16
+    monkeypatch.setattr(b, "needs_build", lambda: True)  # sources edited since the build
+    assert b.provenance()[0] is None and "not a build of the sources" in b.provenance()[1]
+    monkeypatch.setattr(b, "needs_build", lambda: False)
+    monkeypatch.setattr(b, "last_build", lambda: dict(rec, git_dirty_sources=True))  # built from uncommitted kernel sources
+    assert b.provenance()[0] is None and "differ from HEAD" in b.provenance()[1]
+    monkeypatch.setattr(b, "last_build", lambda: dict(rec, git_head=None))
+    assert b.provenance()[0] is None and "no git HEAD" in b.provenance()[1]
+    # the hash names the kernel sources and the flags, nothing else
+    fp = b.fingerprint()
+    assert b.kernels_sha16(fp) == b.kernels_sha16(dict(fp)) and len(b.kernels_sha16(fp)) == 16
+    fp2 = {"files": dict(fp["files"], **{"ce_api.hip": "0" * 16}), "flags": fp["flags"]}
+    assert b.kernels_sha16(fp2) != b.kernels_sha16(fp)

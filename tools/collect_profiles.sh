@@ -8,7 +8,12 @@
 # Output under gpurun_out/prof_$TAG; summarise on the build box with tools/summarise_profiles.py.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
+# A profile set is evidence about ONE commit: refuse to collect unless the in-tree library is a build of the sources that lie
+# here AND those sources were a committed state when it was built (contracts_amd/build.py: provenance; the record travels with
+# the library, the snapshot has no .git).  The summariser on the build box then refuses if HEAD has moved since.
+PROV=$(cd $R && python3 -m contracts_amd.build --provenance) || { echo "collect_profiles: refused — $PROV"; exit 3; }
 rm -rf $OUT; mkdir -p $OUT
+echo "$PROV" > $OUT/provenance.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
 tail -1 $OUT/kt_bench_line.json | cut -c1-200

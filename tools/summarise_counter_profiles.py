@@ -4,12 +4,15 @@
     python tools/summarise_counter_profiles.py gpurun_out/prof_r03_counter r03
 """
 
-import csv, json, sys
+import csv, json, subprocess, sys
 out, tag = sys.argv[1], sys.argv[2]
+prov = json.load(open(out + "/provenance.json"))  # written by the collector: the commit the library was built from
+if subprocess.run(["git", "diff", "--quiet", prov["git_head"], "--", "contracts_amd/csrc", "include"]).returncode != 0 and "--allow-stale" not in sys.argv:
+    sys.exit("summarise_counter_profiles: refused — the kernel sources differ from %s, the commit this set was measured on" % prov["git_head"][:12])
 ALGO = {"c4_step": 7235, "c4_fused": 7235, "c3_step": 7313}
 res = {"how": "tools/collect_counter_profiles.sh: separate rocprofv3 --pmc passes of tools/pmc_driver.py --rng counter (64 measured steps, 16 384 envs, "
               "three slices); FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md); kernel trace of a 400-step per-step run",
-       "kernels": {}}
+       "provenance": prov, "kernels": {}}
 for k, algo in ALGO.items():
     s = json.load(open("%s/pmc_%s.json" % (out, k)))
     per = s["per_env_step"]

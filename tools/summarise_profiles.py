@@ -21,6 +21,15 @@ KIND = {"step": ("cleanup", 8), "fused": ("cleanup", 8), "sd_step": ("selfdrive"
 TRAFFIC_KEY = {"step": "per_step", "fused": "fused", "sd_step": "per_step_C5", "sd_fused": "fused_C5", "c3_step": "per_step_C3",
                "c3_fused": "fused_C3", "c2_step": "per_step_C2", "c2_fused": "fused_C2", "c1_step": "per_step_C1", "c1_fused": "fused_C1"}
 
+# provenance: the set was collected with a library built from committed sources (tools/collect_profiles.sh refuses otherwise);
+# here, on the build box, refuse to write profiles/ if the kernel sources have moved since (a stale set is not evidence about HEAD)
+import subprocess
+prov = json.load(open(os.path.join(src, "provenance.json")))
+changed = subprocess.run(["git", "diff", "--quiet", prov["git_head"], "--", "contracts_amd/csrc", "include"]).returncode != 0
+if changed and "--allow-stale" not in sys.argv:
+    sys.exit("summarise_profiles: refused — the kernel sources differ from %s, the commit this set was measured on "
+             "(re-collect at HEAD, or pass --allow-stale to file it under that commit's name)" % prov["git_head"][:12])
+
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
 shutil.copy(max(stats, key=os.path.getmtime), "profiles/%s_kernel_stats.csv" % tag)
 by_cfg = os.path.join(src, "kernel_stats_by_config.csv")
@@ -39,7 +48,7 @@ json.dump(json.loads(line), open("profiles/%s_bench_line.json" % tag, "w"), inde
 out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 20 "
        "--no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 ; PMC: separate `rocprofv3 --pmc <set>` passes of tools/pmc_driver.py (64 measured steps after "
        "a 300-step pre-roll run with the other mode's kernel), summed over the dispatches of the kernel and divided by envs x steps",
-       "kernels": {}}
+       "provenance": prov, "kernels": {}}
 traffic = {}
 for key in ALGO:
     path = os.path.join(src, "pmc_%s.json" % key)
@@ -68,5 +77,6 @@ try:  # the counter-RNG rows belong to tools/summarise_counter_profiles.py: kept
     traffic.update({k: v for k, v in json.load(open("profiles/traffic.json")).items() if k.endswith("_counter")})
 except (OSError, ValueError):
     pass
+traffic["_provenance"] = dict(prov, profile_set=tag)
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps({k: v.get("hbm", {}).get("hbm_bytes_per_env_step") for k, v in out["kernels"].items()}))
