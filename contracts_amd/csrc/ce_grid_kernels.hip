@@ -826,7 +826,9 @@ template <int KIND> DEVINL void load_rng(Env<KIND>& E, const GridParams& p) {
   wave_sync();
   rng_begin_op(E.rng, E.lane);
 }
-template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
+// `wt`: the key words leave through the L2 (sc1) like the views of the same launch (write_obs: single-step launches of handles
+// that fit the Infinity Cache) — 2.5 KB per env that would otherwise sit dirty in the L2 until the kernel's end
+template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p, bool wt = false) {
   wave_sync();
   if (kCounterRng) {  // only the generation number moves
     if (E.lane == 0) p.rng[(size_t)E.e * kRngRow + 2] = E.rng.gen0 + E.rng.twists;
@@ -837,9 +839,23 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p) {
     const uint4* src = (const uint4*)E.rng.mt;
     const u32 q2 = min(E.lane + 128u, (u32)kMtN / 4 - 1);  // unconditional: idle lanes repeat the last quad
     const uint4 r0 = src[E.lane], r1 = src[E.lane + 64], r2 = src[q2];
-    dst[E.lane] = r0;
-    dst[E.lane + 64] = r1;
-    dst[q2] = r2;
+#ifndef CE_RNG_WT_OFF
+    if (wt) {
+      typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+      const auto base = (CE_GPTR(char))dst;
+      const u32 o = E.lane << 4;
+      const u32x4 v0 = {r0.x, r0.y, r0.z, r0.w}, v1 = {r1.x, r1.y, r1.z, r1.w}, v2 = {r2.x, r2.y, r2.z, r2.w};
+      asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(o), "v"(v0), "s"(base));
+      asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc1\n\ts_nop 1" ::"v"(o), "v"(v1), "s"(base));
+      if (E.lane + 128u < (u32)kMtN / 4)  // (a write-through store is a fabric write of its own: no repeats here)
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc1\n\ts_nop 1" ::"v"(o), "v"(v2), "s"(base));
+    } else
+#endif
+    {
+      dst[E.lane] = r0;
+      dst[E.lane + 64] = r1;
+      dst[q2] = r2;
+    }
   }
   if (E.lane == 0) p.rng[(size_t)E.e * kRngRow + kMtN] = E.rng.pos;
 }
@@ -2303,7 +2319,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   if (!obs_early) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, false, E.waste_perm_dirty);  // (the spawn list was written by the reset that changed it)
-  if (!diag::ablate_rngstore) store_rng(E, p);
+  if (!diag::ablate_rngstore) store_rng(E, p, !FUSED && p.obs_wt != 0);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
     out.done()[E.e] = done ? 1 : 0;
