@@ -107,3 +107,26 @@ def test_bench_default_line_has_every_config():
     assert cr["closed_loop"]["value"] > 0
     rf = row["roofline"]
     assert abs(rf["frac"] * 8000e9 * row["ms_per_step"] * 1e-3 - 7235 * 16384) < 0.01 * 7235 * 16384
+    # round 5: the line checks its own kernels against the oracle (headline + every config row), says where its PMC constant
+    # comes from, and ends in a summary that holds every row
+    raw = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    assert list(row)[-1] == "summary" and raw.rstrip().endswith("}}")
+    sm = row["summary"]
+    assert sm["parity_all_ok"] is True and set(sm) >= {"C4", "C2", "C3", "C5", "C1", "closed_loop_G", "dict_M", "tensor_G", "counter_G", "beyond_cache_frac"}
+    assert len(json.dumps(sm)) < 2048 and raw.index('"summary"') > len(raw) - 2048  # inside the last 8 KB with room to spare
+    for r in [row] + row["configs"]:
+        par = r["parity_in_run"]
+        assert par["ok"] is True and par["envs"] >= 256 and par["steps"] >= 32 and "mismatches" not in par, par
+        assert par["per_step_steps"] + par["fused_steps"] == par["steps"] and par["fused_steps"] % 16 == 0 and par["fused_steps"] > 0
+        assert {"agents", "rng", "reward", "done"} <= set(par["fields"]) or {"sd_state", "rng", "obs_f64"} <= set(par["fields"])
+        assert "_oracle_state" not in r["cpu_baseline"]
+        assert abs(sm[r.get("config", "C4")]["G"] - round(r["value"] / 1e9, 4)) < 1e-9 and sm[r.get("config", "C4")]["parity_ok"] is True
+    assert rf["traffic_ratio"] is None or (1.0 < rf["traffic_ratio"] < 3.0 and "profiles/traffic.json @" in rf["traffic_source"])
+    assert all("roofline_frac_is" in c["fused"] for c in row["configs"])
+    # closed loop: the benchmark policy inside the step kernel (one launch per slice and tick), the launch loop in C (one host
+    # call per tick), and the best row whose policy is a kernel of its own
+    assert {"inkernel_eager", "inkernel_sliced", "policy_graph_all", "inkernel_graph_all"} <= set(cl["modes"])
+    assert cl["modes"]["inkernel_sliced"]["host_calls_per_step"] == 1 and cl["modes"]["inkernel_eager"]["launches_per_slice_and_step"] == 1
+    assert cl["best_with_separate_policy_kernel"]["value"] > 0 and not cl["best_with_separate_policy_kernel"]["issue"].startswith("inkernel")
+    dp = bd["dict_protocol"]
+    assert dp["recycle_dicts"] is True and dp["value"] > dp["value_incl_action_dicts"] > dp["value_with_consumer_copies"] > 0

@@ -24,6 +24,13 @@ CONFIGS = {  # workgroups of one env slice (3 slices per rank) -> BASELINE confi
 }
 
 
+def label(kernel, blocks):
+    """BASELINE config of a (kernel, workgroups) pair; the grid kernels' last template argument (the custom-layout flag)
+    is not part of the mapping's keys"""
+    import re
+    return CONFIGS.get((kernel, blocks)) or CONFIGS.get((re.sub(r", (false|true)>$", ">", kernel), blocks), "")
+
+
 def short(name):
     n = name.replace("void ce::", "").replace("ce::", "")
     return n.split("(")[0].strip()
@@ -50,7 +57,7 @@ def main():
         w = csv.writer(fh)
         w.writerow(["kernel", "workgroups", "config", "calls", "total_ns", "mean_ns", "min_ns", "max_ns"])
         for (k, blocks), (calls, tot, mn, mx) in rows:
-            w.writerow([k, blocks, CONFIGS.get((k, blocks), ""), calls, tot, round(tot / calls, 1), mn, mx])
+            w.writerow([k, blocks, label(k, blocks), calls, tot, round(tot / calls, 1), mn, mx])
     print("kernel_trace_by_config: %d dispatches of %d (kernel, size) pairs from %d file(s) -> %s"
           % (sum(v[0] for v in acc.values()), len(acc), len(files), dst))
 

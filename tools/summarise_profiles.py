@@ -36,10 +36,10 @@ by_cfg = os.path.join(src, "kernel_stats_by_config.csv")
 if os.path.exists(by_cfg):  # the same trace split by launch size: one row per (kernel, config)
     import csv
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from kernel_trace_by_config import CONFIGS  # (labels re-applied here: the mapping may be newer than the run's snapshot)
+    from kernel_trace_by_config import label  # (labels re-applied here: the mapping may be newer than the run's snapshot)
     rows = list(csv.reader(open(by_cfg)))
     for r in rows[1:]:
-        r[2] = CONFIGS.get((r[0], int(r[1])), "")
+        r[2] = label(r[0], int(r[1]))
     with open("profiles/%s_kernel_stats_by_config.csv" % tag, "w", newline="") as fh:
         csv.writer(fh).writerows(rows)
 line = [ln for ln in open(os.path.join(src, "kt_bench_line.json")).read().splitlines() if ln.startswith("{")][-1]
