@@ -450,19 +450,20 @@ extern "C" int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
   return sync_device_params(h);
 }
 
-// Single-step launches write their observations through the L2 (GridParams.obs_wt / SdParams.obs_wt, see write_obs) when the
-// handle's device memory — state, outputs, generator rows — fits the 256 MB Infinity Cache with some room to spare: a
-// write-through store that lands in that cache is cheap and shortens the launch's end (no dirty lines left to write back), one
-// that goes on to HBM is not (round 5, interleaved A/B, agent-steps/s: cleanup n = 8 x 16 384 envs = 174 MB: +3.7 %; C3 +2.6 %;
-// selfdrive n = 4 x 32 768 = 217 MB: +5-8 %; cleanup n = 8 x 32 768 = 348 MB: -30 %; selfdrive x 131 072: -5 %).
-// CE_OBS_WT_MAX_BYTES overrides the limit (0 = never) for A/B runs.
-static bool obs_write_through(const ce_engine* h) {
+// Single-step launches write their observations (and the MT19937 row) through the L2 (GridParams.obs_wt / SdParams.obs_wt ->
+// the launch; write_obs, store_rng, sd_emit_obs) when what the call works on fits the 256 MB Infinity Cache with room to spare:
+// the handle's device memory — state, outputs, generator rows — plus, for ce_rollout, the action planes the call will read.  A
+// write-through store that lands in that cache is cheap and shortens the launch's end (no dirty lines left to write back); one
+// that goes on to HBM is not.  Round 5, interleaved A/B, agent-steps/s: cleanup n = 8 x 16 384 envs (174 MB) + 4 %, closed loop
+// + 20 %; C3 + 3-4 %; selfdrive n = 4 x 32 768 (217 MB) + 5 %; but cleanup n = 8 x 32 768 (348 MB) - 30 %, and the headline batch
+// stepped through 1 000 resident action planes (175 + 131 MB) - 3 to - 8 %.  CE_OBS_WT_MAX_BYTES overrides the limit (0 = never).
+static bool obs_write_through(const ce_engine* h, unsigned long long extra_bytes = 0) {
   static long long limit = -1;
   if (limit < 0) {
     const char* e = getenv("CE_OBS_WT_MAX_BYTES");
     limit = e ? atoll(e) : (224ll << 20);
   }
-  unsigned long long total = 0;
+  unsigned long long total = extra_bytes;
   for (const auto& a : h->allocs) total += a.second;
   return total <= (unsigned long long)limit;
 }
@@ -687,8 +688,9 @@ extern "C" int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   return check_launch(h, "reset kernel");
 }
 
-extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin,
-                             uint32_t env_count, void* stream) {
+// wt: -1 = decide from the handle alone; 0 / 1 = the caller (ce_rollout) has decided for its whole call
+static int step_range_impl(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count, void* stream,
+                           int wt) {
   if (!h || !actions) return CE_EINVAL;
   if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
   begin_call(h);
@@ -699,6 +701,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
     p.actions = (const uint8_t*)actions;
     p.env_first = env_begin;
     p.env_count = env_count;
+    if (wt >= 0) p.obs_wt = (uint32_t)wt;
     (counter_rng(h->cfg) ? launch_grid_step_ctr : launch_grid_step)((int)h->cfg.kind, p, h->d_gparams, stream);
   } else if (is_feat(h->cfg)) {
     GridParams p = grid_params(h);
@@ -712,10 +715,16 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
     p.active = active;
     p.env_first = env_begin;
     p.env_count = env_count;
+    if (wt >= 0) p.obs_wt = (uint32_t)wt;
     launch_sd_step(p, stream);
   }
   if (h->timing_armed) h->timed_launches++;
   return check_launch(h, "step kernel");
+}
+
+extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count,
+                             void* stream) {
+  return step_range_impl(h, actions, active, env_begin, env_count, stream, -1);
 }
 
 extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream) {
@@ -750,11 +759,13 @@ extern "C" int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, 
   if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   const uint32_t E = h->cfg.num_envs;
   const size_t plane = (size_t)E * h->cfg.num_agents * (u8_actions(h->cfg) ? 1 : 4);
+  // the call's working set is the handle AND the action planes it will read: the store policy of its launches follows that
+  const int wt = obs_write_through(h, (unsigned long long)num_steps * plane) ? 1 : 0;
   for (uint32_t t = 0; t < num_steps; ++t) {
     const char* a_t = (const char*)actions + (size_t)t * plane;
     for (uint32_t s = 0; s < num_slices; ++s) {
       const uint32_t b0 = (uint32_t)((uint64_t)E * s / num_slices), b1 = (uint32_t)((uint64_t)E * (s + 1) / num_slices);
-      const int rc = ce_step_range(h, a_t, nullptr, b0, b1 - b0, streams ? streams[s] : nullptr);
+      const int rc = step_range_impl(h, a_t, nullptr, b0, b1 - b0, streams ? streams[s] : nullptr, wt);
       if (rc != CE_OK) return rc;
     }
   }

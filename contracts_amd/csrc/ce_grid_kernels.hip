@@ -724,6 +724,7 @@ template <int KIND> struct Env {
   u32 WS[2];
   unsigned long long* dbg;  // diagnostic builds only
   bool waste_perm_dirty;    // the persistent waste list was shuffled in this launch
+  bool wt;                  // this launch writes its views and the MT19937 row through the L2 (write_obs, store_rng); wave-uniform
   // The layout the env is built from (env_geometry): the static tables and the lengths of its cell lists.  For the shipped layout
   // these are literals — everything is inlined into the kernel, so they fold exactly like the Geo<KIND> constants they stand
   // for; a kernel instance for a caller's layout (ce_config.ascii_map, CM = true) reads them from the parameter block.
@@ -1558,8 +1559,8 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     // Two cache policies for the same bytes (one wave-uniform branch per view):
     //  * nontemporal: the observation is write-once output and the bulk of the step's bytes; keeping it out of L2 / Infinity
     //    Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536 over plain stores)
-    //  * write-through (sc1), single-step launches of handles that fit the Infinity Cache (GridParams.obs_wt, set by the host:
-    //    ce_api.hip obs_write_through): the bytes leave the XCD's L2 as they are produced instead of at the kernel's end, when
+    //  * write-through (sc1), single-step launches of handles that fit the Infinity Cache (Env::wt — bit 8 of the step kernel's
+    //    num_agents argument, decided per launch by the host: ce_api.hip obs_write_through): the bytes leave the XCD's L2 as they are produced instead of at the kernel's end, when
     //    the launch's release writes every dirty line back at once — round 5, interleaved A/B: C4 +3.7 %, C3 +2.6 %, C2 +1.5 %;
     //    a fused rollout LOSES 40 % with it and a 32 768-env batch 30 % (sustained write bandwidth past the cache), hence the switch.
     //    Written as asm: the compiler has no 12-byte sc1 store but the buffer form, and that one (SGPR soffset) it follows
@@ -1567,7 +1568,7 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     //    (tools/dbg_wt.py); the s_nop inside the string is that wait state.
     const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
     if (lane < 60) {
-      if (!RESTORE && p.obs_wt) asm volatile("global_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(dv), "s"(dst_a));
+      if (!RESTORE && E.wt) asm volatile("global_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(dv), "s"(dst_a));
       else __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
     }
   };
@@ -1925,6 +1926,7 @@ template <int KIND> DEVINL bool env_begin(Env<KIND>& E, const GridParams& p, Wav
   const u32 wave = threadIdx.x >> 6;
   E.lane = lane_id();
   E.waste_perm_dirty = false;
+  E.wt = false;  // (the single-step kernels set it from their launch: k_grid_step, k_grid_reset)
   E.e = rfl(env_first + blockIdx.x * kWavesPerBlock + wave);
   E.n = p.n;
   E.is_agent = E.lane < E.n;
@@ -2319,7 +2321,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   if (!obs_early) store_grid(E, p);
   store_agents(E, p);
   store_perms(E, p, false, E.waste_perm_dirty);  // (the spawn list was written by the reset that changed it)
-  if (!diag::ablate_rngstore) store_rng(E, p, !FUSED && p.obs_wt != 0);
+  if (!diag::ablate_rngstore) store_rng(E, p, !FUSED && E.wt);
   if (lane == 0) {
     p.timestep[E.e] = (i32)t;
     out.done()[E.e] = done ? 1 : 0;
@@ -2400,9 +2402,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_C
 #else
   ph.debug = nullptr;
 #endif
-  ph.n = NFIX ? (u32)NFIX : num_agents;
+  ph.n = NFIX ? (u32)NFIX : (num_agents & 0xffu);  // bit 8 of the argument: this launch stores write-through (Env::wt)
   const auto acts = (CE_GPTR(const uint8_t))call_actions;
   env_begin(E, ph, lds, env_first, 0xffffffffu);
+  E.wt = (num_agents & 0x100u) != 0;
   env_geometry<KIND, CM>(E, p);
   const u32 lane = E.lane, n = E.n;
   const size_t ea = (size_t)E.e * n;  // wave-uniform: per-agent arrays are indexed base + 32-bit lane offset
@@ -4563,14 +4566,14 @@ void CE_LAUNCHER(launch_grid_step)(int kind, const GridParams& p, const GridPara
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
   // the state pointers travel as kernel arguments (preloaded into SGPRs at wave launch), see k_grid_step
 #define CE_STEP_LAUNCH(K_, N_)                                                                                          \
-  hipLaunchKernelGGL((k_grid_step<K_, N_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+  hipLaunchKernelGGL((k_grid_step<K_, N_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
   if (p.custom_map) {  // a caller's layout (ce_config.ascii_map): the instance that reads tables and list lengths from the block
     if (kind == CE_KIND_CLEANUP)
-      hipLaunchKernelGGL((k_grid_step<CE_KIND_CLEANUP, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+      hipLaunchKernelGGL((k_grid_step<CE_KIND_CLEANUP, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u),
                          (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
     else
-      hipLaunchKernelGGL((k_grid_step<CE_KIND_HARVEST, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n,
+      hipLaunchKernelGGL((k_grid_step<CE_KIND_HARVEST, 0, 0, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u),
                          (u32*)p.rng, (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp);
     return;
   }
@@ -4590,7 +4593,7 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
 #define CE_STEP_LAUNCH(K_, N_, P_)                                                                                      \
-  hipLaunchKernelGGL((k_grid_step<K_, N_, P_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+  hipLaunchKernelGGL((k_grid_step<K_, N_, P_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
 #define CE_STEP_POLICY(P_)                                         \
   do {                                                             \
@@ -4602,7 +4605,7 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
     }                                                              \
   } while (0)
 #define CE_STEP_POLICY_CM(K_, P_)                                                                                       \
-  hipLaunchKernelGGL((k_grid_step<K_, 0, P_, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n, (u32*)p.rng, \
+  hipLaunchKernelGGL((k_grid_step<K_, 0, P_, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
   if (p.custom_map) {
     if (kind == CE_KIND_CLEANUP) {

@@ -120,7 +120,8 @@ def test_bench_default_line_has_every_config():
         assert par["per_step_steps"] + par["fused_steps"] == par["steps"] and par["fused_steps"] % 16 == 0 and par["fused_steps"] > 0
         assert {"agents", "rng", "reward", "done"} <= set(par["fields"]) or {"sd_state", "rng", "obs_f64"} <= set(par["fields"])
         assert "_oracle_state" not in r["cpu_baseline"]
-        assert abs(sm[r.get("config", "C4")]["G"] - round(r["value"] / 1e9, 4)) < 1e-9 and sm[r.get("config", "C4")]["parity_ok"] is True
+        key = r["config"] if isinstance(r["config"], str) else "C4"  # (the headline's `config` is its workload description)
+        assert abs(sm[key]["G"] - round(r["value"] / 1e9, 4)) < 1e-9 and sm[key]["parity_ok"] is True
     assert rf["traffic_ratio"] is None or (1.0 < rf["traffic_ratio"] < 3.0 and "profiles/traffic.json @" in rf["traffic_source"])
     assert all("roofline_frac_is" in c["fused"] for c in row["configs"])
     # closed loop: the benchmark policy inside the step kernel (one launch per slice and tick), the launch loop in C (one host

@@ -1,0 +1,64 @@
+"""Single-step launches write their observations (and the MT19937 row) either nontemporal or through the L2 (`sc1`), chosen per
+handle by its size (ce_api.hip: obs_write_through, CE_OBS_WT_MAX_BYTES).  The two store forms must leave the SAME BYTES in HBM —
+row padding included, which no oracle comparison looks at — for every kind that has the switch.  The limit is read once per
+process, so each side runs in a child process and reports digests of the raw device buffers after a rollout with in-launch
+resets.  (How this was found to matter: the first write-through build used a buffer store whose data registers the compiler
+overwrote one instruction later; 1.7 % of the envs had garbage in one agent's view rows — DESIGN.md §4.7b.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import hashlib, json, sys
+import numpy as np
+import torch
+sys.path.insert(0, %r)
+from contracts_amd.engine import BatchedEnv, _DevArray
+out = {}
+for kind, n, E, contract in (("cleanup", 8, 3001, "cleanup"), ("cleanup", 3, 700, None), ("harvest", 5, 1500, "harvest_local"),
+                             ("selfdrive", 4, 4099, "selfdrive_distprop")):
+    env = BatchedEnv(kind, E, n, contract=contract, auto_reset=True, horizon=9)
+    T = 31
+    dt = torch.float32 if kind == "selfdrive" else torch.uint8
+    acts = torch.empty((T, E, n), dtype=dt, device="cuda")
+    env.synth_actions(5, 0, T, acts.data_ptr())
+    env.seed(seed0=11)
+    env.reset()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    env.rollout_device(acts.data_ptr(), T, [s.cuda_stream for s in streams])
+    torch.cuda.synchronize()
+    env.check_faults()
+    b = env.b
+    raw = {"obs": (b.obs, E * b.obs_env_stride) if kind != "selfdrive" else (b.obs_f64, E * n * (2 * n + 7) * 8),
+           "rng": (b.rng, E * b.rng_words * 4)}
+    d = {}
+    for f, (ptr, nbytes) in raw.items():
+        t = torch.as_tensor(_DevArray(ptr, (nbytes,), np.uint8, None, env), device="cuda").cpu().numpy()
+        d[f] = hashlib.sha256(t.tobytes()).hexdigest()
+    for f in ("reward", "done", "info", "timestep", "theta"):
+        d[f] = hashlib.sha256(np.ascontiguousarray(env.download(f)).tobytes()).hexdigest()
+    out["%%s,%%d" %% (kind, n)] = d
+    env.close()
+print("DIGESTS " + json.dumps(out))
+""" % ROOT
+
+
+def _run(limit):
+    env = dict(os.environ, CE_OBS_WT_MAX_BYTES=limit)
+    p = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGESTS ")][-1]
+    return json.loads(line[len("DIGESTS "):])
+
+
+@pytest.mark.gpu
+def test_write_through_and_nontemporal_stores_leave_the_same_bytes():
+    nt, wt = _run("0"), _run(str(1 << 40))
+    assert set(nt) == set(wt) and len(nt) == 4
+    for cfg in nt:
+        assert nt[cfg] == wt[cfg], (cfg, {f: nt[cfg][f] == wt[cfg][f] for f in nt[cfg]})
