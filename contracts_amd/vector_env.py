@@ -217,6 +217,15 @@ class _EpochArray(np.ndarray):
 
     __str__ = __repr__
 
+    # copies and pickles are plain arrays of the values (never the generation the stamp points at)
+    def __deepcopy__(self, memo):
+        return self._ce_plain().copy()
+
+    __copy__ = lambda self: self._ce_plain().copy()  # noqa: E731
+
+    def __reduce__(self):
+        return (np.array, (self._ce_plain().tolist(),))
+
 
 def _stamp(arr, owner):
     v = arr.view(_EpochArray)
@@ -268,6 +277,20 @@ class _EpochDict(dict):
         return dict.__eq__(self, other)
 
     __hash__ = None
+
+    # copies and pickles are plain dictionaries of (copies of) the values
+    def __deepcopy__(self, memo):
+        import copy
+        self._ok()
+        return {k: copy.deepcopy(v, memo) for k, v in dict.items(self)}
+
+    def __copy__(self):
+        self._ok()
+        return dict(dict.items(self))
+
+    def __reduce__(self):
+        self._ok()
+        return (dict, (list(dict.items(self)),))
 
 
 def _pydict():

@@ -462,6 +462,11 @@ def test_checked_recycling_wrappers_refuse_stale_reads():
     assert row[2] == 6.0 and float((row + 1).sum()) == 26.0 and type(row + 1) is np.ndarray
     assert np.array_equal(np.concatenate((row, row)), np.r_[buf[1], buf[1]]) and row.copy().tolist() == [4.0, 5.0, 6.0, 7.0]
     assert d["n"] == 5 and list(d) == ["image", "n"] and d.get("image") is row and "n" in d and len(d) == 2
+    import copy
+    import pickle
+    dc, pk = copy.deepcopy(d), pickle.loads(pickle.dumps(d))  # copies / pickles are plain values, not handles on the generation
+    assert type(dc) is dict and type(dc["image"]) is np.ndarray and dc["image"].tolist() == [4.0, 5.0, 6.0, 7.0] and dc["n"] == 5
+    assert type(pk) is dict and np.array_equal(pk["image"], buf[1]) and not np.shares_memory(dc["image"], buf)
     sub = row[1:]  # plain from here on: a value already read is the consumer's
     assert type(sub) is np.ndarray
     g.epoch += 1  # the generation's buffers are about to be rewritten
@@ -469,10 +474,11 @@ def test_checked_recycling_wrappers_refuse_stale_reads():
     for read in (lambda: row[0], lambda: row + 1, lambda: np.concatenate((row, row)), lambda: row.copy(), lambda: row.tolist(),
                  lambda: list(row), lambda: repr(row), lambda: np.add(1.0, row), lambda: row.astype(np.float32), lambda: d["n"],
                  lambda: d.get("n"), lambda: list(d.items()), lambda: list(d), lambda: "n" in d, lambda: row.sum(),
-                 lambda: np.copy(row), lambda: np.mean(row)):
+                 lambda: np.copy(row), lambda: np.mean(row), lambda: copy.deepcopy(d), lambda: copy.deepcopy(row), lambda: pickle.dumps(d)):
         with pytest.raises(StaleDictError):
             read()
     assert np.isnan(np.asarray(row)).all()  # the one path no hook sees reads the poison, not plausible data
+    assert dc["image"].tolist() == [4.0, 5.0, 6.0, 7.0]  # what was copied in time is the consumer's
     fresh = _stamp(buf[0], g)  # the generation's next hand-out is valid again
     buf[0] = 1.0
     assert fresh.sum() == 4.0
