@@ -77,7 +77,7 @@ def test_launcher_fails_fast_when_one_rank_dies(tmp_path):
                       "time.sleep(60)\n")
     t0 = time.monotonic()
     rc = parallel.spawn_local_ranks(str(script), [], 2, timeout=120)
-    assert rc == 7 and time.monotonic() - t0 < 20
+    assert rc == 7 and time.monotonic() - t0 < 40  # (well under the survivor's 60 s; lenient for a loaded build box)
 
 
 def test_launcher_deadline_is_for_the_whole_job(tmp_path):
@@ -86,7 +86,7 @@ def test_launcher_deadline_is_for_the_whole_job(tmp_path):
     script.write_text("import time\ntime.sleep(60)\n")
     t0 = time.monotonic()
     rc = parallel.spawn_local_ranks(str(script), [], 3, timeout=2.0)
-    assert rc == 124 and time.monotonic() - t0 < 15
+    assert rc == 124 and time.monotonic() - t0 < 40
 
 
 def test_eight_rank_shard_equals_single_rank(tmp_path):
