@@ -151,3 +151,14 @@ def test_custom_layout_rules_are_checked_before_the_device():
         assert rc == -19, (rc, msg)
     with pytest.raises(ValueError):
         make_config("cleanup", 1, 1, ascii_map=["@@@", "@@"])
+    # a C caller with garbage dimensions: refused by the frame rule BEFORE anything is read through the pointer (it
+    # used to copy rows * cols bytes first — an out-of-bounds read, or a length_error / bad_alloc through the C boundary)
+    for rows_, cols_ in ((2 ** 31 - 1, 2 ** 31 - 1), (0, 5), (3, 0), (26, 18), (25, 19), (2 ** 20, 1)):
+        cfg = make_config("cleanup", 4, 1, ascii_map=ok)
+        cfg.map_rows, cfg.map_cols = rows_, cols_
+        h = C.c_void_p()
+        rc = L.ce_create(C.byref(cfg), C.byref(h))
+        msg = (L.ce_last_error(h) or b"").decode() if h else ""
+        if h:
+            L.ce_destroy(h)
+        assert rc == -22 and "frame" in msg, (rows_, cols_, rc, msg)

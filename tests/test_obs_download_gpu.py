@@ -59,3 +59,35 @@ def test_download_obs_f64_argument_checks():
     feat.reset()
     with pytest.raises(_lib.EngineError):
         feat.download_obs_f64(staging, out, 4)  # feature kinds have no image observations
+
+
+def test_downloads_on_another_stream_are_ordered_after_a_reset():
+    """ce_reset on one stream followed at once by ce_download_async / ce_download_obs_f64 on ANOTHER non-blocking stream: the
+    copies must see the reset's results (the engine orders the second stream behind the reset itself, as it does for steps —
+    ADVICE r04: the two download entry points skipped that).  A large batch, so that the reset kernel is still running when the
+    host issues the copies; a few steps first so that the buffers hold something else."""
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    E, n = 60000, 8
+    env = BatchedEnv("cleanup", E, n, horizon=1000)
+    env.seed(seed0=5)
+    env.reset()
+    a = np.full((E, n), 4, np.uint8)
+    for _ in range(3):
+        env.step(a)
+    env.synchronize()
+    assert env.download("timestep").min() == 3
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ts = env.host_alloc((E,), np.int32)
+    staging = env.host_alloc((E, env.b.obs_env_stride), np.uint8)
+    out = np.full((E, n, 15, 15, 3), -1.0)
+    ts[:] = -1
+    env.reset(stream=s1.cuda_stream)                       # asynchronous, ~0.2 ms of kernel
+    env.download_async("timestep", ts, stream=s2.cuda_stream)   # issued while it runs
+    env.download_obs_f64(staging, out, 8, parts=4, stream=s2.cuda_stream)
+    env.synchronize(s2.cuda_stream)
+    assert (ts == 0).all(), "the copy on the second stream overtook the reset"
+    torch.cuda.synchronize()
+    want = env.download("obs").reshape(E, n, 15, 15, 3) / 255.0   # the reset observation, read after everything has drained
+    assert np.array_equal(out, want)
+    env.close()
