@@ -253,6 +253,29 @@ def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
         env.close()
 
 
+def oracle_sample(wl, E, K):
+    """the oracle stepped K steps on envs 0..E-1 of a workload (seeds SEED0 + b, the counter-hash actions, horizon 1000 with
+    auto-reset) — untimed; returns what parity_in_run() compares an engine handle with"""
+    import numpy as np
+    from contracts_amd import synth
+    from oracle.pyoracle import Oracle
+    kind, n = wl["kind"], wl["n"]
+    na = {"cleanup": 8, "harvest": 7, "harvest_features": 7, "cleanup_features": 8}.get(kind)
+    import ctypes
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(_usable_cores())  # (the cpu_baseline leg may have left it at one)
+    orc = Oracle(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, rng=wl.get("rng", "mt19937"))
+    orc.seed(seed0=SEED0)
+    orc.reset()
+    for t0 in range(0, K, 32):
+        c = min(32, K - t0)
+        acts = synth.synth_actions_f32(SEED0 + 1, 0, E, n, t0, c) if kind == "selfdrive" else synth.synth_actions_u8(SEED0 + 1, 0, E, n, t0, c, na)
+        for t in range(c):
+            orc.step(acts[t])
+    state = {f: np.array(getattr(orc, f)) for f in PARITY_FIELDS[kind]}
+    orc.close()
+    return {"envs": E, "steps": K, "fields": state}
+
+
 def stream_ceiling():
     """measured streaming ceilings of this box: device-to-device copy (read + write bytes) and fill (write
     only) of a 1 GiB buffer through torch's own kernels, GB/s"""
@@ -595,6 +618,9 @@ def counter_rng(group, wl, a, device_index, big_E=262144):
             row[mode] = cell
             r.close()
         out[label] = row
+    if not a.no_cpu_baseline:  # the counter-mode kernels checked in the run too: a short oracle sample on the same stream
+        wc = dict(wl, rng="counter")
+        out["parity_in_run"] = parity_in_run(wc, oracle_sample(wc, 2048, 1152), device_index, a.streams, a.fused_steps)
     cl = closed_loop(dict(wl, rng="counter"), wl["E"], device_index, a.streams)  # the per-step path is the closed loop's
     out["closed_loop"] = {"value": cl["value"], "ms_per_step": cl["ms_per_step"], "issue": cl["issue"],
                           "by_issue": {m: v.get("value", v.get("error")) for m, v in cl["modes"].items()}}
@@ -904,7 +930,9 @@ def summary(out):
     sm["counter_fused_G"] = g(((hb.get("counter") or {}).get("fused") or {}).get("value"))
     sm["beyond_cache_frac"] = f3((lb.get("mt19937") or {}).get("roofline_frac"))
     sm["beyond_cache_counter_frac"] = f3((lb.get("counter") or {}).get("roofline_frac"))
-    sm["parity_all_ok"] = all(v.get("parity_ok") for k, v in sm.items() if isinstance(v, dict) and v.get("parity_ok") is not None)
+    sm["counter_parity_ok"] = (cr.get("parity_in_run") or {}).get("ok")
+    sm["parity_all_ok"] = all(v.get("parity_ok") for k, v in sm.items() if isinstance(v, dict) and v.get("parity_ok") is not None) \
+        and sm["counter_parity_ok"] is not False
     return sm
 
 

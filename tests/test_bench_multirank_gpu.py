@@ -122,6 +122,8 @@ def test_bench_default_line_has_every_config():
         assert "_oracle_state" not in r["cpu_baseline"]
         key = r["config"] if isinstance(r["config"], str) else "C4"  # (the headline's `config` is its workload description)
         assert abs(sm[key]["G"] - round(r["value"] / 1e9, 4)) < 1e-9 and sm[key]["parity_ok"] is True
+    cpar = cr["parity_in_run"]  # the counter-mode kernels against the oracle's restatement of that stream, in the run
+    assert cpar["ok"] is True and cpar["envs"] == 2048 and cpar["steps"] == 1152 and sm["counter_parity_ok"] is True
     assert rf["traffic_ratio"] is None or (1.0 < rf["traffic_ratio"] < 3.0 and "profiles/traffic.json @" in rf["traffic_source"])
     assert all("roofline_frac_is" in c["fused"] for c in row["configs"])
     # closed loop: the benchmark policy inside the step kernel (one launch per slice and tick), the launch loop in C (one host
