@@ -92,6 +92,10 @@ def parse():
     ap.add_argument("--rng", default="mt19937", choices=["mt19937", "counter"],
                     help="stream of the HEADLINE rows: mt19937 = the reference's (default: the only mode BASELINE's metric is about); "
                          "counter = the engine's own Philox stream, grid kinds only — the line then says so in config.rng")
+    ap.add_argument("--full", action="store_true", help="also print the full record (every row, note and per-mode table; ~25 KB) as "
+                    "a stdout line BEFORE the compact one")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="file the full record goes to ('' = nowhere); the stdout line is the compact record (< 3 KB)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N self-launch: deadline of the whole job, s")
     return ap.parse_args()
 
@@ -200,10 +204,12 @@ def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
     from contracts_amd.engine import BatchedEnv
     kind, n = wl["kind"], wl["n"]
     E, K, ref = oracle_state["envs"], oracle_state["steps"], oracle_state["fields"]
-    # same launch shapes as the timed row where the sample is the row's whole batch; a smaller sample runs as one slice so that
-    # its launches stay above the size thresholds that pick the row's kernel instances
-    S = max(1, min(streams, E)) if E == wl["E"] else 1
-    env = BatchedEnv(kind, E, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
+    # the handle is the timed row's: the row's WHOLE batch, cut into the same slices on as many streams — so the launches this
+    # check makes are the exact kernel instances and launch shapes the row times; the oracle's sample is
+    # envs 0..E-1 of it (global indices, seeds and counter-hash actions are keyed by the env index, not by the batch size)
+    EH = max(E, wl["E"])
+    S = max(1, min(streams, EH))
+    env = BatchedEnv(kind, EH, n, contract=wl["contract"], horizon=1000, auto_reset=True, device=device_index,
                      env_index_base=0, rng=wl.get("rng", "mt19937"))
     try:
         env.seed(seed0=SEED0)
@@ -215,7 +221,7 @@ def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
         k_step = K - k_fused
         dt = torch.float32 if kind == "selfdrive" else torch.uint8
         CH = 512
-        buf = torch.empty((CH, E, n), dtype=dt, device="cuda")
+        buf = torch.empty((CH, EH, n), dtype=dt, device="cuda")
         t = 0
         while t < K:
             fused = t >= k_step
@@ -234,6 +240,7 @@ def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
         bad, digest = {}, hashlib.sha256()
         for f, y in ref.items():
             x = env.download(f, raw=True) if kind in ("harvest_features", "cleanup_features") and f == "grid" else env.download(f)
+            x = x[:E]  # the oracle's sample: the first E envs of the batch
             if f == "rng" and wl.get("rng", "mt19937") == "mt19937":  # key[624] + position of each MT19937 block (pad words are free)
                 x, y = x.reshape(E, -1, 628)[:, :, :625], y.reshape(E, -1, 628)[:, :, :625]
             digest.update(np.ascontiguousarray(x).tobytes())
@@ -242,6 +249,7 @@ def parity_in_run(wl, oracle_state, device_index, streams, fused_T):
                 rows = np.nonzero((np.asarray(x) != np.asarray(y)).reshape(E, -1).any(axis=1))[0]
                 bad[f] = {"envs_differing": int(rows.size), "first": [int(r) for r in rows[:4]]}
         out = {"ok": not bad, "envs": E, "steps": K, "per_step_steps": k_step, "fused_steps": k_fused, "slices": S,
+               "handle_envs": EH, "envs_per_launch": EH // S,
                "episode_ends_crossed": K // 1000 if kind != "selfdrive" else "at each env's own pace",
                "fields": list(ref), "engine_sha256_16": digest.hexdigest()[:16],
                "checker": "oracle/oracle.c (the cpu_baseline leg's final state: same envs, seeds, actions, step count)",
@@ -576,14 +584,20 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
         except Exception as exc:  # capture support differs between ROCm builds: the eager figure stands
             modes[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     one_iter = ("eager", "graph", "policy_eager", "policy_graph", "policy_graph_all", "inkernel_eager", "inkernel_sliced", "inkernel_graph_all")
-    best = max((m for m in one_iter if "value" in modes.get(m, {})), key=lambda m: modes[m]["value"])
+    best_any = max((m for m in one_iter if "value" in modes.get(m, {})), key=lambda m: modes[m]["value"])
     separate = [m for m in one_iter if not m.startswith("inkernel") and "value" in modes.get(m, {})]
+    inker = [m for m in one_iter if m.startswith("inkernel") and "value" in modes.get(m, {})]
     best_sep = max(separate, key=lambda m: modes[m]["value"]) if separate else None
+    best_ink = max(inker, key=lambda m: modes[m]["value"]) if inker else None
+    # `value` = the best row whose policy is a kernel of its OWN (what a policy network needs; comparable across rounds —
+    # ADVICE r05).  The inkernel_* rows evaluate the benchmark's toy policy inside the step kernel's action load
+    # (ce_step_policy CE_POLICY_AHEAD_NOISE): a separately named figure, never `value`.
+    best = best_sep if best_sep is not None else best_any
     out = dict(modes[best], unit="agent-steps/s", issue=best, slices=S, modes=modes,
-               # the best row whose policy is a kernel of its OWN (what a policy network needs): the inkernel_* rows evaluate the
-               # benchmark's policy inside the step kernel's action load (ce_step_policy CE_POLICY_AHEAD_NOISE)
                best_with_separate_policy_kernel=None if best_sep is None else dict(
                    {k: modes[best_sep][k] for k in ("value", "ms_per_step", "host_calls_per_step")}, issue=best_sep),
+               inkernel_policy=None if best_ink is None else dict(
+                   {k: modes[best_ink][k] for k in ("value", "ms_per_step", "host_calls_per_step")}, issue=best_ink),
                policy="torch on device: action = (green(pixel ahead of the agent in the previous observation) + resident noise "
                       "byte, accumulated) mod %d — eager / graph: two elementwise kernels + the step per slice and tick; policy_*: "
                       "one elementwise kernel + ce_step_policy (the modulo happens in the step kernel's action load); inkernel_*: the whole "
@@ -874,6 +888,8 @@ def run_rank(a):
                 if "error" not in r2 and (r2.get("best_with_separate_policy_kernel") or {}).get("value", 0) > \
                         (cl.get("best_with_separate_policy_kernel") or {}).get("value", 0):
                     cl["best_with_separate_policy_kernel"] = dict(r2["best_with_separate_policy_kernel"], slices=S2)
+                if "error" not in r2 and (r2.get("inkernel_policy") or {}).get("value", 0) > (cl.get("inkernel_policy") or {}).get("value", 0):
+                    cl["inkernel_policy"] = dict(r2["inkernel_policy"], slices=S2)
             cl["slices_sweep"] = sweep
         if not a.no_boundary:
             out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
@@ -888,12 +904,81 @@ def run_rank(a):
                     target["parity_in_run"] = extra(parity_in_run, w, st, local_rank, a.streams, a.fused_steps)
                 target["cpu_baseline"] = cb
 
-            with_parity(out, wl, a.cpu_seconds)
+            with_parity(out, dict(wl, E=E), a.cpu_seconds)
             for row in out.get("configs", []):  # the CPU path beside every GPU config, same E rule / seeds / actions
                 with_parity(row, WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
-        out["summary"] = summary(out)  # LAST key: the tail of the line holds every row (the driver keeps the last 8 KB)
-        print(json.dumps(out), flush=True)
+        out["summary"] = summary(out)
+        emit(out, a)
     group.close()
+
+
+COMPACT_MAX_BYTES = 3072  # the driver parses the LAST stdout line; r05's 25 KB line came back `parsed: null`
+
+
+def _sig(x, digits=5):
+    """numbers of the compact line: 5 significant digits (floats), everything else untouched"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact(out, full_record=None):
+    """The ONE stdout line: a standalone record of the headline row — the contract's keys, `roofline`, `cpu_baseline`,
+    `parity_in_run`, and `summary` (one short row per other config) — without prose.  Everything else (per-mode tables, notes,
+    samples, the config rows in full) is the full record, written to `full_record`."""
+    cfg = out.get("config") or {}
+    roof = out.get("roofline") or None
+    cb = out.get("cpu_baseline") or None
+    par = out.get("parity_in_run") or None
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "mode", "envs_per_gpu", "agents", "global_envs", "rng", "streams_per_gpu",
+                                              "parallelism")}
+    line["config"]["mode"] = "per_step"
+    line["roofline"] = None if roof is None else {k: roof.get(k) for k in (
+        "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "kernel", "algorithmic_bytes_per_env_step",
+        "algorithmic_bytes_per_launch", "envs_per_launch", "launch_ms", "event_ms_per_step", "measured_copy_GBs", "measured_fill_GBs")}
+    if cb is not None and "error" not in cb:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "single_thread_value",
+                                                       "python_reference_per_core")}
+        ost = (par or {})
+        line["cpu_baseline"]["sample"] = "envs 0..%s x %s steps of the same batch" % (
+            (ost.get("envs") or 0) - 1 if ost.get("envs") else "?", ost.get("steps", "?"))
+    else:
+        line["cpu_baseline"] = cb
+    if par is not None:
+        line["parity_in_run"] = {k: par.get(k) for k in ("ok", "envs", "steps", "slices", "envs_per_launch", "error") if k in par}
+    line["ranks_seen"] = (out.get("ranks") or {}).get("ranks_seen")
+    line["summary"] = out.get("summary")
+    line["full_record"] = full_record
+    line = _sig(line)
+    line["value"], line["ms_per_step"] = out.get("value"), out.get("ms_per_step")  # the two the driver cross-checks: unrounded
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_MAX_BYTES:  # never let the line outgrow the driver again: drop the digest before the record
+        line["summary"] = {k: v for k, v in (line.get("summary") or {}).items() if k in ("C4", "parity_all_ok", "parity_legs_run")}
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(out, a):
+    """full record -> a file (and stdout under --full, for the tools that read every row); the compact record is the LAST
+    (by default the only) stdout line"""
+    full = json.dumps(out)
+    path = a.full_out
+    try:
+        if path:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as fh:
+                fh.write(full + "\n")
+    except OSError as exc:
+        path = "unwritable (%s)" % type(exc).__name__
+    if a.full:
+        print(full, flush=True)
+    print(compact(out, None if not path else os.path.relpath(path, ROOT) if not path.startswith("unwritable") else path), flush=True)
 
 
 def summary(out):
@@ -920,7 +1005,7 @@ def summary(out):
     sm["closed_loop_G"] = g(cl.get("value"))
     sm["closed_loop_issue"] = cl.get("issue")
     sm["closed_loop_host_calls_per_step"] = cl.get("host_calls_per_step")
-    sm["closed_loop_separate_policy_kernel_G"] = g((cl.get("best_with_separate_policy_kernel") or {}).get("value"))
+    sm["closed_loop_inkernel_G"] = g((cl.get("inkernel_policy") or {}).get("value"))  # the toy policy inside the step kernel: NOT `value`
     sm["dict_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"]["value"] / 1e6, 2)
     sm["dict_incl_action_dicts_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"].get("value_incl_action_dicts", 0) / 1e6, 2)
     sm["tensor_G"] = g((bd.get("tensor_path") or {}).get("value"))
@@ -931,8 +1016,11 @@ def summary(out):
     sm["beyond_cache_frac"] = f3((lb.get("mt19937") or {}).get("roofline_frac"))
     sm["beyond_cache_counter_frac"] = f3((lb.get("counter") or {}).get("roofline_frac"))
     sm["counter_parity_ok"] = (cr.get("parity_in_run") or {}).get("ok")
-    sm["parity_all_ok"] = all(v.get("parity_ok") for k, v in sm.items() if isinstance(v, dict) and v.get("parity_ok") is not None) \
-        and sm["counter_parity_ok"] is not False
+    ran = [v["parity_ok"] for v in sm.values() if isinstance(v, dict) and v.get("parity_ok") is not None]
+    if sm["counter_parity_ok"] is not None:
+        ran.append(sm["counter_parity_ok"])
+    sm["parity_legs_run"] = len(ran)
+    sm["parity_all_ok"] = all(ran) if ran else None  # None = no parity leg ran (--no-cpu-baseline, world > 1): not a pass
     return sm
 
 

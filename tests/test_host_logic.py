@@ -506,3 +506,47 @@ def test_profile_provenance_rules(monkeypatch):
     assert b.kernels_sha16(fp) == b.kernels_sha16(dict(fp)) and len(b.kernels_sha16(fp)) == 16
     fp2 = {"files": dict(fp["files"], **{"ce_api.hip": "0" * 16}), "flags": fp["flags"]}
     assert b.kernels_sha16(fp2) != b.kernels_sha16(fp)
+
+
+def test_bench_compact_line_stays_parseable_and_small():
+    """the driver parses bench.py's LAST stdout line and lost round 5's (25-29 KB -> `parsed: null`).  The
+    stdout line is now bench.compact(): built here from the committed full records of earlier rounds, it must stay under 4 KB,
+    be one standalone JSON object and carry the contract's keys + roofline + cpu_baseline + parity_in_run + summary."""
+    import glob
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    srcs = sorted(glob.glob(os.path.join(root, "profiles", "r0[456]_bench_driver.json")))
+    assert srcs
+    for src in srcs:
+        d = json.load(open(src))
+        d["summary"] = bench.summary(d)
+        line = bench.compact(d, "gpurun_out/bench_full.json")
+        assert "\n" not in line and len(line) < 4096 and len(line) <= bench.COMPACT_MAX_BYTES + 256, (src, len(line))
+        c = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
+            assert k in c, (src, k)
+        assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"]  # the pair the driver cross-checks: unrounded
+        assert c["config"]["workload"] == d["config"]["workload"] and "model" not in c["config"]
+        r = c["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+        assert abs(r["frac"] - d["roofline"]["frac"]) < 1e-4 and r["traffic"] == d["roofline"]["traffic"]
+        cb = c["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+        assert set(c["summary"]) >= {"C4", "parity_all_ok"}
+    # no parity leg ran -> parity_all_ok is None, not a vacuous True (ADVICE r05)
+    d = json.load(open(srcs[-1]))
+    d.pop("parity_in_run", None)
+    for row in d.get("configs", []):
+        row.pop("parity_in_run", None)
+    (d.get("counter_rng") or {}).pop("parity_in_run", None)
+    sm = bench.summary(d)
+    assert sm["parity_all_ok"] is None and sm["parity_legs_run"] == 0
+    # a summary that would push the line over the cap is cut down to the headline row, never the record itself
+    d["summary"] = dict(bench.summary(d), **{"pad%d" % i: "x" * 64 for i in range(64)})
+    assert len(bench.compact(d, None)) < bench.COMPACT_MAX_BYTES

@@ -15,7 +15,7 @@ PROV=$(cd $R && python3 -m contracts_amd.build --provenance) || { echo "collect_
 rm -rf $OUT; mkdir -p $OUT
 echo "$PROV" > $OUT/provenance.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 > $OUT/kt_bench_line.json 2> $OUT/kt.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-closed-loop --no-boundary --no-counter-rng --min-seconds 0.2 --full-out $OUT/kt_bench_full.json > $OUT/kt_bench_line.json 2> $OUT/kt.log
 tail -1 $OUT/kt_bench_line.json | cut -c1-200
 python3 $R/tools/kernel_trace_by_config.py $OUT/kt $OUT/kernel_stats_by_config.csv
 cd $R

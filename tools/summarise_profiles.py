@@ -42,7 +42,8 @@ if os.path.exists(by_cfg):  # the same trace split by launch size: one row per (
         r[2] = label(r[0], int(r[1]))
     with open("profiles/%s_kernel_stats_by_config.csv" % tag, "w", newline="") as fh:
         csv.writer(fh).writerows(rows)
-line = [ln for ln in open(os.path.join(src, "kt_bench_line.json")).read().splitlines() if ln.startswith("{")][-1]
+full = os.path.join(src, "kt_bench_full.json")  # round 6: stdout carries the compact record, the full one goes to --full-out
+line = [ln for ln in open(full if os.path.exists(full) else os.path.join(src, "kt_bench_line.json")).read().splitlines() if ln.startswith("{")][-1]
 json.dump(json.loads(line), open("profiles/%s_bench_line.json" % tag, "w"), indent=1)
 
 out = {"round": tag, "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 400 --warmup 20 "
