@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "ce_device.h"
 
@@ -527,6 +528,64 @@ DEVINL u32 rank_in(u64 m, u32 /*lane*/) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
+// The draws of the waste-list shuffle (np.random.shuffle: for i = len-1 .. 1: j = random_interval(i), masked rejection
+// sampling, one stream word per attempt; cleanup_new.py:339).  Word-parallel over the 64 cached stream words: word k is
+// consumed at index i_k = i0 - a_k, a_k = the number of words accepted before it, and is accepted iff
+// (w_k & mask(i_k)) <= i_k with mask(i) = 2^bitlen(i) - 1 -- a self-referential predicate whose solution is the unique fixed
+// point of X <- { k : accept(w_k, i0 - rank_X(k)) }: if X is a fixed point then, by induction over k, every word's rank and
+// therefore its decision is the sequential one.  The iteration from any start reaches it (the lowest word that is still wrong
+// has a correct rank and is right after the next pass), and `X' == X` both ends the loop and proves the result, so neither
+// monotone bounds nor a cut at the mask segments (round 5: one batch per segment [2^b, 2^(b+1)) and a serial walk below 8)
+// are needed: a batch runs through as many segments as its words reach, down to index 1.  Three batches and ~14 passes of
+// 7 VALU per 119-entry list where the segmented form took six batches, ~20 passes and a serial tail.
+// The iteration runs on the complement: Y = the unread cached words that are REJECTED, because the index of word k is then
+// i0 - (k - off) + |Y below k| — two v_mbcnt with the start index as their accumulator, no subtraction.  Past the end of
+// the list the index runs to 0 and below: v_ffbh_i32 gives those a mask of 1 (index 0 or -1) or of the leading-ones run,
+// the signed compare rejects every negative index and at index 0 accepts the first even word — a deterministic function of
+// the ranks like the real draws, so the fixed point stays unique; real draws are the accepted words with index >= 1.
+// Two passes per convergence test (a pass over a fixed point reproduces it): half the scalar compares and taken branches.
+// J[i] (LDS) receives the draw of index i; r advances past every consumed word.
+#ifndef CE_SHUFFLE_DRAWS_SEGMENTED
+DEVINL i32 draw_mask(i32 idx) {  // idx >= 1: 2^bitlen(idx) - 1 (v_ffbh_i32: defined for every input, unlike __builtin_clz)
+  u32 lead;
+  asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(idx));
+  return (i32)(0xffffffffu >> (lead & 31u));
+}
+DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
+  rng_assert_uniform(r);
+  u32 i0 = rfl(len) - 1;  // indices i0 .. 1 are still to be drawn
+  while (i0 >= 1) {
+    u32 off = r.pos - r.cbase;
+    if (off >= r.ccount || r.ccount - off < 32u) {  // a short rest of an earlier consumer's cache: recache at pos (a batch per refill)
+      rng_refill(r, lane);
+      off = 0;
+    }
+    const u64 have = r.cvalid & (~0ull << off);  // unread cached words
+    const i32 c7 = (i32)(r.cache & 127u);        // every mask is <= 127
+    const i32 istart = (i32)i0 - (i32)(lane - off);  // the word's index if every unread word before it were accepted
+    i32 idx = istart;
+    u64 Y = ballot((c7 & draw_mask(idx)) > idx) & have;
+    for (;;) {
+      idx = istart + (i32)rank_in(Y, lane);
+      const u64 Y1 = ballot((c7 & draw_mask(idx)) > idx) & have;
+      idx = istart + (i32)rank_in(Y1, lane);
+      Y = ballot((c7 & draw_mask(idx)) > idx) & have;
+      if (Y == Y1) break;  // idx belongs to Y1 == Y: the fixed point
+    }
+    const u64 real = ~Y & have & ballot(idx >= 1);  // accepted, without whatever follows the end of the list
+    const u32 total = popc64(real);
+    if (total >= i0) {                            // the list completes inside this batch: stop behind the draw of index 1
+      r.pos = r.cbase + ctz64(real & ballot(idx == 1)) + 1;
+      i0 = 0;
+    } else {                                      // every cached word is consumed (accepted or rejected)
+      r.pos = r.cbase + r.ccount;
+      i0 -= total;
+    }
+    if ((real >> lane) & 1ull) J[idx] = (u32)(c7 & draw_mask(idx));
+  }
+  wave_sync();
+}
+#else
 // The draws of the waste-list shuffle.  Indices >= 32 are vectorised: for one mask segment [lo, i0] and the
 // cached words k = off.. (v_k = word_k & mask), sequential rejection sampling accepts word k iff
 // v_k <= i0 - a_k, where a_k is the number of words accepted before k.  That self-referential predicate is
@@ -580,6 +639,7 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
   if (lane >= 1 && lane <= i0) J[lane] = JL;
   wave_sync();
 }
+#endif
 
 // Applies swap(x[i], x[J[i]]) for i = len-1 .. 1 to the list held across lanes (L0: elements 0..63, L1: 64..)
 DEVINL void shuffle_apply(u32& L0, u32& L1, u32 len, const u32* J, u32 lane) {
@@ -1509,16 +1569,16 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     if (E.is_agent) pm[E.P] = (uint8_t)(pm[E.P] & kCodeMask);  // reset(): agents are not on the colour map
     wave_sync();
   }
-  // crop address of view pixel (i, j): off = o0 + i*A + j*B, kept per agent in its own lane
-  u32 VW = 0;
+  // crop address of view pixel (i, j): off = o0 + i*A + j*B, kept per agent in its own lane — three registers, so that a
+  // view's parameters are three v_readlane and nothing else (packed into one word they cost a readlane + three scalar unpack
+  // instructions per view, on the CU's one scalar pipe: DESIGN.md 4.8)
+  i32 VO = 0, VA = 0, VB = 0;
   {
     const i32 base = (i32)(E.is_agent ? E.P : pad_of<KIND>(0, 0)) - kView * G::PW - kView;
-    i32 o0, A, B;
-    if (E.O == 0) { o0 = base; A = G::PW; B = 1; }                                   // UP
-    else if (E.O == 3) { o0 = base + 14; A = -1; B = G::PW; }                        // LEFT  rot90(k=1)
-    else if (E.O == 2) { o0 = base + 14 * G::PW + 14; A = -G::PW; B = -1; }          // DOWN  rot90(k=2)
-    else { o0 = base + 14 * G::PW; A = 1; B = -G::PW; }                              // RIGHT rot90(k=1,(1,0))
-    VW = ((u32)o0 & 0xffffu) | (((u32)A & 0xffu) << 16) | (((u32)B & 0xffu) << 24);
+    if (E.O == 0) { VO = base; VA = G::PW; VB = 1; }                                   // UP
+    else if (E.O == 3) { VO = base + 14; VA = -1; VB = G::PW; }                        // LEFT  rot90(k=1)
+    else if (E.O == 2) { VO = base + 14 * G::PW + 14; VA = -G::PW; VB = -1; }          // DOWN  rot90(k=2)
+    else { VO = base + 14 * G::PW; VA = 1; VB = -G::PW; }                              // RIGHT rot90(k=1,(1,0))
   }
   wave_sync();
   // One lane round per agent: lane l < 60 produces the 4 horizontally adjacent pixels (row l / 4, columns
@@ -1534,9 +1594,8 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
   typedef u32 u32x3 __attribute__((ext_vector_type(3)));
   // the 4 pixels of this lane in agent a's view, packed as 12 bytes
   auto view_unit = [&](u32 a) -> u32x3 {
-    const u32 vw = rdl(VW, a);
-    const i32 A = (i32)(vw << 8) >> 24, B = (i32)vw >> 24;
-    const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)(vw & 0xffffu);
+    const i32 A = (i32)rdl((u32)VA, a), B = (i32)rdl((u32)VB, a);
+    const i32 off0 = __mul24((i32)row, A) + __mul24((i32)j0, B) + (i32)rdl((u32)VO, a);
     const i32 off1 = off0 + B, off2 = off1 + B, off3 = off2 + B;  // a chain of adds with the scalar B
     const auto lut = [&](i32 off) { return *(const u32*)((const char*)rgb + pm[off]); };  // a map byte is code * 4
     const u32 c0 = lut(off0);
@@ -1549,37 +1608,42 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     d.z = __builtin_amdgcn_perm(c3, c2, selz);         // B2 R3 G3 B3 (padding lanes: B2 0 0 0)
     return d;
   };
-  auto put_unit = [&](u32 a, const u32x3& dv) {
-    // the agent's view starts a * 720 bytes into the env's block: folded into the wave-uniform base (scalar add), the
-    // per-lane part of the address stays lane * 12 for every agent
-    if (diag::ablate_obsstore) {  // traffic experiment: the pixels are computed but not written
-      asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
-      return;
-    }
-    // Two cache policies for the same bytes (one wave-uniform branch per view):
-    //  * nontemporal: the observation is write-once output and the bulk of the step's bytes; keeping it out of L2 / Infinity
-    //    Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536 over plain stores)
-    //  * write-through (sc1), single-step launches of handles that fit the Infinity Cache (Env::wt — bit 8 of the step kernel's
-    //    num_agents argument, decided per launch by the host: ce_api.hip obs_write_through): the bytes leave the XCD's L2 as they are produced instead of at the kernel's end, when
-    //    the launch's release writes every dirty line back at once — round 5, interleaved A/B: C4 +3.7 %, C3 +2.6 %, C2 +1.5 %;
-    //    a fused rollout LOSES 40 % with it and a 32 768-env batch 30 % (sustained write bandwidth past the cache), hence the switch.
-    //    Written as asm: the compiler has no 12-byte sc1 store but the buffer form, and that one (SGPR soffset) it follows
-    //    with a write to the data registers without the wait state gfx950 needs — corrupted view rows in 2 % of the envs
-    //    (tools/dbg_wt.py); the s_nop inside the string is that wait state.
-    const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
-    if (lane < 60) {
-      if (!RESTORE && E.wt) asm volatile("global_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(dv), "s"(dst_a));
-      else __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
+  // Two cache policies for the same bytes, chosen ONCE per pass (the whole loop over the views exists twice: as a branch per
+  // view — round 5 — the switch cost ~10 scalar instructions per store, 80 per step, on the pipe the step is shortest of):
+  //  * nontemporal: the observation is write-once output and the bulk of the step's bytes; keeping it out of L2 / Infinity
+  //    Cache leaves them to the env state that is re-read next step (+2 % at 16 384 envs, +23 % at 65 536 over plain stores)
+  //  * write-through (sc1), single-step launches of handles that fit the Infinity Cache (Env::wt — bit 8 of the step kernel's
+  //    num_agents argument, decided per launch by the host: ce_api.hip obs_write_through): the bytes leave the XCD's L2 as they are produced instead of at the kernel's end, when
+  //    the launch's release writes every dirty line back at once — round 5, interleaved A/B: C4 +3.7 %, C3 +2.6 %, C2 +1.5 %;
+  //    a fused rollout LOSES 40 % with it and a 32 768-env batch 30 % (sustained write bandwidth past the cache), hence the switch.
+  //    Written as asm: the compiler has no 12-byte sc1 store but the buffer form, and that one (SGPR soffset) it follows
+  //    with a write to the data registers without the wait state gfx950 needs — corrupted view rows in 2 % of the envs
+  //    (tools/dbg_wt.py); the s_nop inside the string is that wait state.  ("memory": nothing may move across the store.)
+  auto views = [&](auto WT) {
+    auto put_unit = [&](u32 a, const u32x3& dv) {
+      // the agent's view starts a * 720 bytes into the env's block: folded into the wave-uniform base (scalar add), the
+      // per-lane part of the address stays lane * 12 for every agent
+      if (diag::ablate_obsstore) {  // traffic experiment: the pixels are computed but not written
+        asm volatile("" ::"v"(dv.x), "v"(dv.y), "v"(dv.z));
+        return;
+      }
+      const auto dst_a = dst_env + (size_t)__umul24(a, (u32)kObsAgentStride);
+      if (lane < 60) {
+        if (decltype(WT)::value) asm volatile("global_store_dwordx3 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(dv), "s"(dst_a) : "memory");
+        else __builtin_nontemporal_store(dv, (CE_GPTR(u32x3))(dst_a + voff));
+      }
+    };
+    // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
+    // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
+    for (u32 a = 0; a < E.n; a += 2) {
+      const u32 a1 = min(a + 1u, E.n - 1u);
+      const u32x3 d0 = view_unit(a), d1 = view_unit(a1);
+      put_unit(a, d0);
+      put_unit(a1, d1);
     }
   };
-  // two agents per round: their two dependent LDS lookups (map byte, then colour) overlap instead of queueing up;
-  // with an odd n the last round repeats agent n - 1 (same bytes to the same place)
-  for (u32 a = 0; a < E.n; a += 2) {
-    const u32 a1 = min(a + 1u, E.n - 1u);
-    const u32x3 d0 = view_unit(a), d1 = view_unit(a1);
-    put_unit(a, d0);
-    put_unit(a1, d1);
-  }
+  if (!RESTORE && E.wt) views(std::true_type{});
+  else views(std::false_type{});
   if (RESTORE && paint_agents) {
     wave_sync();
     pm_put(pm, E.is_agent, E.P, under);
@@ -4460,6 +4524,44 @@ __global__ void k_selftest(u32* out) {
       shuffle_apply(a0, a1, len, jl[0], lane);
       shuffle_apply_par(b0, b1, len, jl[1], lane);
       if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0) fail |= 8u;
+      wave_sync();
+    }
+  }
+  // (4) the word-parallel draws of the waste-list shuffle (shuffle_draws + the serial list update) against the serial swap
+  // walk (shuffle_core) from the same generator state: list contents and stream position, over start positions that put
+  // the generation end before, inside and behind the draws, and over list lengths 65 .. 128
+  {
+    __shared__ u32 jd[128];
+    for (u32 trial = 0; trial < 96; ++trial) {
+      const u32 len = trial < 64 ? 119u : 65u + ((trial * 29u) & 63u);
+      const u32 start = trial < 8 ? (u32)kMtN - 3u - 23u * trial : (trial * 2654435761u >> 7) % (u32)kMtN;
+      for (u32 k = lane; k < (u32)kMtN; k += 64) {
+        u32 h = (k + 1u) * 2246822519u ^ (trial + 1u) * 0x9e3779b9u;
+        h ^= h >> 15;
+        h *= 0x85ebca6bu;
+        h ^= h >> 13;
+        mt[k] = h;
+        ref[k] = h;
+      }
+      wave_sync();
+      Rng ra, rb;
+      ra.mt = mt, rb.mt = ref;
+      ra.pos = rb.pos = start;
+      ra.cbase = rb.cbase = 0, ra.ccount = rb.ccount = 0, ra.cvalid = rb.cvalid = 0, ra.cache = rb.cache = 0;
+      ra.twists = rb.twists = 0, ra.k0 = rb.k0 = 0, ra.k1 = rb.k1 = 0, ra.gen0 = rb.gen0 = 0;
+      if (trial & 1u) {  // a consumer before the shuffle leaves a partly read cache behind
+        (void)rng_next(ra, lane);
+        (void)rng_next(rb, lane);
+        for (u32 q = 0; q < (trial >> 1) % 40u; ++q) {
+          (void)rng_next(ra, lane);
+          (void)rng_next(rb, lane);
+        }
+      }
+      u32 a0 = lane, a1 = lane + 64, b0 = lane, b1 = lane + 64;
+      shuffle_core<true>(rb, b0, b1, len, lane);
+      shuffle_draws(ra, len, jd, lane);
+      shuffle_apply(a0, a1, len, jd, lane);
+      if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0 || ra.pos != rb.pos || ra.twists != rb.twists) fail |= 16u;
       wave_sync();
     }
   }
