@@ -42,7 +42,8 @@ namespace ce {
 namespace diag {
 constexpr bool ablate_moves = false, ablate_features = false, ablate_shuffle = false, ablate_obsstore = false,
                ablate_gridstore = false, ablate_rngstore = false, seq_shuffle = false, serial_apply = false,
-               serial_small_shuffle = false, ablate_twist = false, ablate_half_narrow = false;
+               serial_small_shuffle = false, ablate_twist = false, ablate_half_narrow = false, ablate_featscan = false,
+               ablate_obs = false;
 }
 }  // namespace ce
 #endif
@@ -551,12 +552,12 @@ DEVINL i32 draw_mask(i32 idx) {  // idx >= 1: 2^bitlen(idx) - 1 (v_ffbh_i32: def
   asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(idx));
   return (i32)(0xffffffffu >> (lead & 31u));
 }
-DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
+template <bool STORE = true, u32 RECACHE = 32u> DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
   rng_assert_uniform(r);
   u32 i0 = rfl(len) - 1;  // indices i0 .. 1 are still to be drawn
   while (i0 >= 1) {
     u32 off = r.pos - r.cbase;
-    if (off >= r.ccount || r.ccount - off < 32u) {  // a short rest of an earlier consumer's cache: recache at pos (a batch per refill)
+    if (off >= r.ccount || r.ccount - off < RECACHE) {  // a short rest of an earlier consumer's cache: recache at pos (a batch per refill)
       rng_refill(r, lane);
       off = 0;
     }
@@ -581,9 +582,16 @@ DEVINL void shuffle_draws(Rng& r, u32 len, u32* J, u32 lane) {
       r.pos = r.cbase + r.ccount;
       i0 -= total;
     }
-    if ((real >> lane) & 1ull) J[idx] = (u32)(c7 & draw_mask(idx));
+    if (STORE && ((real >> lane) & 1ull)) J[idx] = (u32)(c7 & draw_mask(idx));
   }
-  wave_sync();
+  if (STORE) wave_sync();
+}
+// The stream words of a shuffle whose order nobody looks at (an interaction-free update_moves, fewer than two beams): the same
+// fixed point, nothing stored.  ~4 passes of 6 VALU for a list of <= 8 where the find-first walk (shuffle_le8<2>) spent 8
+// dependent scalar instructions per draw on the CU's one scalar pipe, twice per step.
+DEVINL void shuffle_consume(Rng& r, u32 len, u32 lane) {
+  if (len < 2) return;
+  shuffle_draws<false, 24u>(r, len, nullptr, lane);
 }
 #else
 // The draws of the waste-list shuffle.  Indices >= 32 are vectorised: for one mask segment [lo, i0] and the
@@ -727,6 +735,14 @@ DEVINL void shuffle_apply_par(u32& L0, u32& L1, u32 len, u32* scratch, u32 lane)
   wave_sync();
 }
 
+DEVINL void consume_small(Rng& r, u32 len, u32 lane) {  // the stream words of a shuffle of len <= 64 entries, no swaps
+#ifndef CE_SHUFFLE_DRAWS_SEGMENTED
+  shuffle_consume(r, len, lane);
+#else
+  u32 d0 = 0;
+  shuffle_small<2>(r, d0, len, lane);
+#endif
+}
 DEVINL void shuffle_lanes1(Rng& r, u32& L0, u32 len, u32 lane) {  // len <= 64
   shuffle_small<0>(r, L0, len, lane);
 }
@@ -1145,8 +1161,7 @@ template <int KIND> DEVINL void update_moves(Env<KIND>& E, u32 ACT) {
     const bool ma = ((mlo >> a) & 1u) != 0, mb = ((mlo >> b) & 1u) != 0;
     const bool clash = ma && a != b && b < E.n && (ta == pb || (mb && ta == tb));
     if (ballot(clash) == 0) {
-      u32 d0 = 0;
-      shuffle_small<2>(E.rng, d0, m, lane);
+      consume_small(E.rng, m, lane);
       if (mover) E.P = TGT0;
       return;
     }
@@ -1826,7 +1841,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
     const u64 fb = ballot(f);
     if (r < 3) presA[r < 3 ? r : 0] = fb;
     napples += popc64(fb);
-    keyA[lane + 64 * r] = f ? rc : kNoKey;
+    if (!diag::ablate_featscan) keyA[lane + 64 * r] = f ? rc : kNoKey;
   }
   if (KIND == CE_KIND_CLEANUP) {
 #pragma unroll
@@ -1834,7 +1849,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       const bool f = both(lane + 64 * r < E.nwaste, (pm[cell_pad(E.WS[r])] & kCodeMask) == kWaste);
       presW[r] = ballot(f);
       nwaste += popc64(presW[r]);
-      keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
+      if (!diag::ablate_featscan) keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
     }
   }
   const u32 sh = n <= 4 ? 4u : n <= 8 ? 3u : 2u;
@@ -1843,7 +1858,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   wave_sync();
   u32 ka = 0xffffffffu, kw = 0xffffffffu;
 #pragma unroll 1  // unrolling keeps 8 b128 loads in flight and costs an occupancy step
-  for (u32 kc = 0; kc < (NCHUNK >> sh); ++kc) {  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
+  for (u32 kc = 0; kc < (diag::ablate_featscan ? 0u : (NCHUNK >> sh)); ++kc) {  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
     const u32 c = gl + (kc << sh);
     // key = manhattan << 16 | row << 8 | col in one v_sad_hi_u8 per cell (absent entries land at >= kNoKey)
     const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
@@ -2165,8 +2180,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
     if (firing & (firing - 1)) {  // the shuffled order only matters between two or more beams
       shuffle_lanes1(E.rng, IDS, n, lane);
     } else {
-      u32 d0 = 0;
-      shuffle_small<2>(E.rng, d0, n, lane);  // same stream words, no swaps
+      consume_small(E.rng, n, lane);  // same stream words, no swaps
     }
     if (firing != 0) {
       // positions of the shuffled list that hold a firing agent, visited in list order
@@ -2224,7 +2238,7 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
       if (diag::ablate_features) store_grid(E, p);
       else store_grid_bits(E, p, presA, presW);  // the feature pass has just taken the map's presence ballots
     }
-    write_obs<KIND, FUSED>(E, p, out.obs(), true);
+    if (!diag::ablate_obs) write_obs<KIND, FUSED>(E, p, out.obs(), true);
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
   // A quiet step — nobody ate, cleaned, fired or was hit: every reward, transfer and metric increment is zero — skips the
@@ -4562,6 +4576,36 @@ __global__ void k_selftest(u32* out) {
       shuffle_draws(ra, len, jd, lane);
       shuffle_apply(a0, a1, len, jd, lane);
       if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0 || ra.pos != rb.pos || ra.twists != rb.twists) fail |= 16u;
+      wave_sync();
+    }
+  }
+  // (5) the stream words of a small shuffle (consume_small: the fixed-point form, nothing stored) against the find-first walk
+  {
+    for (u32 trial = 0; trial < 128; ++trial) {
+      const u32 len = 2u + trial % 8u;  // 2 .. 9
+      const u32 start = trial < 16 ? (u32)kMtN - 1u - trial : (trial * 2654435761u >> 9) % (u32)kMtN;
+      for (u32 k = lane; k < (u32)kMtN; k += 64) {
+        u32 h = (k + 7u) * 2246822519u ^ (trial + 3u) * 0x9e3779b9u;
+        h ^= h >> 15;
+        h *= 0x85ebca6bu;
+        h ^= h >> 13;
+        mt[k] = h;
+        ref[k] = h;
+      }
+      wave_sync();
+      Rng ra, rb;
+      ra.mt = mt, rb.mt = ref;
+      ra.pos = rb.pos = start;
+      ra.cbase = rb.cbase = 0, ra.ccount = rb.ccount = 0, ra.cvalid = rb.cvalid = 0, ra.cache = rb.cache = 0;
+      ra.twists = rb.twists = 0, ra.k0 = rb.k0 = 0, ra.k1 = rb.k1 = 0, ra.gen0 = rb.gen0 = 0;
+      for (u32 q = 0; q < (trial * 5u) % 61u; ++q) {  // a partly read cache
+        (void)rng_next(ra, lane);
+        (void)rng_next(rb, lane);
+      }
+      u32 d0 = 0;
+      shuffle_small<2>(rb, d0, len, lane);
+      consume_small(ra, len, lane);
+      if (ra.pos != rb.pos || ra.twists != rb.twists || rng_next(ra, lane) != rng_next(rb, lane)) fail |= 32u;
       wave_sync();
     }
   }
