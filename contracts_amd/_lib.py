@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONTRACTS_AMD_LIB") or os.path.join(HERE, "csrc", "libcontracts_engine.so")
 
-CE_ABI_VERSION = 3
+CE_ABI_VERSION = 4
 KIND = {"cleanup": 0, "harvest": 1, "selfdrive": 2, "harvest_features": 3, "cleanup_features": 4}
 FEAT_KINDS = ("harvest_features", "cleanup_features")
 FEAT_APPLE_SLOTS, FEAT_WASTE_SLOTS, FEAT_STATE_BYTES = 160, 120, 568  # CE_FEAT_* of the header
@@ -56,8 +56,24 @@ class CeBuffers(C.Structure):
 
 
 class CeTraj(C.Structure):
-    _fields_ = [("num_planes", C.c_uint32), ("first_plane", C.c_uint32), ("obs", _P), ("obs_f64", _P), ("base_reward", _P),
+    _fields_ = [("num_planes", C.c_uint32), ("first_plane", C.c_uint32), ("num_envs", C.c_uint32), ("num_agents", C.c_uint32),
+                ("obs", _P), ("obs_f64", _P), ("base_reward", _P),
                 ("reward", _P), ("done", _P), ("done_agents", _P), ("info", _P), ("features", _P), ("sd_info", _P)]
+
+
+class CeStateHeader(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("abi_version", C.c_uint32), ("header_bytes", C.c_uint32), ("kind", C.c_uint32),
+                ("num_envs", C.c_uint32), ("num_agents", C.c_uint32), ("contract", C.c_uint32), ("flags", C.c_uint32),
+                ("horizon", C.c_uint32), ("what", C.c_uint32), ("num_fields", C.c_uint32), ("reserved", C.c_uint32),
+                ("env_index_base", C.c_uint64), ("layout_hash", C.c_uint64), ("total_bytes", C.c_uint64),
+                ("params", C.c_double * 9)]
+
+
+class CeStateField(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("offset", C.c_uint64), ("env_bytes", C.c_uint64)]
+
+
+STATE_MAGIC, STATE_OUTPUTS = 0x54534543, 1
 
 
 class CeFieldReq(C.Structure):
@@ -89,6 +105,10 @@ EXPORTS = {
     "ce_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
     "ce_download_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeFieldReq), C.c_uint32]),
     "ce_upload": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ce_state_bytes": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "ce_get_state": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ce_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ce_set_cache_budget": (C.c_int, [C.c_void_p, C.c_uint64]),
     "ce_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "ce_host_free": (C.c_int, [C.c_void_p]),
     "ce_download_async": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),

@@ -176,6 +176,10 @@ struct ce_engine {
   std::vector<std::pair<void*, uint64_t>> reset_seen;  // (stream, generation it has already waited for)
   bool timing_armed;
   uint32_t timed_launches;
+  // write-through decision (obs_write_through): the handle's device bytes, summed once at ce_create, against the share of the
+  // last-level cache the integrator grants this handle (ce_set_cache_budget; default from CE_OBS_WT_MAX_BYTES / the device)
+  unsigned long long device_bytes;
+  unsigned long long cache_budget;
 };
 
 static int fail(ce_engine* h, int code, const char* what, hipError_t e = hipSuccess) {
@@ -214,6 +218,7 @@ extern "C" int ce_device_count(void) {
 
 struct ce_engine;
 static int sync_device_params(ce_engine* h);
+static unsigned long long default_cache_budget(int device);
 
 static bool is_grid(const ce_config& c) { return c.kind == CE_KIND_CLEANUP || c.kind == CE_KIND_HARVEST; }
 static bool is_feat(const ce_config& c) { return c.kind == CE_KIND_HARVEST_FEATURES || c.kind == CE_KIND_CLEANUP_FEATURES; }
@@ -248,6 +253,8 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   h->cfg = *cfg;
   if (h->cfg.horizon == 0) h->cfg.horizon = 1000;
   h->timing_armed = false;
+  h->device_bytes = 0;
+  h->cache_budget = 0;
   h->mask_in_flight = false;
   h->ev_reset = nullptr;
   h->reset_stream = nullptr;
@@ -407,6 +414,9 @@ extern "C" int ce_create(const ce_config* cfg, ce_handle* out) {
   if (rc == CE_OK) rc = dalloc(h, &h->d_stage_active, E * n);
   if (rc == CE_OK) rc = dalloc(h, &h->d_debug, E * 16);
   if (rc == CE_OK && u8_actions(*cfg)) rc = dalloc(h, &h->d_gparams, 1);
+  h->device_bytes = 0;
+  for (const auto& a : h->allocs) h->device_bytes += a.second;
+  h->cache_budget = default_cache_budget(cfg->device);
   if (rc == CE_OK && u8_actions(*cfg)) rc = sync_device_params(h);
 #undef A
   return rc;
@@ -457,15 +467,26 @@ extern "C" int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
 // that goes on to HBM is not.  Round 5, interleaved A/B, agent-steps/s: cleanup n = 8 x 16 384 envs (174 MB) + 4 %, closed loop
 // + 20 %; C3 + 3-4 %; selfdrive n = 4 x 32 768 (217 MB) + 5 %; but cleanup n = 8 x 32 768 (348 MB) - 30 %, and the headline batch
 // stepped through 1 000 resident action planes (175 + 131 MB) - 3 to - 8 %.  CE_OBS_WT_MAX_BYTES overrides the limit (0 = never).
+// The budget is per handle (ce_set_cache_budget): the default assumes the handle has the cache to itself — what a bench or a
+// sampler without a network on the same GPU has; an integrator whose policy network, other handles or other ranks share the
+// cache passes the share it wants the env to assume (0 = never write through).
+static unsigned long long default_cache_budget(int device) {
+  if (const char* e = getenv("CE_OBS_WT_MAX_BYTES")) return (unsigned long long)atoll(e);
+  // MI355X: 256 MiB Infinity Cache behind eight 4 MiB L2s; HIP reports the L2 only, so the last-level size is taken as
+  // 64 x the L2 (256 MiB on gfx950) and an eighth of it is left to everything that is not this handle
+  int l2 = 0;
+  if (hipDeviceGetAttribute(&l2, hipDeviceAttributeL2CacheSize, device) != hipSuccess || l2 <= 0) l2 = 4 << 20;
+  const unsigned long long llc = (unsigned long long)l2 * 64ull;
+  return llc - llc / 8ull;  // 224 MiB on an MI355X
+}
 static bool obs_write_through(const ce_engine* h, unsigned long long extra_bytes = 0) {
-  static long long limit = -1;
-  if (limit < 0) {
-    const char* e = getenv("CE_OBS_WT_MAX_BYTES");
-    limit = e ? atoll(e) : (224ll << 20);
-  }
-  unsigned long long total = extra_bytes;
-  for (const auto& a : h->allocs) total += a.second;
-  return total <= (unsigned long long)limit;
+  return h->device_bytes + extra_bytes <= h->cache_budget;
+}
+extern "C" int ce_set_cache_budget(ce_handle h, uint64_t bytes) {
+  if (!h) return CE_EINVAL;
+  h->cache_budget = bytes;
+  (void)hipSetDevice(h->cfg.device);
+  return h->d_gparams ? sync_device_params(h) : CE_OK;
 }
 
 static GridParams grid_params(ce_engine* h) {
@@ -727,7 +748,7 @@ extern "C" int ce_step_range(ce_handle h, const void* actions, const uint8_t* ac
   return step_range_impl(h, actions, active, env_begin, env_count, stream, -1);
 }
 
-extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream) {
+extern "C" int ce_step_policy(ce_handle h, void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream) {
   if (!h || !policy_out) return CE_EINVAL;
   if (!is_grid(h->cfg)) return fail(h, CE_EINVAL, "ce_step_policy belongs to the grid kinds");
   if (mode != CE_POLICY_BYTES_MOD && mode != CE_POLICY_ARGMAX_F32 && mode != CE_POLICY_AHEAD_NOISE) return fail(h, CE_EINVAL, "unknown CE_POLICY_* mode");
@@ -744,7 +765,7 @@ extern "C" int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode
   return check_launch(h, "policy step kernel");
 }
 
-extern "C" int ce_step_policy_sliced(ce_handle h, const void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams) {
+extern "C" int ce_step_policy_sliced(ce_handle h, void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams) {
   if (!h || !policy_out || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   const uint32_t E = h->cfg.num_envs;
   for (uint32_t s = 0; s < num_slices; ++s) {
@@ -777,6 +798,8 @@ extern "C" int ce_rollout_fused(ce_handle h, const void* actions, uint32_t num_s
   if (!h || !actions || num_steps == 0 || num_slices == 0 || num_slices > h->cfg.num_envs) return CE_EINVAL;
   if (traj && traj->num_planes == 0) return fail(h, CE_EINVAL, "ce_traj.num_planes must be at least 1");
   if (traj && traj->first_plane >= traj->num_planes) return fail(h, CE_EINVAL, "ce_traj.first_plane out of range");
+  if (traj && (traj->num_envs != h->cfg.num_envs || traj->num_agents != h->cfg.num_agents))
+    return fail(h, CE_EINVAL, "ce_traj.num_envs / num_agents do not match this handle: the ring was sized for another batch");
   begin_call(h);
   const ce_buffers& b = h->buf;
   const uint64_t E = h->cfg.num_envs, n = h->cfg.num_agents;
@@ -1315,6 +1338,190 @@ extern "C" int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uin
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy((char*)f.base + (size_t)env_begin * f.env_bytes, src, (size_t)env_count * f.env_bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) return fail(h, CE_ENODEV, "upload", e);
+  return CE_OK;
+}
+
+// ---- one-call state snapshot (checkpoint / resume for a C caller that does not know the field list) ----
+namespace {
+struct StateField {
+  const char* name;
+  void* base;
+  size_t env_bytes;
+  bool output;  // per-step output (only with CE_STATE_OUTPUTS)
+};
+// every persistent field of the handle's kind in its DEVICE layout (grid kinds: the 32-byte presence rows, not the image),
+// then the per-step outputs
+size_t state_fields(ce_engine* h, StateField* out) {
+  const ce_buffers& b = h->buf;
+  const size_t n = b.num_agents;
+  const StateField all[] = {
+      {"error_flags", b.error_flags, 4, false},
+      {"grid", b.grid, (size_t)b.grid_env_stride, false},
+      {"agents", b.agents, n * 4, false},
+      {"spawn_perm", b.spawn_perm, 20, false},
+      {"waste_perm", b.waste_perm, 119, false},
+      {"rng", b.rng, (size_t)b.rng_words * 4, false},
+      {"timestep", b.timestep, 4, false},
+      {"theta", b.theta, 8, false},
+      {"sd_state", b.sd_state, CE_SD_STATE_DOUBLES(n) * 8, false},
+      {"int_metrics", b.int_metrics, (size_t)b.num_int_metrics * 8, false},
+      {"f64_metrics", b.f64_metrics, (size_t)b.num_f64_metrics * 8, false},
+      {"final_int_metrics", b.final_int_metrics, (size_t)b.num_int_metrics * 8, false},
+      {"final_f64_metrics", b.final_f64_metrics, (size_t)b.num_f64_metrics * 8, false},
+      {"done", b.done, 1, false},
+      {"done_agents", b.done_agents, n, false},
+      {"obs", b.obs, b.obs_env_stride, true},
+      {"obs_f64", b.obs_f64, n * (2 * n + 7) * 8, true},
+      {"base_reward", b.base_reward, n * 4, true},
+      {"reward", b.reward, n * 8, true},
+      {"info", b.info, n * 2, true},
+      {"features", b.features, n * b.num_features * 2, true},
+      {"sd_info", b.sd_info, 16, true},
+      {"beam_map", b.beam_map, (size_t)b.grid_h * b.grid_w, true},
+      {"actions_taken", b.actions_taken, n, true},
+  };
+  size_t k = 0;
+  for (const StateField& f : all)
+    if (f.base && f.env_bytes) out[k++] = f;
+  return k;
+}
+constexpr size_t kMaxStateFields = 32;
+uint64_t fnv1a(const void* p, size_t len, uint64_t hsh = 1469598103934665603ull) {
+  const unsigned char* c = (const unsigned char*)p;
+  for (size_t i = 0; i < len; ++i) hsh = (hsh ^ c[i]) * 1099511628211ull;
+  return hsh;
+}
+// what a continuation must agree on to be bit-identical: the layout text (or the shipped one's name) and the table sizes
+uint64_t layout_hash(const ce_engine* h) {
+  uint64_t v = fnv1a(&h->cfg.kind, sizeof(h->cfg.kind));
+  if (!h->map_text.empty()) {
+    v = fnv1a(&h->map_h, sizeof(h->map_h), v);
+    v = fnv1a(&h->map_w, sizeof(h->map_w), v);
+    v = fnv1a(h->map_text.data(), h->map_text.size(), v);
+  }
+  return v;
+}
+void fill_header(ce_engine* h, uint32_t what, ce_state_header* hd, const StateField* f, size_t nf, ce_state_field* dir) {
+  std::memset(hd, 0, sizeof(*hd));
+  hd->magic = CE_STATE_MAGIC;
+  hd->abi_version = CE_ABI_VERSION;
+  hd->header_bytes = (uint32_t)(sizeof(ce_state_header) + nf * sizeof(ce_state_field));
+  hd->kind = h->cfg.kind;
+  hd->num_envs = h->cfg.num_envs;
+  hd->num_agents = h->cfg.num_agents;
+  hd->contract = h->cfg.contract;
+  hd->flags = h->cfg.flags;
+  hd->horizon = h->cfg.horizon;
+  hd->what = what;
+  hd->num_fields = 0;
+  hd->env_index_base = h->cfg.env_index_base;
+  hd->layout_hash = layout_hash(h);
+  const double prm[9] = {h->cfg.contract_low, h->cfg.contract_high, h->cfg.null_prob, h->cfg.alpha, h->cfg.beta,
+                         h->cfg.low_bound, h->cfg.high_bound, h->cfg.start_vel, h->cfg.start_vel_ambulance};
+  std::memcpy(hd->params, prm, sizeof(prm));
+  uint64_t off = hd->header_bytes;
+  for (size_t i = 0; i < nf; ++i) {
+    if (f[i].output && !(what & CE_STATE_OUTPUTS)) continue;
+    ce_state_field& d = dir[hd->num_fields++];
+    std::memset(&d, 0, sizeof(d));
+    std::strncpy(d.name, f[i].name, sizeof(d.name) - 1);
+    d.env_bytes = f[i].env_bytes;
+    off = (off + 15ull) & ~15ull;
+    d.offset = off;
+    off += (uint64_t)f[i].env_bytes * h->cfg.num_envs;
+  }
+  hd->header_bytes = (uint32_t)(sizeof(ce_state_header) + hd->num_fields * sizeof(ce_state_field));
+  hd->total_bytes = (off + 15ull) & ~15ull;
+}
+}  // namespace
+
+extern "C" int ce_state_bytes(ce_handle h, uint32_t what, uint64_t* bytes) {
+  if (!h || !bytes) return CE_EINVAL;
+  if (what & ~CE_STATE_OUTPUTS) return fail(h, CE_EINVAL, "ce_state_bytes: unknown bits in `what`");
+  StateField f[kMaxStateFields];
+  ce_state_field dir[kMaxStateFields];
+  ce_state_header hd;
+  fill_header(h, what, &hd, f, state_fields(h, f), dir);
+  *bytes = hd.total_bytes;
+  return CE_OK;
+}
+
+extern "C" int ce_get_state(ce_handle h, uint32_t what, void* dst, uint64_t dst_bytes) {
+  if (!h || !dst) return CE_EINVAL;
+  if (what & ~CE_STATE_OUTPUTS) return fail(h, CE_EINVAL, "ce_get_state: unknown bits in `what`");
+  begin_call(h);
+  StateField f[kMaxStateFields];
+  ce_state_field dir[kMaxStateFields];
+  ce_state_header hd;
+  const size_t nf = state_fields(h, f);
+  fill_header(h, what, &hd, f, nf, dir);
+  if (dst_bytes < hd.total_bytes) return fail(h, CE_EINVAL, "ce_get_state: buffer smaller than ce_state_bytes");
+  hipError_t e = hipDeviceSynchronize();  // between steps, whatever stream they ran on
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "ce_get_state", e);
+  char* out = (char*)dst;
+  std::memset(out, 0, hd.header_bytes + 16);
+  std::memcpy(out, &hd, sizeof(hd));
+  std::memcpy(out + sizeof(hd), dir, hd.num_fields * sizeof(ce_state_field));
+  for (uint32_t i = 0; i < hd.num_fields; ++i) {
+    const StateField* sf = nullptr;
+    for (size_t k = 0; k < nf; ++k)
+      if (std::strcmp(f[k].name, dir[i].name) == 0) sf = &f[k];
+    e = hipMemcpy(out + dir[i].offset, sf->base, (size_t)dir[i].env_bytes * hd.num_envs, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(h, CE_ENODEV, "ce_get_state: copy", e);
+  }
+  return CE_OK;
+}
+
+extern "C" int ce_set_state(ce_handle h, const void* src, uint64_t src_bytes) {
+  if (!h || !src) return CE_EINVAL;
+  begin_call(h);
+  if (src_bytes < sizeof(ce_state_header)) return fail(h, CE_EINVAL, "ce_set_state: not a state blob (too short)");
+  ce_state_header hd;
+  std::memcpy(&hd, src, sizeof(hd));
+  if (hd.magic != CE_STATE_MAGIC) return fail(h, CE_EINVAL, "ce_set_state: not a state blob (magic)");
+  if (hd.abi_version != CE_ABI_VERSION) return fail(h, CE_EINVAL, "ce_set_state: the blob was written by another ABI version (field layouts differ)");
+  if (hd.total_bytes > src_bytes || hd.header_bytes > src_bytes || hd.num_fields > kMaxStateFields ||
+      hd.header_bytes != sizeof(ce_state_header) + hd.num_fields * sizeof(ce_state_field))
+    return fail(h, CE_EINVAL, "ce_set_state: truncated or inconsistent blob");
+  if (hd.kind != h->cfg.kind || hd.num_envs != h->cfg.num_envs || hd.num_agents != h->cfg.num_agents)
+    return fail(h, CE_EINVAL, "ce_set_state: the blob is for another kind / num_envs / num_agents");
+  if (hd.layout_hash != layout_hash(h)) return fail(h, CE_EINVAL, "ce_set_state: the blob was taken on another map layout");
+  // every parameter that enters a step: continuing under different ones would silently not reproduce the saved run
+  const uint32_t step_flags = ~(uint32_t)CE_FLAG_BEAM_TRACE;
+  const double prm[9] = {h->cfg.contract_low, h->cfg.contract_high, h->cfg.null_prob, h->cfg.alpha, h->cfg.beta,
+                         h->cfg.low_bound, h->cfg.high_bound, h->cfg.start_vel, h->cfg.start_vel_ambulance};
+  if (hd.contract != h->cfg.contract || hd.horizon != h->cfg.horizon || ((hd.flags ^ h->cfg.flags) & step_flags) != 0 ||
+      hd.env_index_base != h->cfg.env_index_base || std::memcmp(hd.params, prm, sizeof(prm)) != 0)
+    return fail(h, CE_EINVAL, "ce_set_state: blob and handle disagree on contract / flags / horizon / env_index_base / parameters");
+  StateField f[kMaxStateFields];
+  const size_t nf = state_fields(h, f);
+  const char* in = (const char*)src;
+  const ce_state_field* dir = (const ce_state_field*)(in + sizeof(ce_state_header));
+  // validate the whole directory before the first byte of the handle is touched
+  uint32_t persistent_seen = 0, persistent_need = 0;
+  for (size_t k = 0; k < nf; ++k) persistent_need += f[k].output ? 0u : 1u;
+  for (uint32_t i = 0; i < hd.num_fields; ++i) {
+    ce_state_field d;
+    std::memcpy(&d, &dir[i], sizeof(d));
+    d.name[sizeof(d.name) - 1] = 0;
+    const StateField* sf = nullptr;
+    for (size_t k = 0; k < nf; ++k)
+      if (std::strcmp(f[k].name, d.name) == 0) sf = &f[k];
+    if (!sf || sf->env_bytes != d.env_bytes || d.offset > hd.total_bytes || (uint64_t)d.env_bytes * hd.num_envs > hd.total_bytes - d.offset)
+      return fail(h, CE_EINVAL, "ce_set_state: a field of the blob does not exist on this handle or has another row size");
+    persistent_seen += sf->output ? 0u : 1u;
+  }
+  if (persistent_seen != persistent_need) return fail(h, CE_EINVAL, "ce_set_state: the blob lacks a persistent field of this handle");
+  hipError_t e = hipDeviceSynchronize();  // no step may still be writing what this replaces
+  for (uint32_t i = 0; i < hd.num_fields && e == hipSuccess; ++i) {
+    ce_state_field d;
+    std::memcpy(&d, &dir[i], sizeof(d));
+    d.name[sizeof(d.name) - 1] = 0;
+    for (size_t k = 0; k < nf; ++k)
+      if (std::strcmp(f[k].name, d.name) == 0)
+        e = hipMemcpy(f[k].base, in + d.offset, (size_t)d.env_bytes * hd.num_envs, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) return fail(h, CE_ENODEV, "ce_set_state: copy", e);
   return CE_OK;
 }
 

@@ -2427,7 +2427,12 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
 // other entry point); CE_POLICY_BYTES_MOD = one policy byte per agent, action = byte mod |A|; CE_POLICY_ARGMAX_F32 = |A| float
 // scores per agent, action = index of the first maximum (Gumbel-max sampling when the policy adds the noise).  The action a
 // policy step took is written to `actions_taken`.  Separate instances: the plain step kernel sits exactly at its 64 VGPRs.
-template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, size_t ea, u32 lane, bool is_agent, u32 A,
+// The plane a step launch takes its actions from.  Read-only (const, restrict: loads may be scalarised / hoisted) for every
+// action source but CE_POLICY_AHEAD_NOISE, whose launch also WRITES the plane: that instance gets a plain pointer, so the
+// compiler may assume nothing about it (the write went through a cast of a const __restrict__ argument).
+template <int POLICY> struct ActionPlane { typedef const uint8_t* __restrict__ type; };
+template <> struct ActionPlane<CE_POLICY_AHEAD_NOISE> { typedef uint8_t* type; };
+template <int POLICY> DEVINL u32 policy_action(typename ActionPlane<POLICY>::type src, size_t ea, u32 lane, bool is_agent, u32 A,
                                                 CE_GPTR(const uint8_t) prev_view) {
   if (POLICY == CE_POLICY_AHEAD_NOISE) {
     // the benchmark's closed-loop policy evaluated here: the env's noise byte moves on by the green channel of the cell in front
@@ -2462,7 +2467,7 @@ template <int POLICY> DEVINL u32 policy_action(const uint8_t* __restrict__ src, 
 
 template <int KIND, int NFIX, int POLICY = 0, bool CM = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, KIND == CE_KIND_CLEANUP ? CE_CLEANUP_WAVES : CE_HARVEST_WAVES) void k_grid_step(
-    const uint8_t* __restrict__ call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
+    typename ActionPlane<POLICY>::type call_actions, u32 env_first, u32 num_agents, u32* rng_base, uint8_t* grid_base, uint8_t* agents_base,
     uint8_t* waste_perm_base, const GridParams* __restrict__ pp) {
   // fourteen dwords — sixteen user SGPRs less the kernarg segment pointer — are preloaded: exactly these arguments.  The
   // launch has one workgroup per env of its range, so no upper bound travels (kWavesPerBlock == 1).
@@ -4541,7 +4546,7 @@ __global__ void k_selftest(u32* out) {
       wave_sync();
     }
   }
-  // (4) the word-parallel draws of the waste-list shuffle (shuffle_draws + the serial list update) against the serial swap
+  // (6) [bits 4, 5 belong to the counter-mode self-test] the word-parallel draws of the waste-list shuffle (shuffle_draws + the serial list update) against the serial swap
   // walk (shuffle_core) from the same generator state: list contents and stream position, over start positions that put
   // the generation end before, inside and behind the draws, and over list lengths 65 .. 128
   {
@@ -4575,11 +4580,11 @@ __global__ void k_selftest(u32* out) {
       shuffle_core<true>(rb, b0, b1, len, lane);
       shuffle_draws(ra, len, jd, lane);
       shuffle_apply(a0, a1, len, jd, lane);
-      if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0 || ra.pos != rb.pos || ra.twists != rb.twists) fail |= 16u;
+      if (ballot(a0 != b0 || (lane < len - 64 && a1 != b1)) != 0 || ra.pos != rb.pos || ra.twists != rb.twists) fail |= 64u;
       wave_sync();
     }
   }
-  // (5) the stream words of a small shuffle (consume_small: the fixed-point form, nothing stored) against the find-first walk
+  // (7) the stream words of a small shuffle (consume_small: the fixed-point form, nothing stored) against the find-first walk
   {
     for (u32 trial = 0; trial < 128; ++trial) {
       const u32 len = 2u + trial % 8u;  // 2 .. 9
@@ -4605,7 +4610,7 @@ __global__ void k_selftest(u32* out) {
       u32 d0 = 0;
       shuffle_small<2>(rb, d0, len, lane);
       consume_small(ra, len, lane);
-      if (ra.pos != rb.pos || ra.twists != rb.twists || rng_next(ra, lane) != rng_next(rb, lane)) fail |= 32u;
+      if (ra.pos != rb.pos || ra.twists != rb.twists || rng_next(ra, lane) != rng_next(rb, lane)) fail |= 128u;
       wave_sync();
     }
   }
@@ -4739,7 +4744,7 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
   const u32 first = p.env_first, count = p.env_count ? p.env_count : p.E - p.env_first;
   dim3 grid((count + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
 #define CE_STEP_LAUNCH(K_, N_, P_)                                                                                      \
-  hipLaunchKernelGGL((k_grid_step<K_, N_, P_>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
+  hipLaunchKernelGGL((k_grid_step<K_, N_, P_>), grid, block, extra_lds(), (hipStream_t)stream, (typename ActionPlane<P_>::type)p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
 #define CE_STEP_POLICY(P_)                                         \
   do {                                                             \
@@ -4751,7 +4756,7 @@ void CE_LAUNCHER(launch_grid_step_policy)(int kind, int policy, const GridParams
     }                                                              \
   } while (0)
 #define CE_STEP_POLICY_CM(K_, P_)                                                                                       \
-  hipLaunchKernelGGL((k_grid_step<K_, 0, P_, true>), grid, block, extra_lds(), (hipStream_t)stream, p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
+  hipLaunchKernelGGL((k_grid_step<K_, 0, P_, true>), grid, block, extra_lds(), (hipStream_t)stream, (typename ActionPlane<P_>::type)p.actions, first, p.n | (p.obs_wt ? 0x100u : 0u), (u32*)p.rng, \
                      (uint8_t*)p.grid, (uint8_t*)p.agents, (uint8_t*)p.waste_perm, dp)
   if (p.custom_map) {
     if (kind == CE_KIND_CLEANUP) {

@@ -102,6 +102,7 @@ class Trajectory:
         self.tensors = {}
         self.c = _lib.CeTraj()
         self.c.num_planes, self.c.first_plane = P, 0
+        self.c.num_envs, self.c.num_agents = E, n  # ABI 4: ce_rollout_fused refuses a ring sized for another batch
         for f, (shape, dt) in shapes.items():
             if fields is not None and f not in fields:
                 continue
@@ -310,7 +311,7 @@ class BatchedEnv:
         env slice per stream (None = one slice on the null stream)."""
         self._dirty()
         if traj is not None and (traj.E, traj.n, traj.env.kind) != (self.E, self.n, self.kind):
-            # the C side cannot bounds-check caller-owned arrays: a ring allocated for another batch would be overrun
+            # (ce_rollout_fused checks E and n itself since ABI 4 — ce_traj.num_envs / num_agents; the kind only exists here)
             raise ValueError("trajectory was allocated for %s E=%d n=%d, this handle is %s E=%d n=%d"
                              % (traj.env.kind, traj.E, traj.n, self.kind, self.E, self.n))
         t = None if traj is None else C.byref(traj.c)
@@ -487,12 +488,52 @@ class BatchedEnv:
             self.upload(f, state[f])
         self.check_faults()
 
-    def save(self, path):
-        np.savez_compressed(path, **self.state_dict())
+    # ---- the C-ABI's one-call snapshot (ce_state_bytes / ce_get_state / ce_set_state): save / load are thin wrappers ----
+    def get_state(self, outputs=False):
+        """the handle's whole persistent state (with outputs=True also the last step's outputs) as ONE self-describing blob
+        (uint8 array: ce_state_header + directory + fields) — what a C caller gets from ce_get_state"""
+        what = _lib.STATE_OUTPUTS if outputs else 0
+        nbytes = C.c_uint64()
+        check(self._L.ce_state_bytes(self._h, what, C.byref(nbytes)), self._h, "ce_state_bytes")
+        blob = np.empty(nbytes.value, np.uint8)
+        check(self._L.ce_get_state(self._h, what, blob.ctypes.data, blob.nbytes), self._h, "ce_get_state")
+        return blob
+
+    def set_state(self, blob):
+        """restores a blob of get_state(); raises (CE_EINVAL + the reason) when blob and handle disagree on anything that
+        enters a step — the handle is untouched then"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._dirty()
+        check(self._L.ce_set_state(self._h, blob.ctypes.data, blob.nbytes), self._h, "ce_set_state")
+        self.check_faults()
+
+    @staticmethod
+    def state_fields(blob):
+        """{field: array [E, row bytes]} views into a blob, by its directory (no field list hard-coded on this side)"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        hd = _lib.CeStateHeader.from_buffer_copy(blob[:C.sizeof(_lib.CeStateHeader)].tobytes())
+        if hd.magic != _lib.STATE_MAGIC:
+            raise ValueError("not a ce_get_state blob")
+        out, off = {}, C.sizeof(_lib.CeStateHeader)
+        for i in range(hd.num_fields):
+            d = _lib.CeStateField.from_buffer_copy(blob[off + i * C.sizeof(_lib.CeStateField):off + (i + 1) * C.sizeof(_lib.CeStateField)].tobytes())
+            out[d.name.decode()] = blob[d.offset:d.offset + d.env_bytes * hd.num_envs].reshape(hd.num_envs, d.env_bytes)
+        return out
+
+    def save(self, path, outputs=False):
+        """checkpoint file = the ce_get_state blob (compressed .npz with one member)"""
+        np.savez_compressed(path, ce_state=self.get_state(outputs))
 
     def load(self, path):
         with np.load(path) as z:
-            self.load_state_dict({k: z[k] for k in z.files})
+            if "ce_state" in z.files:
+                self.set_state(z["ce_state"])
+            else:  # a state_dict() written field by field (rounds 1-5)
+                self.load_state_dict({k: z[k] for k in z.files})
+
+    def set_cache_budget(self, nbytes):
+        """share of the GPU's last-level cache this handle may assume (ce_set_cache_budget): 0 = never write observations through"""
+        check(self._L.ce_set_cache_budget(self._h, int(nbytes)), self._h, "ce_set_cache_budget")
 
     def feature_state(self):
         """feature kinds: (apple_stamp u16 [E, 160], waste_stamp u16 [E, 120], next_stamp u32 [E, 2]) — the rank of each

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define CE_ABI_VERSION 3
+/* ABI 4 (round 6): ce_traj carries num_envs / num_agents (ce_rollout_fused refuses a ring sized for another batch);
+ * ce_state_bytes / ce_get_state / ce_set_state (one-call snapshot); ce_set_cache_budget; ce_step_policy takes a non-const
+ * plane (CE_POLICY_AHEAD_NOISE writes it).  Nothing else moved: ce_config / ce_buffers are those of ABI 3. */
+#define CE_ABI_VERSION 4
 
 /* error codes */
 #define CE_OK 0
@@ -335,10 +338,11 @@ int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint3
  *                         device with ONE launch per env slice and tick.  A policy that is a network keeps its own kernel and
  *                         hands its output over with one of the two modes above. */
 #define CE_POLICY_AHEAD_NOISE 3
-int ce_step_policy(ce_handle h, const void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream);
+/* (policy_out is not const: CE_POLICY_AHEAD_NOISE updates the plane in place; the other two modes only read it) */
+int ce_step_policy(ce_handle h, void* policy_out, uint32_t mode, uint32_t env_begin, uint32_t env_count, void* stream);
 /* ce_step_policy over all envs as `num_slices` contiguous env slices, slice i launched on streams[i] (NULL = the null stream): the
  * launch loop of a sampler tick in C — ONE host call per tick (ce_rollout's slicing rule; round 5 addition). */
-int ce_step_policy_sliced(ce_handle h, const void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams);
+int ce_step_policy_sliced(ce_handle h, void* policy_out, uint32_t mode, uint32_t num_slices, void* const* streams);
 
 /* Launch loop in C for pre-supplied actions (benchmarks, random-policy rollouts): `num_steps` consecutive
  * steps over all envs, each issued as `num_slices` ce_step_range launches on streams[0..num_slices-1] (NULL =
@@ -350,12 +354,14 @@ int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t nu
  * layout of the per-step buffer of the same name in ce_buffers: obs [P][E][obs_env_stride], base_reward [P][E][n], ...).
  * A NULL array means "not wanted as a trajectory": that output is written to the handle's own per-step buffer instead,
  * every step, and holds the last step's values on return — exactly what num_steps ce_step calls leave there.
- * The arrays are caller-owned and the library cannot bounds-check them: each non-NULL array MUST hold num_planes
- * planes of THIS handle's E and n (a ring allocated for another batch size is overrun silently; the Python front end
- * checks it, contracts_amd/engine.py: rollout_fused). */
+ * The arrays are caller-owned and the library cannot see their sizes: each non-NULL array MUST hold num_planes planes of
+ * THIS handle's E and n.  The struct says which batch they were allocated for (num_envs, num_agents) and a mismatch is
+ * refused; a caller that states the right batch but allocates less is still on its own. */
 typedef struct ce_traj {
   uint32_t num_planes;   /* planes per array; step s of a call goes to plane (first_plane + s) % num_planes   */
   uint32_t first_plane;
+  uint32_t num_envs;     /* ABI 4: the batch the arrays were sized for — must equal the handle's E and n, or     */
+  uint32_t num_agents;   /*        ce_rollout_fused returns CE_EINVAL before a byte is written                  */
   uint8_t* obs;          /* grid kinds                                                                         */
   double* obs_f64;       /* selfdrive                                                                          */
   int32_t* base_reward;
@@ -403,6 +409,44 @@ int ce_synchronize(ce_handle h, void* stream);
 int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
 int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);
 
+/* ---- one-call state snapshot (ABI 4) ----
+ * The reference never checkpoints env state; a batched engine that holds thousands of episodes must be able to.
+ * ce_get_state writes ONE self-describing blob to a host buffer: a ce_state_header, a directory of ce_state_field entries,
+ * then every persistent field of the handle's kind in its device layout (16-byte aligned) — for the grid kinds the presence
+ * rows, agent table, persistent shuffled lists, generator rows, timestep, theta, running and latched metrics, done and fault
+ * flags; selfdrive: sd_state, both generator blocks, ...; with CE_STATE_OUTPUTS also the last step's outputs (observations,
+ * rewards, infos, feature rows: what a sampler needs to choose the NEXT action after a restore).  ce_set_state restores it:
+ * the header must agree with the handle on ABI, kind, E, n, map layout (hash of the ascii_map), contract, horizon, every
+ * step-relevant flag, env_index_base and the float parameters — stepping on from a restored handle is then bit-identical to
+ * the run that was saved; any disagreement is CE_EINVAL (ce_last_error names it) and leaves the handle untouched.  A caller
+ * needs no field list: ce_state_bytes, one buffer, two calls.  Both synchronize the device. */
+#define CE_STATE_MAGIC 0x54534543u /* "CEST" */
+#define CE_STATE_OUTPUTS 0x1u      /* `what`: also the per-step output buffers */
+typedef struct ce_state_header {
+  uint32_t magic, abi_version, header_bytes, kind;
+  uint32_t num_envs, num_agents, contract, flags;
+  uint32_t horizon, what, num_fields, reserved;
+  uint64_t env_index_base, layout_hash, total_bytes;
+  double params[9]; /* contract_low, contract_high, null_prob, alpha, beta, low_bound, high_bound, start_vel, start_vel_ambulance */
+} ce_state_header;
+typedef struct ce_state_field {
+  char name[24];      /* field name as for ce_download */
+  uint64_t offset;    /* of env 0's row, from the start of the blob */
+  uint64_t env_bytes; /* row size; the field is num_envs consecutive rows */
+} ce_state_field;
+int ce_state_bytes(ce_handle h, uint32_t what, uint64_t* bytes);
+int ce_get_state(ce_handle h, uint32_t what, void* dst, uint64_t dst_bytes);
+int ce_set_state(ce_handle h, const void* src, uint64_t src_bytes);
+
+/* How much of the GPU's last-level cache (MI355X: the 256 MiB Infinity Cache) this handle may assume for itself.  Single-step
+ * launches write their observations through the L2 while the handle's device memory (+ the action planes a ce_rollout call
+ * reads) is within the budget — the views then leave the chip as they are produced instead of at the launch's end (+4 % on the
+ * headline, +20 % closed loop) — and keep them nontemporal beyond it, where a write-through store is an HBM write of its own
+ * (-30 %).  Default: 7/8 of the cache (224 MiB; CE_OBS_WT_MAX_BYTES in the environment overrides the default), i.e. the
+ * handle alone on the GPU.  An integrator whose policy network, other handles or other ranks share the cache passes the share
+ * left for this handle; 0 = never write through.  Takes effect at the next launch. */
+int ce_set_cache_budget(ce_handle h, uint64_t bytes);
+
 /* Several fields of one env slice in ONE call (the per-env adapters fetch a whole step result this way): the device is
  * synchronized once; small requests are gathered on the device into a staging buffer and leave in a single copy.
  * "grid" (which needs the expand kernel) is not accepted here.  Same slice / size rules as ce_download. */
@@ -449,7 +493,8 @@ int ce_timing_end(ce_handle h, void* stream, double* mean_ms, uint32_t* launches
 
 /* Device self-test of the wave primitives the kernels rely on (DPP reduction, parallel MT
  * twist, cross-lane list swap; bits 4, 5: Philox4x32-10 against the Random123 known-answer vectors and the counter-mode LDS
- * fill against per-block evaluation).  failed_mask: bit i set = check i failed.  0 on success. */
+ * fill against per-block evaluation; bits 6, 7: the fixed-point draws of the waste-list shuffle and of the small shuffles against
+ * the serial rejection-sampling walk, list contents and stream position).  failed_mask: bit i set = check i failed.  0 on success. */
 int ce_selftest(int device, uint32_t* failed_mask);
 
 /* 64-bit counter hash behind ce_synth_actions (selfdrive: action = ((hash>>40) / 2^24) * 0.2f - 0.1f) */

@@ -2132,3 +2132,165 @@ double orc_rng_double(uint32_t seed, int python_seeding, int index) {
   for (int i = 0; i <= index; i++) d = mt_double(&m);
   return d;
 }
+
+/* ------------------------------------------------------------------------- */
+/* The engine's own entry-point names over this library ("device = cpu"): the core of the C-ABI in                 */
+/* include/contracts_engine.h — create / seed / reset / step / step_range / rollout / buffers / download / upload / flags /    */
+/* contract — with the SAME prototypes, so that a C harness written against libcontracts_engine.so can be linked against       */
+/* liboracle.so instead and run the same calls on the host.  Every pointer is a HOST pointer, `stream`    */
+/* arguments are ignored (every call is synchronous), layouts are the ones ce_get_buffers reports here (dense 15 x 15 x 3     */
+/* views, the unpadded map image).  Still test infrastructure: the product never loads this file.  Entry points of the device  */
+/* boundary that have no host meaning (page-locked staging, hipGraph-friendly slicing, fused rollouts, write-through budget,   */
+/* the device-layout snapshot) are not restated.                                                                               */
+/* ------------------------------------------------------------------------- */
+int ce_abi_version(void) { return CE_ABI_VERSION; }
+int ce_device_count(void) { return 1; } /* the host */
+int ce_create(const ce_config* cfg, ce_handle* out) { return orc_create(cfg, (orc_t**)out); }
+int ce_destroy(ce_handle h) { return orc_destroy((orc_t*)h); }
+int ce_seed(ce_handle h, const uint64_t* seeds, uint64_t seed0, const uint8_t* mask, int mode) {
+  if (!h || (mode & ~(CE_SEED_RESEED | CE_SEED_CONSTRUCT)) || mode == 0) return CE_EINVAL;
+  return orc_seed((orc_t*)h, seeds, seed0, mask, mode);
+}
+int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
+  (void)stream;
+  return orc_reset((orc_t*)h, mask);
+}
+int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count, void* stream) {
+  (void)stream;
+  orc_t* o = (orc_t*)h;
+  if (!o || !actions || env_count == 0 || (uint64_t)env_begin + env_count > o->cfg.num_envs) return CE_EINVAL;
+  int n = o->n;
+#pragma omp parallel for schedule(static)
+  for (long ei = (long)env_begin; ei < (long)(env_begin + env_count); ei++) {
+    if (is_feat_kind(o->kind))
+      feat_step(o, (int)ei, (const uint8_t*)actions + (size_t)ei * n);
+    else if (o->kind == CE_KIND_SELFDRIVE)
+      sd_step(o, (int)ei, (const float*)actions + (size_t)ei * n, active ? active + (size_t)ei * n : NULL);
+    else
+      grid_step(o, (int)ei, (const uint8_t*)actions + (size_t)ei * n);
+  }
+  return CE_OK;
+}
+int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
+  if (!h) return CE_EINVAL;
+  return ce_step_range(h, actions, active, 0, ((orc_t*)h)->cfg.num_envs, stream);
+}
+int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) { return ce_step(h, host_actions, host_active, stream); }
+int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
+  (void)streams;
+  orc_t* o = (orc_t*)h;
+  if (!o || !actions || num_steps == 0 || num_slices == 0 || num_slices > o->cfg.num_envs) return CE_EINVAL;
+  const size_t plane = (size_t)o->cfg.num_envs * o->n * (o->kind == CE_KIND_SELFDRIVE ? 4 : 1);
+  for (uint32_t t = 0; t < num_steps; t++) {
+    int rc = ce_step(h, (const char*)actions + (size_t)t * plane, NULL, NULL);
+    if (rc != CE_OK) return rc;
+  }
+  return CE_OK;
+}
+int ce_get_buffers(ce_handle h, ce_buffers* out) { return orc_get_buffers((orc_t*)h, out); }
+int ce_synchronize(ce_handle h, void* stream) {
+  (void)stream;
+  return h ? CE_OK : CE_EINVAL;
+}
+int ce_set_contract(ce_handle h, uint32_t contract, double contract_low, double contract_high, double null_prob) {
+  orc_t* o = (orc_t*)h;
+  if (!o) return CE_EINVAL;
+  const int ok = contract == CE_CONTRACT_NONE ||
+                 (contract == CE_CONTRACT_CLEANUP && (o->kind == CE_KIND_CLEANUP || o->kind == CE_KIND_CLEANUP_FEATURES)) ||
+                 (contract == CE_CONTRACT_HARVEST_LOCAL && (o->kind == CE_KIND_HARVEST || o->kind == CE_KIND_HARVEST_FEATURES)) ||
+                 (contract == CE_CONTRACT_SELFDRIVE_DISTPROP && o->kind == CE_KIND_SELFDRIVE);
+  if (!ok) return CE_EINVAL;
+  o->cfg.contract = contract;
+  o->cfg.contract_low = contract_low;
+  o->cfg.contract_high = contract_high;
+  o->cfg.null_prob = null_prob;
+  return CE_OK;
+}
+int ce_set_flags(ce_handle h, uint32_t mask, uint32_t value) {
+  orc_t* o = (orc_t*)h;
+  if (!o || (mask & ~(CE_FLAG_AUTO_RESET | CE_FLAG_EXTERNAL_THETA | CE_FLAG_BEAM_TRACE))) return CE_EINVAL;
+  if ((mask & value & CE_FLAG_BEAM_TRACE) && o->kind != CE_KIND_CLEANUP && o->kind != CE_KIND_HARVEST) return CE_EINVAL;
+  o->cfg.flags = (o->cfg.flags & ~mask) | (value & mask);
+  return CE_OK;
+}
+typedef struct {
+  const char* name;
+  void* base;
+  size_t env_bytes;
+} orc_field_t;
+static int orc_find_field(orc_t* o, const char* name, orc_field_t* out) {
+  const ce_buffers* b = &o->b;
+  const size_t n = (size_t)o->n;
+  const orc_field_t fields[] = {
+      {"grid", b->grid, (size_t)b->grid_env_stride},
+      {"agents", b->agents, n * 4},
+      {"spawn_perm", b->spawn_perm, 20},
+      {"waste_perm", b->waste_perm, 119},
+      {"rng", b->rng, (size_t)b->rng_words * 4},
+      {"timestep", b->timestep, 4},
+      {"theta", b->theta, 8},
+      {"sd_state", b->sd_state, CE_SD_STATE_DOUBLES(n) * 8},
+      {"obs", b->obs, b->obs_env_stride},
+      {"obs_f64", b->obs_f64, n * (2 * n + 7) * 8},
+      {"base_reward", b->base_reward, n * 4},
+      {"reward", b->reward, n * 8},
+      {"done", b->done, 1},
+      {"done_agents", b->done_agents, n},
+      {"info", b->info, n * 2},
+      {"features", b->features, n * b->num_features * 2},
+      {"int_metrics", b->int_metrics, (size_t)b->num_int_metrics * 8},
+      {"f64_metrics", b->f64_metrics, (size_t)b->num_f64_metrics * 8},
+      {"final_int_metrics", b->final_int_metrics, (size_t)b->num_int_metrics * 8},
+      {"final_f64_metrics", b->final_f64_metrics, (size_t)b->num_f64_metrics * 8},
+      {"error_flags", b->error_flags, 4},
+      {"beam_map", b->beam_map, (size_t)b->grid_h * b->grid_w},
+      {"sd_info", b->sd_info, 16},
+  };
+  for (size_t i = 0; i < sizeof(fields) / sizeof(fields[0]); i++)
+    if (strcmp(fields[i].name, name) == 0) {
+      if (!fields[i].base || !fields[i].env_bytes) return 0;
+      *out = fields[i];
+      return 1;
+    }
+  return 0;
+}
+int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes) {
+  orc_t* o = (orc_t*)h;
+  orc_field_t f;
+  if (!o || !field || !dst) return CE_EINVAL;
+  if (!orc_find_field(o, field, &f)) {
+    snprintf(o->err, sizeof(o->err), "unknown or absent field");
+    return CE_EINVAL;
+  }
+  if ((uint64_t)env_begin + env_count > o->cfg.num_envs || dst_bytes < (uint64_t)env_count * f.env_bytes) {
+    snprintf(o->err, sizeof(o->err), "slice out of range");
+    return CE_EINVAL;
+  }
+  memcpy(dst, (const char*)f.base + (size_t)env_begin * f.env_bytes, (size_t)env_count * f.env_bytes);
+  return CE_OK;
+}
+/* state fields only: what is uploaded is imported into the envs' working state (orc_import_state), as ce_upload on the engine
+ * replaces the device rows a step reads */
+int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes) {
+  orc_t* o = (orc_t*)h;
+  orc_field_t f;
+  if (!o || !field || !src) return CE_EINVAL;
+  static const char* const state[] = {"grid", "agents", "spawn_perm", "waste_perm", "rng", "timestep", "theta", "sd_state"};
+  int is_state = 0;
+  for (size_t i = 0; i < sizeof(state) / sizeof(state[0]); i++) is_state |= strcmp(state[i], field) == 0;
+  if (!is_state || !orc_find_field(o, field, &f)) {
+    snprintf(o->err, sizeof(o->err), "unknown, absent or not a state field");
+    return CE_EINVAL;
+  }
+  if ((uint64_t)env_begin + env_count > o->cfg.num_envs || src_bytes < (uint64_t)env_count * f.env_bytes) {
+    snprintf(o->err, sizeof(o->err), "slice out of range");
+    return CE_EINVAL;
+  }
+  memcpy((char*)f.base + (size_t)env_begin * f.env_bytes, src, (size_t)env_count * f.env_bytes);
+  for (uint32_t e = env_begin; e < env_begin + env_count; e++) {
+    int rc = orc_import_state(o, e);
+    if (rc != CE_OK) return rc;
+  }
+  return CE_OK;
+}
+const char* ce_last_error(ce_handle h) { return h ? ((orc_t*)h)->err : "null handle"; }

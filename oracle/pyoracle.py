@@ -71,7 +71,7 @@ def make_config(kind, num_envs, num_agents, contract=None, horizon=1000, firing=
             raise ValueError("ascii_map must be a non-empty list of equally long strings")
         cfg.ascii_map = "".join(rows).encode("ascii")  # (ctypes keeps the bytes object alive with the structure)
         cfg.map_rows, cfg.map_cols = len(rows), len(rows[0])
-    cfg.abi_version = 3  # CE_ABI_VERSION of include/contracts_engine.h (the oracle refuses any other)
+    cfg.abi_version = 4  # CE_ABI_VERSION of include/contracts_engine.h (the oracle refuses any other)
     cfg.kind = KIND[kind]
     cfg.num_envs = num_envs
     cfg.num_agents = num_agents

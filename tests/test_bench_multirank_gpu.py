@@ -11,14 +11,27 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ARGS = ["--gpus", "2", "--steps", "60", "--warmup", "10", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--no-configs",
-        "--min-seconds", "0.05"]
+        "--min-seconds", "0.05", "--full", "--full-out", ""]
+
+
+def _lines(out):
+    """--full: the full record, then — LAST — the compact record the driver parses (round 6: one stdout line by default)"""
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 2, out.stdout  # only rank 0 reports
+    full, compact = json.loads(lines[0]), json.loads(lines[1])
+    assert len(lines[1]) < 4096 and compact["value"] == full["value"] and compact["ms_per_step"] == full["ms_per_step"]
+    assert compact["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4) and compact["summary"]["C4"]["G"] == full["summary"]["C4"]["G"]
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert compact[k] == full[k], k
+    assert compact["config"]["workload"] == full["config"]["workload"] and compact["ranks_seen"] == full["ranks"]["ranks_seen"]
+    return full, compact, lines[0]
 
 
 def _check(out, world=2, envs=2048):
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout  # only rank 0 reports
-    row = json.loads(lines[0])
+    row, compact, _ = _lines(out)
+    assert "cpu_baseline" not in compact or compact["cpu_baseline"] is None
+    assert compact["summary"]["parity_all_ok"] is None  # no parity leg ran (world > 1 / --no-cpu-baseline): not a pass (ADVICE r05)
     assert row["n_gpus"] == world and row["steps"] == 60 and row["scaling"] == "weak" and row["value"] > 0
     assert row["config"]["global_envs"] == world * envs and row["config"]["parallelism"].startswith("env-shard x%d" % world)
     assert row["repeats"] >= 3 and row["value_min"] <= row["value"] <= row["value_max"]
@@ -71,10 +84,14 @@ def test_bench_default_line_has_every_config():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.05",
-           "--cpu-seconds", "1.0", "--config-steps", "48", "--config-seconds", "0.05", "--config-cpu-seconds", "0.5"]
+           "--cpu-seconds", "1.0", "--config-steps", "48", "--config-seconds", "0.05", "--config-cpu-seconds", "0.5", "--full",
+           "--full-out", ""]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    row = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    row, compact, raw = _lines(out)
+    assert compact["cpu_baseline"]["kind"] == "port" and compact["cpu_baseline"]["cores"] >= 1 and "sample" in compact["cpu_baseline"]
+    assert compact["parity_in_run"]["ok"] is True and compact["parity_in_run"]["slices"] == 3  # on the timed row's launch shape
+    assert compact["summary"]["parity_all_ok"] is True and compact["summary"]["parity_legs_run"] == 6
     assert row["metric"] == "agent-steps/sec" and row["n_gpus"] == 1 and row["dtype"] == "u8"
     assert [c["config"] for c in row["configs"]] == ["C2", "C3", "C5", "C1"]
     for c in row["configs"]:
@@ -109,14 +126,14 @@ def test_bench_default_line_has_every_config():
     assert abs(rf["frac"] * 8000e9 * row["ms_per_step"] * 1e-3 - 7235 * 16384) < 0.01 * 7235 * 16384
     # round 5: the line checks its own kernels against the oracle (headline + every config row), says where its PMC constant
     # comes from, and ends in a summary that holds every row
-    raw = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     assert list(row)[-1] == "summary" and raw.rstrip().endswith("}}")
     sm = row["summary"]
-    assert sm["parity_all_ok"] is True and set(sm) >= {"C4", "C2", "C3", "C5", "C1", "closed_loop_G", "dict_M", "tensor_G", "counter_G", "beyond_cache_frac"}
-    assert len(json.dumps(sm)) < 2048 and raw.index('"summary"') > len(raw) - 2048  # inside the last 8 KB with room to spare
+    assert sm["parity_all_ok"] is True and set(sm) >= {"C4", "C2", "C3", "C5", "C1", "closed_loop_G", "closed_loop_inkernel_G", "dict_M", "tensor_G", "counter_G", "beyond_cache_frac"}
+    assert len(json.dumps(sm)) < 2048
     for r in [row] + row["configs"]:
         par = r["parity_in_run"]
         assert par["ok"] is True and par["envs"] >= 256 and par["steps"] >= 32 and "mismatches" not in par, par
+        assert par["slices"] == 3 and par["handle_envs"] == r.get("envs_per_gpu", 16384)  # the timed row's own batch and slicing
         assert par["per_step_steps"] + par["fused_steps"] == par["steps"] and par["fused_steps"] % 16 == 0 and par["fused_steps"] > 0
         assert {"agents", "rng", "reward", "done"} <= set(par["fields"]) or {"sd_state", "rng", "obs_f64"} <= set(par["fields"])
         assert "_oracle_state" not in r["cpu_baseline"]
@@ -131,5 +148,8 @@ def test_bench_default_line_has_every_config():
     assert {"inkernel_eager", "inkernel_sliced", "policy_graph_all", "inkernel_graph_all"} <= set(cl["modes"])
     assert cl["modes"]["inkernel_sliced"]["host_calls_per_step"] == 1 and cl["modes"]["inkernel_eager"]["launches_per_slice_and_step"] == 1
     assert cl["best_with_separate_policy_kernel"]["value"] > 0 and not cl["best_with_separate_policy_kernel"]["issue"].startswith("inkernel")
+    # `value` is the best row whose policy is a kernel of its own; the toy policy inside the step kernel is reported beside it
+    assert not cl["issue"].startswith("inkernel") and cl["value"] == cl["best_with_separate_policy_kernel"]["value"] or cl["slices_sweep"]
+    assert cl["inkernel_policy"]["issue"].startswith("inkernel") and sm["closed_loop_inkernel_G"] == round(cl["inkernel_policy"]["value"] / 1e9, 4)
     dp = bd["dict_protocol"]
     assert dp["recycle_dicts"] is True and dp["value"] > dp["value_incl_action_dicts"] > dp["value_with_consumer_copies"] > 0

@@ -26,7 +26,7 @@ def test_header_functions_exported():
     for name in names:
         assert hasattr(L, name), "library does not export %s" % name
         assert name in _lib.EXPORTS, "ctypes table misses %s" % name
-    assert L.ce_abi_version() == _lib.CE_ABI_VERSION == 3
+    assert L.ce_abi_version() == _lib.CE_ABI_VERSION == 4
 
 
 def test_struct_layout_matches_ctypes():
@@ -42,6 +42,9 @@ int main(void) {
   printf("%zu ", offsetof(ce_buffers, actions_taken));
   printf("%zu %zu %zu %zu %zu %d\n", offsetof(ce_buffers, sd_info), sizeof(ce_traj), offsetof(ce_traj, obs),
          offsetof(ce_traj, features), offsetof(ce_traj, sd_info), CE_ABI_VERSION);
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(ce_traj, num_envs), offsetof(ce_traj, num_agents), sizeof(ce_state_header),
+         offsetof(ce_state_header, horizon), offsetof(ce_state_header, layout_hash), offsetof(ce_state_header, params),
+         sizeof(ce_state_field), offsetof(ce_state_field, env_bytes));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -54,6 +57,9 @@ int main(void) {
     want = [C.sizeof(cfg), cfg.env_index_base.offset, cfg.contract_low.offset, cfg.start_vel_ambulance.offset,
             C.sizeof(buf), buf.grid.offset, buf.error_flags.offset,
             buf.actions_taken.offset, buf.sd_info.offset, C.sizeof(traj), traj.obs.offset, traj.features.offset, traj.sd_info.offset, _lib.CE_ABI_VERSION]
+    sh, sf = _lib.CeStateHeader, _lib.CeStateField  # ABI 4: the ring's batch echo and the one-call snapshot's header / directory
+    want += [traj.num_envs.offset, traj.num_agents.offset, C.sizeof(sh), sh.horizon.offset, sh.layout_hash.offset, sh.params.offset,
+             C.sizeof(sf), sf.env_bytes.offset]
     assert got == want
     # the oracle's own ctypes mirrors (oracle/pyoracle.py) follow the same header: orc_get_buffers writes a whole ce_buffers
     from oracle import pyoracle as po

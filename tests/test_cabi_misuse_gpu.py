@@ -129,3 +129,137 @@ def test_distinct_handles_from_concurrent_threads():
     assert sorted(threaded) == list(range(len(specs)))
     for i in range(len(specs)):
         assert threaded[i] == serial[i], specs[i]
+
+
+@pytest.mark.parametrize("kind,n,contract", [("cleanup", 5, "cleanup"), ("harvest", 3, "harvest_local"),
+                                              ("selfdrive", 4, "selfdrive_distprop"), ("harvest_features", 2, "harvest_local")])
+def test_one_call_state_snapshot_through_the_abi(kind, n, contract):
+    """ce_state_bytes / ce_get_state / ce_set_state (ABI 4): a C caller checkpoints a live handle without knowing
+    the field list — round trip mid-episode into a FRESH handle, then 50 more steps (across an in-launch reset) leave every
+    field identical to the handle that never stopped; a blob that disagrees with the handle on anything that enters a step
+    is CE_EINVAL and leaves the handle as it was."""
+    import hashlib
+    import torch
+    from contracts_amd import _lib
+    from contracts_amd.engine import BatchedEnv
+    E, kw = 48, dict(contract=contract, auto_reset=True)
+    if kind != "selfdrive":
+        kw["horizon"] = 37
+    a = BatchedEnv(kind, E, n, **kw)
+    a.seed(seed0=11)
+    a.reset()
+    dt = torch.float32 if kind == "selfdrive" else torch.uint8
+    acts = torch.empty((80, E, n), dtype=dt, device="cuda")
+    a.synth_actions(3, 0, 80, acts.data_ptr())
+    a.synchronize()
+    plane = E * n * (4 if kind == "selfdrive" else 1)
+    a.rollout_device(acts.data_ptr(), 30)
+    L, h = a._L, a._h
+    # -- through ctypes, as a C caller would
+    for what in (0, _lib.STATE_OUTPUTS):
+        nbytes = C.c_uint64()
+        assert L.ce_state_bytes(h, what, C.byref(nbytes)) == 0 and nbytes.value % 16 == 0
+        blob = np.empty(nbytes.value, np.uint8)
+        assert L.ce_get_state(h, what, blob.ctypes.data, blob.nbytes - 1) == EINVAL  # too small: nothing written past the end
+        assert L.ce_get_state(h, what, blob.ctypes.data, blob.nbytes) == 0
+        hd = _lib.CeStateHeader.from_buffer_copy(blob[:C.sizeof(_lib.CeStateHeader)].tobytes())
+        assert (hd.magic, hd.abi_version, hd.kind, hd.num_envs, hd.num_agents, hd.total_bytes) == (
+            _lib.STATE_MAGIC, _lib.CE_ABI_VERSION, _lib.KIND[kind], E, n, blob.nbytes)
+        fields = BatchedEnv.state_fields(blob)
+        assert ("obs" in fields or "obs_f64" in fields or "features" in fields) == bool(what)
+        for f, arr in fields.items():  # the directory describes exactly what ce_download hands out, row for row
+            if not (f == "grid" and kind in ("cleanup", "harvest")):  # (ce_download("grid") expands the bits to the image)
+                assert arr.tobytes() == a.download(f, raw=True).tobytes(), f
+    assert L.ce_state_bytes(h, 2, C.byref(nbytes)) == EINVAL and L.ce_get_state(None, 0, blob.ctypes.data, 1) == EINVAL
+    full = a.get_state(outputs=True)
+    # -- restore into a fresh handle that has been somewhere else, then both step on
+    b = BatchedEnv(kind, E, n, **kw)
+    b.seed(seed0=99)
+    b.reset()
+    b.rollout_device(acts.data_ptr() + 60 * plane, 5)
+    assert L.ce_set_state(b._h, full.ctypes.data, full.nbytes) == 0
+    for f in ("obs", "obs_f64", "features", "reward"):  # the outputs came along: a sampler sees the observation it left
+        if f in BatchedEnv.state_fields(full):
+            assert b.download(f, raw=True).tobytes() == a.download(f, raw=True).tobytes(), f
+    for e in (a, b):
+        e.rollout_device(acts.data_ptr() + 30 * plane, 50)
+        e.check_faults()
+
+    def digest(e):
+        m = hashlib.sha256()
+        for f, arr in sorted(BatchedEnv.state_fields(e.get_state(outputs=True)).items()):
+            m.update(f.encode() + arr.tobytes())
+        return m.hexdigest()
+
+    assert digest(a) == digest(b)
+    # -- blobs the handle must refuse, untouched
+    before = digest(b)
+
+    def refused(blob, needle, handle=b):
+        rc = L.ce_set_state(handle._h, blob.ctypes.data, blob.nbytes)
+        assert rc == EINVAL and needle in L.ce_last_error(handle._h), (rc, L.ce_last_error(handle._h))
+
+    bad = full.copy(); bad[0] ^= 1; refused(bad, b"magic")
+    bad = full.copy(); bad[4] += 1; refused(bad, b"ABI")
+    refused(full[:full.nbytes - 16], b"truncated")
+    refused(full[:8], b"too short")
+    hoff = _lib.CeStateHeader.horizon.offset
+    bad = full.copy(); bad[hoff] += 1; refused(bad, b"disagree")
+    foff = C.sizeof(_lib.CeStateHeader) + _lib.CeStateField.env_bytes.offset
+    bad = full.copy(); bad[foff] += 1; refused(bad, b"row size")
+    assert digest(b) == before
+    c = BatchedEnv(kind, E + 1, n, **kw)
+    refused(full, b"another kind", c)
+    c.close()
+    if kind == "cleanup":  # another layout: same frame, one apple cell fewer -> another hash
+        rows = _lib.static_map("cleanup")
+        r = next(i for i, row in enumerate(rows) if "B" in row)
+        rows[r] = rows[r].replace("B", " ", 1)
+        d = BatchedEnv(kind, E, n, ascii_map=rows, **kw)
+        refused(full, b"layout", d)
+        d.close()
+    for e in (a, b):
+        e.close()
+
+
+def test_fused_rollout_refuses_a_ring_sized_for_another_batch(env):
+    """ce_traj.num_envs / num_agents (ABI 4): the library cannot see the size of caller-owned trajectory
+    arrays, but it can refuse a ring that SAYS it was allocated for another batch — before a byte is written"""
+    import torch
+    from contracts_amd._lib import CeTraj
+    from contracts_amd.engine import BatchedEnv
+    L, h = env._L, env._h
+    acts = torch.zeros((4, 6, 3), dtype=torch.uint8, device="cuda")
+    small = BatchedEnv("cleanup", 4, 3, contract="cleanup", horizon=9, auto_reset=True)
+    ring = small.alloc_trajectory(2)
+    assert (ring.c.num_envs, ring.c.num_agents) == (4, 3)
+    guard = {f: t.clone() for f, t in ring.tensors.items()}
+    assert L.ce_rollout_fused(h, acts.data_ptr(), 2, 0, C.byref(ring.c), 1, None) == EINVAL and b"another batch" in L.ce_last_error(h)
+    torch.cuda.synchronize()
+    assert all(torch.equal(guard[f], ring.tensors[f]) for f in guard)
+    bare = CeTraj(num_planes=2, first_plane=0)  # a ring that does not say: refused too (0 != E)
+    assert L.ce_rollout_fused(h, acts.data_ptr(), 2, 0, C.byref(bare), 1, None) == EINVAL
+    own = env.alloc_trajectory(2)
+    assert L.ce_rollout_fused(h, acts.data_ptr(), 2, 0, C.byref(own.c), 1, None) == 0
+    env.synchronize()
+    env.check_faults()
+    small.close()
+
+
+def test_cache_budget_switches_the_store_policy_per_handle(env):
+    """ce_set_cache_budget: the write-through decision is per handle and the integrator's to override; either
+    policy writes the same bytes"""
+    import torch
+    from contracts_amd.engine import BatchedEnv
+    twin = BatchedEnv("cleanup", 6, 3, contract="cleanup", horizon=9, auto_reset=True)
+    twin.seed(seed0=5)
+    twin.reset()
+    twin.set_cache_budget(0)  # never write through
+    assert env._L.ce_set_cache_budget(None, 0) == EINVAL
+    acts = torch.randint(0, 8, (20, 6, 3), dtype=torch.uint8, device="cuda")
+    for e in (env, twin):
+        e.rollout_device(acts.data_ptr(), 20)
+        e.check_faults()
+    for f in ("obs", "rng", "reward", "features"):
+        assert env.download(f, raw=True).tobytes() == twin.download(f, raw=True).tobytes(), f
+    twin.close()
