@@ -2155,9 +2155,9 @@ int ce_reset(ce_handle h, const uint8_t* mask, void* stream) {
   (void)stream;
   return orc_reset((orc_t*)h, mask);
 }
-int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count, void* stream) {
-  (void)stream;
-  orc_t* o = (orc_t*)h;
+/* (calls between the entry points below go through static functions: with the engine loaded RTLD_GLOBAL in the same process —
+ * the parity tests load both — a call through the PLT would land in the ENGINE's function of the same name) */
+static int step_range_impl(orc_t* o, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count) {
   if (!o || !actions || env_count == 0 || (uint64_t)env_begin + env_count > o->cfg.num_envs) return CE_EINVAL;
   int n = o->n;
 #pragma omp parallel for schedule(static)
@@ -2171,18 +2171,27 @@ int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint3
   }
   return CE_OK;
 }
-int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
-  if (!h) return CE_EINVAL;
-  return ce_step_range(h, actions, active, 0, ((orc_t*)h)->cfg.num_envs, stream);
+int ce_step_range(ce_handle h, const void* actions, const uint8_t* active, uint32_t env_begin, uint32_t env_count, void* stream) {
+  (void)stream;
+  return step_range_impl((orc_t*)h, actions, active, env_begin, env_count);
 }
-int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) { return ce_step(h, host_actions, host_active, stream); }
+int ce_step(ce_handle h, const void* actions, const uint8_t* active, void* stream) {
+  (void)stream;
+  if (!h) return CE_EINVAL;
+  return step_range_impl((orc_t*)h, actions, active, 0, ((orc_t*)h)->cfg.num_envs);
+}
+int ce_step_host(ce_handle h, const void* host_actions, const uint8_t* host_active, void* stream) {
+  (void)stream;
+  if (!h) return CE_EINVAL;
+  return step_range_impl((orc_t*)h, host_actions, host_active, 0, ((orc_t*)h)->cfg.num_envs);
+}
 int ce_rollout(ce_handle h, const void* actions, uint32_t num_steps, uint32_t num_slices, void* const* streams) {
   (void)streams;
   orc_t* o = (orc_t*)h;
   if (!o || !actions || num_steps == 0 || num_slices == 0 || num_slices > o->cfg.num_envs) return CE_EINVAL;
   const size_t plane = (size_t)o->cfg.num_envs * o->n * (o->kind == CE_KIND_SELFDRIVE ? 4 : 1);
   for (uint32_t t = 0; t < num_steps; t++) {
-    int rc = ce_step(h, (const char*)actions + (size_t)t * plane, NULL, NULL);
+    int rc = step_range_impl(o, (const char*)actions + (size_t)t * plane, NULL, 0, o->cfg.num_envs);
     if (rc != CE_OK) return rc;
   }
   return CE_OK;
