@@ -743,7 +743,46 @@ def boundary(wl, E, device_index):
     out["dict_protocol_rebuilt"] = {"value": E * n / dt, "unit": "agent-steps/s", "ms_per_step": dt * 1e3,
                                     "what": "recycle_dicts=False: lazily built per-env dictionaries, every one looked up"}
     venv.stop()
+    # the joint baseline (JointEnv semantics over ONE handle: vector_env.BatchedJointBaseEnv; reference two_stage_train.py:476-617,
+    # experiment_configs/cleanup-joint-2agents.json): the centralised agent's [E, n] MultiDiscrete plane in, one launch per tick;
+    # tensor path with the global colour map produced on the device (ce_global_view), and the dict protocol for a few ticks
+    out["joint"] = joint_boundary(wl, E, device_index, planes)
     return out
+
+
+def joint_boundary(wl, E, device_index, planes):
+    import numpy as np
+    from contracts_amd.vector_env import BatchedJointBaseEnv
+    kind, n = wl["kind"], wl["n"]
+    res = {"envs": E, "agents": n, "what": "JointEnv over one engine handle: summed rewards / infos, MultiDiscrete actions as one plane"}
+    for mode in ("global", "concatenated"):
+        venv = BatchedJointBaseEnv(kind, E, n, mode=mode, seed0=SEED0, horizon=1000, device=device_index)
+        venv.poll()
+        for t in range(5):
+            venv.send_actions_array(planes[t % 8])
+            venv.poll_tensors()
+        t0, steps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.3 or steps < 20:
+            venv.send_actions_array(planes[steps % 8])
+            tt = venv.poll_tensors()
+            tt["reward"].sum().item()  # the sampler looks at the step's rewards (forces completion, incl. the view launch)
+            steps += 1
+        dt = time.perf_counter() - t0
+        row = {"tensor_value": E * n * steps / dt, "tensor_env_steps_per_s": E * steps / dt, "tensor_ms_per_step": dt / steps * 1e3}
+        acts = [{e: {"a0": planes[k][e]} for e in range(E)} for k in range(2)]
+        venv.send_actions(acts[0])
+        venv.poll()
+        t0 = time.perf_counter()
+        for k in range(2):
+            venv.send_actions(acts[k])
+            obs, rew, dones, infos, _ = venv.poll()
+            for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
+                pass
+        dt = (time.perf_counter() - t0) / 2
+        row.update({"dict_value": E * n / dt, "dict_env_steps_per_s": E / dt, "dict_ms_per_step": dt * 1e3, "unit": "agent-steps/s"})
+        res[mode] = row
+        venv.stop()
+    return res
 
 
 KERNEL = {"cleanup": ("k_grid_step<cleanup>", "k_grid_rollout<cleanup>"), "harvest": ("k_grid_step<harvest>", "k_grid_rollout<harvest>"),
@@ -1009,6 +1048,7 @@ def summary(out):
     sm["dict_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"]["value"] / 1e6, 2)
     sm["dict_incl_action_dicts_M"] = None if "dict_protocol" not in bd else round(bd["dict_protocol"].get("value_incl_action_dicts", 0) / 1e6, 2)
     sm["tensor_G"] = g((bd.get("tensor_path") or {}).get("value"))
+    sm["joint_global_tensor_G"] = g((((bd.get("joint") or {}).get("global")) or {}).get("tensor_value"))
     hb, lb = cr.get("headline_batch") or {}, cr.get("large_batch") or {}
     sm["counter_G"] = g((hb.get("counter") or {}).get("value"))
     sm["counter_frac"] = f3((hb.get("counter") or {}).get("roofline_frac"))

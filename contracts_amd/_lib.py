@@ -105,6 +105,7 @@ EXPORTS = {
     "ce_download": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
     "ce_download_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(CeFieldReq), C.c_uint32]),
     "ce_upload": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ce_global_view": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "ce_state_bytes": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "ce_get_state": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
     "ce_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),

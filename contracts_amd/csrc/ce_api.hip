@@ -1003,6 +1003,19 @@ extern "C" int ce_download(ce_handle h, const char* field, uint32_t env_begin, u
   return CE_OK;
 }
 
+// MapEnv.global_view for an env slice, on the device (JointEnv's `global_obs`): see k_grid_global_view
+extern "C" int ce_global_view(ce_handle h, uint32_t env_begin, uint32_t env_count, uint8_t* out, void* stream) {
+  if (!h || !out) return CE_EINVAL;
+  if (!is_grid(h->cfg)) return fail(h, CE_EINVAL, "ce_global_view belongs to the grid kinds (cleanup_new / harvest_new)");
+  if (env_count == 0 || (uint64_t)env_begin + env_count > h->cfg.num_envs) return fail(h, CE_EINVAL, "env range out of bounds");
+  begin_call(h);
+  if (hipError_t e = order_after_reset(h, stream); e != hipSuccess) return fail(h, CE_ENODEV, "global view: the stream could not be ordered after the last ce_reset", e);
+  launch_grid_global_view((int)h->cfg.kind, h->buf.grid, h->buf.agents, h->buf.timestep, out, env_begin, env_count, h->cfg.num_agents, h->d_tab,
+                          h->d_tab ? h->map_counts[0] : grid_napple(h->cfg), h->d_tab ? h->map_counts[1] : grid_nwaste(h->cfg), h->buf.grid_h,
+                          h->buf.grid_w, stream);
+  return check_launch(h, "global view kernel");
+}
+
 // ---- host boundary helpers (the RLlib vector hook's fast path, contracts_amd/vector_env.py) ----
 extern "C" int ce_host_alloc(uint64_t bytes, void** out) {
   if (!out) return CE_EINVAL;

@@ -167,6 +167,9 @@ void launch_feat_rollout(int kind, uint32_t num_agents, const GridParams* dp, co
 int upload_grid_tables(int kind, const GridTables& t, const uint32_t* rgb16);
 void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, uint32_t env_first, uint32_t env_count, const GridTables* tab,
                         uint32_t napple, uint32_t nwaste, void* stream);
+void launch_grid_global_view(int kind, const uint8_t* state, const uint8_t* agents, const int32_t* timestep, uint8_t* out, uint32_t env_first,
+                             uint32_t env_count, uint32_t n, const GridTables* tab, uint32_t napple, uint32_t nwaste, uint32_t H, uint32_t W,
+                             void* stream);
 void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, uint32_t* error_flags, uint32_t env_first, uint32_t env_count,
                       const GridTables* tab, uint32_t napple, uint32_t nwaste, void* stream);
 void launch_mt_seed(uint32_t* rng, uint32_t stride_words, uint32_t block_offset_words, const uint64_t* seeds_dev,

@@ -4366,6 +4366,49 @@ template <int KIND> __global__ __launch_bounds__(64) void k_grid_expand(const ui
   if (KIND == CE_KIND_CLEANUP)
     for (u32 c = lane; c < nwaste; c += 64) img[cell_pad(T.waste[c])] = (bits[4 + (c >> 5)] >> (c & 31)) & 1u ? CE_CELL_WASTE : CE_CELL_RIVER;
 }
+// ----------------------------------------------------------------------------------------
+// ce_global_view: the whole colour map of an env, agents painted — MapEnv.global_view (map_env.py:394-395:
+// world_map_color without its padding), what JointEnv's `global_obs` hands the centralised agent
+// (two_stage_train.py:531,572-586, cleanup_new.py:299-300).  world_map_color carries the agents a step painted
+// (map_env.py:257-261: in agent order, the later agent wins a shared cell) and none after reset() (map_env.py:306-342
+// rebuilds it from the map alone), so an env paints iff its timestep is past 0; beams never enter it.  One wave per env,
+// dense uint8 [H][W][3] rows.  Only launched when asked for: rollouts do not pay for it.
+// ----------------------------------------------------------------------------------------
+template <int KIND> __global__ __launch_bounds__(64) void k_grid_global_view(const uint8_t* __restrict__ state, const uint8_t* __restrict__ agents,
+                                                                          const i32* __restrict__ timestep, uint8_t* __restrict__ out,
+                                                                          u32 env_first, u32 env_count, u32 n, const GridTables* tab, u32 napple,
+                                                                          u32 nwaste, u32 H, u32 W) {
+  typedef Geo<KIND> G;
+  const GridTables& T = tab ? *tab : c_tab[KIND];
+  if (blockIdx.x >= env_count) return;
+  __shared__ uint8_t img[G::IMAGE_STRIDE];
+  const u32 lane = lane_id(), e = env_first + blockIdx.x;
+  const u32* bits = (const u32*)(state + (size_t)e * kGridStateBytes);
+  const bool blank = (bits[7] >> (kGridBlankBit & 31)) & 1u;
+  const u32* base = (const u32*)T.base_pmap;
+  u32* img4 = (u32*)img;
+  for (u32 k = lane; k < (u32)G::IMAGE_STRIDE / 4; k += 64) img4[k] = (blank || k >= (u32)G::PCELLS / 4) ? 0u : base[k];
+  __syncthreads();
+  if (!blank) {
+    for (u32 c = lane; c < napple; c += 64) img[cell_pad(T.apple[c])] = (bits[c >> 5] >> (c & 31)) & 1u ? CE_CELL_APPLE : CE_CELL_EMPTY;
+    if (KIND == CE_KIND_CLEANUP)
+      for (u32 c = lane; c < nwaste; c += 64) img[cell_pad(T.waste[c])] = (bits[4 + (c >> 5)] >> (c & 31)) & 1u ? CE_CELL_WASTE : CE_CELL_RIVER;
+  }
+  __syncthreads();
+  if (lane == 0 && timestep[e] > 0) {  // in agent order: the later agent wins
+    const uint8_t* ag = agents + (size_t)e * n * 4;
+    for (u32 a = 0; a < n; ++a) img[pad_of<KIND>(ag[4 * a], ag[4 * a + 1])] = (uint8_t)(6 + a);
+  }
+  __syncthreads();
+  uint8_t* dst = out + (size_t)blockIdx.x * H * W * 3;
+  for (u32 k = lane; k < H * W; k += 64) {
+    const u32 r = k / W, c = k - r * W;
+    const u32 rgbv = c_rgb[img[pad_of<KIND>(r, c)] & 15u];
+    dst[3 * k] = (uint8_t)rgbv;
+    dst[3 * k + 1] = (uint8_t)(rgbv >> 8);
+    dst[3 * k + 2] = (uint8_t)(rgbv >> 16);
+  }
+}
 template <int KIND> __global__ __launch_bounds__(64) void k_grid_pack(const uint8_t* __restrict__ image, uint8_t* __restrict__ state,
                                                                    u32* __restrict__ error_flags, u32 env_first, u32 env_count, const GridTables* tab,
                                                                    u32 napple, u32 nwaste) {
@@ -4810,6 +4853,15 @@ void launch_grid_expand(int kind, const uint8_t* state, uint8_t* image, u32 env_
                         u32 nwaste, void* stream) {
   if (kind == CE_KIND_CLEANUP) hipLaunchKernelGGL(k_grid_expand<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count, tab, napple, nwaste);
   else hipLaunchKernelGGL(k_grid_expand<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, image, env_first, env_count, tab, napple, nwaste);
+}
+void launch_grid_global_view(int kind, const uint8_t* state, const uint8_t* agents, const int32_t* timestep, uint8_t* out, u32 env_first,
+                             u32 env_count, u32 n, const GridTables* tab, u32 napple, u32 nwaste, u32 H, u32 W, void* stream) {
+  if (kind == CE_KIND_CLEANUP)
+    hipLaunchKernelGGL(k_grid_global_view<CE_KIND_CLEANUP>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, agents, timestep, out, env_first,
+                       env_count, n, tab, napple, nwaste, H, W);
+  else
+    hipLaunchKernelGGL(k_grid_global_view<CE_KIND_HARVEST>, dim3(env_count), dim3(64), 0, (hipStream_t)stream, state, agents, timestep, out, env_first,
+                       env_count, n, tab, napple, nwaste, H, W);
 }
 void launch_grid_pack(int kind, const uint8_t* image, uint8_t* state, u32* error_flags, u32 env_first, u32 env_count, const GridTables* tab,
                       u32 napple, u32 nwaste, void* stream) {

@@ -323,6 +323,11 @@ class BatchedEnv:
         if traj is not None:
             traj.c.first_plane = (traj.c.first_plane + int(num_steps)) % traj.c.num_planes
 
+    def global_view(self, out_ptr, env_begin=0, env_count=None, stream=None):
+        """MapEnv.global_view of the env slice into a DEVICE buffer uint8 [count, grid_h, grid_w, 3] (ce_global_view)"""
+        cnt = self.E - env_begin if env_count is None else int(env_count)
+        check(self._L.ce_global_view(self._h, int(env_begin), cnt, out_ptr, stream), self._h, "ce_global_view")
+
     def alloc_trajectory(self, num_planes, fields=None):
         """device-resident trajectory arrays [P, E, ...] for rollout_fused (torch owns the memory: plumbing only)"""
         return Trajectory(self, num_planes, fields)

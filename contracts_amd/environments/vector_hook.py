@@ -12,8 +12,13 @@ launch, with `runner.py` / `ray_config_utils.py` unchanged.  The replicas run pr
 `seed0 + index` (`seed0` = the value last passed to `env.seed()`, else the next draw of a COPY of the process-global
 `np.random`: seeded scripts stay reproducible and the global stream does not move).
 
+A `JointEnv` over a pixel grid env (`global_obs` or `concatenated_obs`: the reference's joint baseline) gets a
+`BatchedJointBaseEnv`: the same single handle, the centralised agent's MultiDiscrete action split into the [E, n] plane, summed
+rewards / infos, the global colour map produced on the device (ce_global_view) or the stacked egocentric views.
+
 Configurations the batched hook does not serve — a single sub-env, remote sub-envs, grid envs in feature-vector or
-one-hot mode, a user-defined host contract, the negotiate / combined / solver stages — get `SubEnvBaseEnv`, which keeps
+one-hot mode, a user-defined host contract, the negotiate / combined / solver stages, a JointEnv over the float path — get
+`SubEnvBaseEnv`, which keeps
 RLlib's object-per-sub-env semantics over the adapters themselves (`make_env(i)` builds the additional ones).
 """
 import numpy as np
@@ -110,10 +115,22 @@ def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_ba
     `recycle_dicts` (BatchedBaseEnv's knob, vector_env.py module docstring): None = the env's `vector_recycle_dicts`
     attribute / constructor kwarg, else CONTRACTS_AMD_VECTOR_RECYCLE (auto | on | off | checked), else "auto" — recycled
     dictionary trees only where RLlib copies every observation at once (Dict spaces: the grid kinds); Box-space kinds rebuild."""
-    from .two_stage_train import SeparateContractSubgameStage
+    from .two_stage_train import JointEnv, SeparateContractSubgameStage
     num_envs = int(num_envs)
     base, contract_kw, convolutional = env, {}, True
     batched_ok = num_envs > 1 and not remote_envs
+    if batched_ok and isinstance(env, JointEnv) and (env.global_obs or env.concatenated_obs) and hasattr(env.base_env, "_ensure_engine"):
+        # the joint baseline over a pixel grid env (experiment_configs/cleanup-joint-2agents.json): one handle, one launch per tick
+        jcfg = _engine_config(env.base_env)
+        if jcfg is not None and jcfg[0] in ("cleanup", "harvest"):
+            from ..vector_env import BatchedJointBaseEnv
+            kind, kw = jcfg
+            if seed0 is None:
+                seed0 = vector_seed0(env.base_env)
+            if kw.get("rng", "mt19937") != "counter" and int(seed0) + num_envs - 1 > 0xffffffff:
+                raise ValueError("to_base_env: seed %d + %d sub-envs runs past 2**32 - 1 (np.random.seed's range)" % (seed0, num_envs))
+            return BatchedJointBaseEnv(kind, num_envs, env.base_env.num_agents, mode="global" if env.global_obs else "concatenated",
+                                       seed0=seed0, device=getattr(env.base_env, "_device", 0), **kw)
     if isinstance(env, SeparateContractSubgameStage):
         base = env.base_env
         convolutional = env.convolutional

@@ -770,3 +770,107 @@ class BatchedBaseEnv(_RLlibBaseEnv):
 
     def stop(self):
         self.engine.close()
+
+
+class BatchedJointBaseEnv(BatchedBaseEnv):
+    """`JointEnv` semantics (reference environments/two_stage_train.py:476-617 — the joint baseline of
+    experiment_configs/cleanup-joint-2agents.json, built at utils/ray_config_utils.py:160-183) for E sub-envs from ONE engine
+    handle: RLlib's `to_base_env(num_envs=E)` of a JointEnv over a pixel grid env is one kernel launch per sampler tick
+    instead of E Python objects.  The centralised agent 'a0'
+      * sends one MultiDiscrete action per base agent (`global_action_space`): the [E, n] ids go to the device as one plane;
+      * receives the SUM of the agents' rewards (Python's left-to-right `sum`) and of every info entry (`feature_obs` rows
+        add elementwise), `dones = {'a0': d, '__all__': d}`;
+      * observes `{'image': ...}`: under `mode="global"` the whole colour map with the agents painted (`MapEnv.global_view`
+        / 255 — produced on the device by ce_global_view, [E, H, W, 3] uint8, one launch and one copy per tick), under
+        `mode="concatenated"` the n egocentric views stacked on the channel axis ([15, 15, 3 n]; the engine's `obs` buffer
+        read as [E, 15, 15, n, 3], i.e. a strided view of what the step wrote).
+    Dictionaries are built lazily per env on access, as in BatchedBaseEnv's rebuilt path (the joint baseline has one agent per
+    env: E dictionaries of one entry each).  `poll_tensors()` additionally carries `global_view` (device uint8) under
+    mode="global"."""
+
+    def __init__(self, kind, num_envs, num_agents, mode="concatenated", seed0=73907, **engine_kwargs):
+        if kind not in _GRID:
+            raise ValueError("BatchedJointBaseEnv serves the pixel grid kinds (cleanup_new / harvest_new), not %r" % (kind,))
+        if mode not in ("global", "concatenated"):
+            raise ValueError("mode must be 'global' or 'concatenated', not %r" % (mode,))
+        engine_kwargs.pop("contract", None)  # the joint baseline runs the bare base env (utils/ray_config_utils.py:159-176)
+        BatchedBaseEnv.__init__(self, kind, num_envs, num_agents, contract=None, seed0=seed0, recycle_dicts=False, **engine_kwargs)
+        self.mode = mode
+        self._gv = None  # device buffer of the global views (torch owns it: plumbing)
+
+    # ---- observations ----------------------------------------------------------------------------------------------
+    def global_view_device(self, env_begin=0, env_count=None):
+        """uint8 [E, H, W, 3] on the device: MapEnv.global_view of every sub-env; the rows of the env slice are refreshed by one
+        ce_global_view launch"""
+        import torch
+        b = self.engine.b
+        if self._gv is None:
+            self._gv = torch.zeros((self.num_envs, b.grid_h, b.grid_w, 3), dtype=torch.uint8, device="cuda:%d" % self.engine.cfg.device)
+        cnt = self.num_envs - env_begin if env_count is None else env_count
+        self.engine.global_view(self._gv[env_begin:].data_ptr(), env_begin, cnt)
+        return self._gv
+
+    def _obs_fields(self, env_begin=0, env_count=None):
+        snap = {"base": env_begin, "theta": None}
+        cnt = self.num_envs - env_begin if env_count is None else env_count
+        if self.mode == "global":
+            gv = self.global_view_device(env_begin, cnt)
+            self.engine.synchronize()
+            snap["image"] = gv[env_begin:env_begin + cnt].cpu().numpy()
+        else:
+            o = self.engine.download("obs", env_begin, env_count)  # uint8 [cnt, n, 15, 15, 3]
+            snap["image"] = np.ascontiguousarray(o.transpose(0, 2, 3, 1, 4)).reshape(o.shape[0], 15, 15, 3 * self.num_agents)
+        return snap
+
+    def _obs_of(self, snap, e, acting=None):
+        return {"a0": {"image": snap["image"][e - snap["base"]] / 255}}
+
+    # ---- BaseEnv protocol ------------------------------------------------------------------------------------------
+    def poll(self):
+        if self._pending is None:
+            ids, self._fresh = self._fresh, []
+            snap = self._obs_fields() if ids else None
+            return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": 0.0}),
+                    _LazyEnvMap(ids, lambda e: {"__all__": False}), _LazyEnvMap(ids, lambda e: {"a0": {}}), {})
+        ids, self._pending = self._pending, None
+        eng, n = self.engine, self.num_agents
+        self._settle_faults()
+        snap = self._obs_fields()
+        rew = eng.download("reward") if self._float_rewards else eng.download("base_reward")
+        total = 0  # Python's sum(): 0 + r_a0 + r_a1 + ... left to right (ints stay ints, inequity-averse floats add in that order)
+        for a in range(n):
+            total = total + rew[:, a]
+        done = eng.download("done")
+        info = eng.download("info").astype(np.int64).sum(axis=1)  # [E, 2]: eaten_apples, cleaned_squares | eaten_close_apples
+        feats = eng.download("features").astype(np.float64)
+        fsum = 0
+        for a in range(n):
+            fsum = fsum + feats[:, a]
+        self._done_ids = {int(e) for e in np.nonzero(done)[0]}
+        self._episode_over = set(self._done_ids)
+        self._reset_obs = {}
+        second = _SECOND_INFO[self.kind]
+        tot, inf = total.tolist(), info.tolist()
+
+        def dones(e):
+            d = bool(done[e])
+            return {"a0": d, "__all__": d}
+
+        return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": tot[e]}), _LazyEnvMap(ids, dones),
+                _LazyEnvMap(ids, lambda e: {"a0": {second: inf[e][1], "eaten_apples": inf[e][0], "feature_obs": fsum[e]}}), {})
+
+    def send_actions(self, action_dict):
+        """{env_id: {'a0': [action of a0, action of a1, ...]}} for every env: one [E, n] plane, one launch"""
+        E, n = self.num_envs, self.num_agents
+        if len(action_dict) != E or any(e not in action_dict for e in range(E)):
+            raise KeyError("send_actions needs actions for all %d sub-envs in one call" % E)
+        a = np.empty((E, n), np.int64)
+        for e in range(E):
+            a[e] = np.asarray(action_dict[e]["a0"]).reshape(-1)[:n]
+        self.send_actions_array(a)
+
+    def poll_tensors(self):
+        t = dict(BatchedBaseEnv.poll_tensors(self))
+        if self.mode == "global":
+            t["global_view"] = self.global_view_device()
+        return t

@@ -409,6 +409,14 @@ int ce_synchronize(ce_handle h, void* stream);
 int ce_download(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, void* dst, uint64_t dst_bytes);
 int ce_upload(ce_handle h, const char* field, uint32_t env_begin, uint32_t env_count, const void* src, uint64_t src_bytes);
 
+/* Replaces: MapEnv.global_view() (map_env.py:394-395) / get_global_obs (cleanup_new.py:299-300) — the whole colour map of
+ * each env of the slice with the agents a step painted on it (agent order, the later agent wins a shared cell; none right
+ * after a reset, as the reference's world_map_color), what JointEnv hands its centralised agent under `global_obs`
+ * (two_stage_train.py:531,572-586).  out: DEVICE pointer, uint8 [env_count][grid_h][grid_w][3], dense; the reference's
+ * float image is out / 255.  Asynchronous on `stream`, ordered after a ce_reset on another stream like a step.  Grid kinds
+ * only.  A launch of its own, issued only by callers that want the view: rollouts do not pay for it.  ABI 4. */
+int ce_global_view(ce_handle h, uint32_t env_begin, uint32_t env_count, uint8_t* out, void* stream);
+
 /* ---- one-call state snapshot (ABI 4) ----
  * The reference never checkpoints env state; a batched engine that holds thousands of episodes must be able to.
  * ce_get_state writes ONE self-describing blob to a host buffer: a ce_state_header, a directory of ce_state_field entries,

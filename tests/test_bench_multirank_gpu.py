@@ -114,6 +114,10 @@ def test_bench_default_line_has_every_config():
     bd = row["boundary"]
     assert "error" not in bd, bd
     assert bd["tensor_path"]["value"] > bd["dict_protocol"]["value"] > bd["dict_protocol_rebuilt"]["value"] > 0
+    # the joint baseline through the batched hook (round 6): JointEnv semantics over one handle, both observation modes
+    jt = bd["joint"]
+    assert "error" not in jt and jt["envs"] == 16384 and jt["global"]["tensor_value"] > jt["global"]["dict_value"] > 0
+    assert jt["concatenated"]["tensor_value"] > 0 and compact["summary"]["joint_global_tensor_G"] == round(jt["global"]["tensor_value"] / 1e9, 4)
     # the counter-RNG rows sit beside the line, never in it: the headline's rng is the reference's
     assert row["config"]["rng"] == "mt19937-numpy-compat"
     cr = row["counter_rng"]

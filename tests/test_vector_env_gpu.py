@@ -590,3 +590,99 @@ def test_a_sampler_that_holds_observations_for_several_ticks(kind, n, contract):
     assert stale_seen > 0
     for v in {id(default): default, id(rebuilt): rebuilt, id(checked): checked}.values():
         v.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["joint_cleanup_n3_global", "joint_cleanup_n3_concat", "joint_harvest_n2_global"])
+def test_joint_baseline_through_the_batched_hook(name):
+    """`to_base_env(num_envs=E)` of a JointEnv over a pixel env is ONE handle (BatchedJointBaseEnv), one
+    launch per tick.  E = 1 024; sub-env 5 is seeded like the reference-generated joint_* fixture and fed its actions: reset
+    observation, every step's observation (global colour map from ce_global_view / stacked views), summed reward, dones and
+    summed infos reproduce the reference's JointEnv trace; every OTHER sub-env is held to the oracle (views, global map composed
+    from its grid + agents, rewards, infos) on its own random actions, incl. a mid-episode try_reset (agents unpainted)."""
+    import hashlib
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.harvest_new import HarvestEnv
+    from contracts_amd.environments.map_env import AGENT_RGB, CELL_RGB
+    from contracts_amd.environments.two_stage_train import JointEnv
+    from contracts_amd.environments.vector_hook import to_base_env
+    from contracts_amd.vector_env import BatchedJointBaseEnv
+    from oracle.pyoracle import Oracle
+    import golden_check as gc
+    g = np.load("%s/%s.npz" % (gc.GOLDEN_DIR, name))
+    kind, n, seed, mode = str(g["kind"]), int(g["n"]), int(g["seed"]), str(g["mode"])
+    E, J = 1024, 5
+    base = (CleanupEnv if kind == "cleanup" else HarvestEnv)(num_agents=n)
+    env = JointEnv(base, num_agents=n, global_obs=mode == "global", concatenated_obs=mode == "concat")
+    venv = to_base_env(env, num_envs=E, seed0=seed - J)
+    assert isinstance(venv, BatchedJointBaseEnv) and venv.num_envs == E and venv.mode == ("global" if mode == "global" else "concatenated")
+    orc = Oracle(kind, E, n)
+    orc.seed(seed0=seed - J)
+    orc.reset()
+
+    def want_image(e, painted):
+        if mode == "concat":
+            return np.concatenate([orc.obs[e][i] for i in range(n)], axis=-1)
+        rgb = CELL_RGB[orc.grid[e].reshape(venv.engine.b.grid_h, venv.engine.b.grid_w)].copy()
+        if painted:
+            for i, a in enumerate(orc.agents[e]):
+                rgb[a[0], a[1]] = AGENT_RGB[i]
+        return rgb
+
+    def u8(img):
+        u = np.rint(img * 255).astype(np.uint8)
+        assert np.array_equal(u / 255, img)
+        return u
+
+    obs, rew, dones, infos, _ = venv.poll()
+    assert sorted(obs.keys()) == list(range(E)) and rew[7] == {"a0": 0.0} and dones[7] == {"__all__": False} and infos[7] == {"a0": {}}
+    assert np.array_equal(u8(obs[J]["a0"]["image"]), g["reset_obs"]) and tuple(obs[J]["a0"]["image"].shape) == tuple(g["obs_space_shape"])
+    for e in range(0, E, 37):
+        assert np.array_equal(u8(obs[e]["a0"]["image"]), want_image(e, False)), e
+    rs = np.random.RandomState(4)
+    na = venv.engine.num_actions
+    second = "cleaned_squares" if kind == "cleanup" else "eaten_close_apples"
+    painted = np.zeros(E, bool)
+    for t in range(len(g["actions"])):
+        a = rs.randint(na, size=(E, n)).astype(np.uint8)
+        a[J] = g["actions"][t]
+        venv.send_actions({e: {"a0": a[e]} for e in range(E)})
+        orc.step(a)
+        painted[:] = True
+        obs, rew, dones, infos, _ = venv.poll()
+        img = u8(obs[J]["a0"]["image"])
+        if t < len(g["obs"]):
+            assert np.array_equal(img, g["obs"][t]), t
+        assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8), g["obs_sha"][t]), t
+        assert float(rew[J]["a0"]) == g["rew"][t] and dones[J] == {"a0": bool(g["done"][t]), "__all__": bool(g["done"][t])}
+        keys = sorted(infos[J]["a0"].keys())
+        assert ",".join(keys) == str(g["info_keys"][t])
+        vals = np.concatenate([np.atleast_1d(np.asarray(infos[J]["a0"][k], np.float64)).ravel() for k in keys])
+        assert np.array_equal(vals, g["info_vals"][t]), t
+        for e in range(t % 29, E, 29):  # the rest of the batch against the oracle, a different residue class every tick
+            assert np.array_equal(u8(obs[e]["a0"]["image"]), want_image(e, painted[e])), (t, e)
+            assert rew[e]["a0"] == sum(int(x) for x in orc.base_reward[e]) and type(rew[e]["a0"]) is int
+            inf = infos[e]["a0"]
+            assert inf["eaten_apples"] == int(orc.info[e][:, 0].sum()) and inf[second] == int(orc.info[e][:, 1].sum())
+            assert np.array_equal(inf["feature_obs"], orc.features[e].astype(np.float64).sum(axis=0))
+        if t == 40:  # a mid-episode reset of two sub-envs: their maps show no agents until they step again
+            mask = np.zeros(E, np.uint8)
+            mask[[3, 900]] = 1
+            orc.reset(mask)
+            for e in (3, 900):
+                ob = venv.try_reset(e)
+                painted[e] = False
+                assert np.array_equal(u8(ob[e]["a0"]["image"]), want_image(e, False)), e
+    # the tensor path: the same tick from a dense plane, the global map stays on the device
+    a = rs.randint(na, size=(E, n)).astype(np.uint8)
+    venv.send_actions_array(a)
+    orc.step(a)
+    tt = venv.poll_tensors()
+    venv.check_faults()
+    if mode == "global":
+        gv = tt["global_view"].cpu().numpy()
+        for e in range(0, E, 41):
+            assert np.array_equal(gv[e], want_image(e, True)), e
+    assert np.array_equal(tt["reward"].cpu().numpy().sum(axis=1), orc.base_reward.sum(axis=1))
+    venv.stop()
+    base.close()
