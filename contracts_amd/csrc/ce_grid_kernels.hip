@@ -922,10 +922,10 @@ template <int KIND> DEVINL void store_rng(Env<KIND>& E, const GridParams& p, boo
       const auto base = (CE_GPTR(char))dst;
       const u32 o = E.lane << 4;
       const u32x4 v0 = {r0.x, r0.y, r0.z, r0.w}, v1 = {r1.x, r1.y, r1.z, r1.w}, v2 = {r2.x, r2.y, r2.z, r2.w};
-      asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(o), "v"(v0), "s"(base));
-      asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc1\n\ts_nop 1" ::"v"(o), "v"(v1), "s"(base));
+      asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(o), "v"(v0), "s"(base) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc1\n\ts_nop 1" ::"v"(o), "v"(v1), "s"(base) : "memory");
       if (E.lane + 128u < (u32)kMtN / 4)  // (a write-through store is a fabric write of its own: no repeats here)
-        asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc1\n\ts_nop 1" ::"v"(o), "v"(v2), "s"(base));
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048 sc1\n\ts_nop 1" ::"v"(o), "v"(v2), "s"(base) : "memory");
     } else
 #endif
     {

@@ -240,7 +240,41 @@ static PyObject* refresh_dones(PyObject* self, PyObject* args) {
   return PyLong_FromLong(changed);
 }
 
+/* assign_rows(dicts, keys, rows) -> None; dicts: list of E dictionaries, rows: list of E * len(keys) objects:
+ * dicts[e][keys[k]] = rows[e * len(keys) + k] (the Box-space kinds' observation rows, fresh every tick) */
+static PyObject* assign_rows(PyObject* self, PyObject* args) {
+  PyObject *dicts, *keys, *rows;
+  if (!PyArg_ParseTuple(args, "O!O!O!", &PyList_Type, &dicts, &PyTuple_Type, &keys, &PyList_Type, &rows)) return NULL;
+  const Py_ssize_t E = PyList_GET_SIZE(dicts), nk = PyTuple_GET_SIZE(keys);
+  if (PyList_GET_SIZE(rows) != E * nk) {
+    PyErr_SetString(PyExc_ValueError, "assign_rows: rows must hold len(dicts) * len(keys) objects");
+    return NULL;
+  }
+  for (Py_ssize_t e = 0; e < E; ++e) {
+    PyObject* d = PyList_GET_ITEM(dicts, e);
+    for (Py_ssize_t k = 0; k < nk; ++k)
+      if (PyDict_SetItem(d, PyTuple_GET_ITEM(keys, k), PyList_GET_ITEM(rows, e * nk + k)) != 0) return NULL;
+  }
+  Py_RETURN_NONE;
+}
+
+/* assign_key(dicts, key, values) -> None; dicts[i][key] = values[i] (the per-agent info dictionaries' feature_obs rows) */
+static PyObject* assign_key(PyObject* self, PyObject* args) {
+  PyObject *dicts, *key, *values;
+  if (!PyArg_ParseTuple(args, "O!OO!", &PyList_Type, &dicts, &key, &PyList_Type, &values)) return NULL;
+  const Py_ssize_t N = PyList_GET_SIZE(dicts);
+  if (PyList_GET_SIZE(values) != N) {
+    PyErr_SetString(PyExc_ValueError, "assign_key: one value per dictionary");
+    return NULL;
+  }
+  for (Py_ssize_t i = 0; i < N; ++i)
+    if (PyDict_SetItem(PyList_GET_ITEM(dicts, i), key, PyList_GET_ITEM(values, i)) != 0) return NULL;
+  Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
+    {"assign_rows", assign_rows, METH_VARARGS, "dicts[e][keys[k]] = rows[e * len(keys) + k]"},
+    {"assign_key", assign_key, METH_VARARGS, "dicts[i][key] = values[i]"},
     {"parse_actions", parse_actions, METH_VARARGS, "action dictionaries -> uint8 [E][n]"},
     {"refresh_floats", refresh_floats, METH_VARARGS, "update {agent: float} dictionaries from a float64 [E][n] snapshot"},
     {"refresh_ints", refresh_ints, METH_VARARGS, "update {agent: int} dictionaries from an int32 [E][n] snapshot"},

@@ -26,11 +26,13 @@ Built to stay usable at E = 16 384:
     dictionaries — stays intact through tick t + 1 and is REWRITTEN IN PLACE by tick t + 2.  A consumer may therefore keep a
     reference for one tick at most; anything it wants longer it must copy.
       - `"auto"` (the default): recycled for the grid kinds, whose observation space is a Dict — RLlib's
-        DictFlatteningPreprocessor copies every observation into a fresh flat array before its collectors see it — and
-        REBUILT per tick (`False`) for the feature-vector kinds, whose Box observations RLlib's NoPreprocessor / NoFilter pass
-        through by reference into the rollout fragment (a recycled buffer would alias every row of it).  Under "auto" the grid
-        kinds' info dictionaries are still recycled: a consumer that keeps `infos` beyond one tick (SampleBatch.INFOS does)
-        and reads them later wants `False`.
+        DictFlatteningPreprocessor copies every observation into a fresh flat array before its collectors see it.  The
+        feature-vector kinds, whose Box observations RLlib's NoPreprocessor / NoFilter pass through by reference into the
+        rollout fragment (a recycled buffer would alias every row of it), keep the recycled machinery but get FRESH
+        observation and `feature_obs` rows every tick (`recycle_dicts` reads "fresh_obs": one [E, n, F] copy, per-env
+        observation dictionaries over its rows) and per-tick copies of the info dictionaries.  Under "auto" the GRID kinds' info
+        dictionaries are still recycled: a consumer that keeps `infos` beyond one tick (SampleBatch.INFOS does) and reads their
+        scalar entries later wants `False`.
       - `True` / `False`: force either path.
       - `"checked"` (debug): the recycled data path with the contract ENFORCED — the generation about to be rewritten is
         poisoned first (NaN fill of its observation / feature blocks), and every array / info dictionary handed out is
@@ -224,12 +226,15 @@ class _EpochArray(np.ndarray):
     __copy__ = lambda self: self._ce_plain().copy()  # noqa: E731
 
     def __reduce__(self):
-        return (np.array, (self._ce_plain().tolist(),))
+        a = self._ce_plain()
+        return (np.array, (a.tolist(), a.dtype.str))  # (values AND dtype: tolist() alone would come back float64 / int64)
 
 
-def _stamp(arr, owner):
+def _stamp(arr, owner, epoch=None):
+    """`epoch` = the generation's epoch at the poll() the array belongs to (None: now) — a wrapper built LATER from a mapping that
+    poll() returned earlier must carry the epoch of that poll, not of the access"""
     v = arr.view(_EpochArray)
-    v._ce_owner, v._ce_epoch = owner, owner.epoch
+    v._ce_owner, v._ce_epoch = owner, owner.epoch if epoch is None else epoch
     return v
 
 
@@ -237,9 +242,9 @@ class _EpochDict(dict):
     """recycle_dicts="checked": an info / observation dictionary stamped like _EpochArray (reads raise once stale)"""
     __slots__ = ("_ce_owner", "_ce_epoch")
 
-    def __init__(self, owner, items):
+    def __init__(self, owner, items, epoch=None):
         dict.__init__(self, items)
-        self._ce_owner, self._ce_epoch = owner, owner.epoch
+        self._ce_owner, self._ce_epoch = owner, owner.epoch if epoch is None else epoch
 
     def _ok(self):
         _stale(self._ce_owner, self._ce_epoch)
@@ -366,6 +371,7 @@ class _DictGeneration:
             self.dones[e] = {"__all__": False, "a0": False, "a1": False}  # the reference's dones dict (cleanup_new.py:242)
         self.reward_list = [self.rewards[e] for e in range(E)]
         self.done_list = [self.dones[e] for e in range(E)]
+        self.obs_list = [self.obs[e] for e in range(E)]
 
     def poison(self):
         """"checked": what a holder of this generation's previous hand-out would read from now on is NaN, not plausible data"""
@@ -398,11 +404,16 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         # (selfdrive's dictionaries change their key sets with the acting cars: always rebuilt)
         if recycle_dicts not in ("auto", "checked", True, False):
             raise ValueError("recycle_dicts must be 'auto', 'checked', True or False, not %r" % (recycle_dicts,))
-        if recycle_dicts == "auto":  # see the module docstring: Dict observation spaces are copied by RLlib's preprocessor
-            recycle_dicts = kind in _GRID
+        # "auto" (see the module docstring): Dict observation spaces are copied by RLlib's preprocessor, so the grid kinds recycle
+        # everything; the Box-space feature kinds keep the recycled machinery (C action parser, asynchronous copies, refreshed
+        # reward / done / info trees) but hand out FRESH observation / feature_obs rows every tick — the only objects RLlib's
+        # NoPreprocessor keeps by reference (dropping the whole fast path cost ~290 ms instead of ~8 ms per tick)
+        self._fresh_obs = recycle_dicts == "auto" and kind in ("harvest_features", "cleanup_features")
+        if recycle_dicts == "auto":
+            recycle_dicts = kind in _GRID or self._fresh_obs
         self._checked = recycle_dicts == "checked" and kind != "selfdrive"
         self._recycle = bool(recycle_dicts) and kind != "selfdrive"
-        self.recycle_dicts = "checked" if self._checked else self._recycle
+        self.recycle_dicts = "checked" if self._checked else ("fresh_obs" if self._fresh_obs else self._recycle)
         self._gens, self._gen = [None, None], 0
         self._act_planes, self._act_turn = None, 0
         self._keys_t = tuple(self._keys)
@@ -649,11 +660,24 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             t2 = time.perf_counter()
         finally:
             job.result()
+        if self._fresh_obs:  # Box-space kinds under "auto": this tick's rows live in arrays of their own (nothing rewrites them)
+            fresh = G.obs_vec.copy()
+            rows = list(fresh.reshape(self.num_envs * self.num_agents, fresh.shape[2]))
+            n, keys = self.num_agents, self._keys
+            fresh_obs = {e: dict(zip(keys, rows[e * n:(e + 1) * n])) for e in self._env_keys}  # (per-env dictionaries of their own too)
+            if G.key0 is not None:  # infos[..]['feature_obs'] (kept by SampleBatch.INFOS): the feature part of the same rows
+                F = G.feat_f64.shape[2]
+                pd.assign_key(G.agent_infos, "feature_obs", rows if fresh.shape[2] == F else [r[:F] for r in rows])
+            # ... and info dictionaries of their own too (SampleBatch.INFOS keeps the dictionary objects): copies of the refreshed ones
+            flat = [d.copy() for d in G.agent_infos]
+            fresh_infos = {e: dict(zip(keys, flat[e * n:(e + 1) * n])) for e in self._env_keys}
         t3 = time.perf_counter()
         tm["step_and_small_fields_ms"], tm["refresh_dicts_ms"], tm["wait_for_obs_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
         tm["poll_ms"] = (t3 - t0) * 1e3
         if self._checked:
             return self._checked_maps(G)
+        if self._fresh_obs:
+            return fresh_obs, G.rewards, G.dones, fresh_infos, {}
         return G.obs, G.rewards, G.dones, G.infos, {}
 
     def _checked_maps(self, G):
@@ -663,27 +687,31 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         keys, contract, second, key0 = self._keys, bool(self.contract), G.second, G.key0
         ids = self._env_keys
         rew, info, done = G.rew.tolist(), G.info.tolist(), G.done.tolist()
+        epoch = G.epoch  # of THIS poll: a sampler that keeps the top-level mappings and first indexes them two ticks later gets
+        #                  StaleDictError from the builder, never wrappers stamped with the newer epoch over the newer data
 
         def obs(e):
+            _stale(G, epoch)
             if G.grid:
                 img = G.obs_f64[e]
                 if contract:
-                    c = _stamp(G.cobs[e], G)
-                    return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G)), ("contract", c)))) for i, k in enumerate(keys)))
-                return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G)),))) for i, k in enumerate(keys)))
+                    c = _stamp(G.cobs[e], G, epoch)
+                    return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G, epoch)), ("contract", c)), epoch)) for i, k in enumerate(keys)), epoch)
+                return _EpochDict(G, ((k, _EpochDict(G, (("image", _stamp(img[i], G, epoch)),), epoch)) for i, k in enumerate(keys)), epoch)
             ov = G.obs_vec[e]
-            return _EpochDict(G, ((k, _stamp(ov[i], G)) for i, k in enumerate(keys)))
+            return _EpochDict(G, ((k, _stamp(ov[i], G, epoch)) for i, k in enumerate(keys)), epoch)
 
         def infos(e):
+            _stale(G, epoch)
             fe = G.feat_f64[e]
             out = {}
             for i, k in enumerate(keys):
                 it = [(second, info[e][i][1])]
                 if key0 is not None:
-                    it += [("eaten_apples", info[e][i][0]), ("feature_obs", _stamp(fe[i], G))]
+                    it += [("eaten_apples", info[e][i][0]), ("feature_obs", _stamp(fe[i], G, epoch))]
                 if contract:
-                    it.append(("contract_param", _stamp(G.cparam[e], G)))
-                out[k] = _EpochDict(G, it)
+                    it.append(("contract_param", _stamp(G.cparam[e], G, epoch)))
+                out[k] = _EpochDict(G, it, epoch)
             return out
 
         def dones(e):

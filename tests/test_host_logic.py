@@ -397,11 +397,14 @@ def test_to_base_env_maps_the_env_configuration(monkeypatch):
     HarvestEnv(num_agents=3, horizon=50, rng="private").to_base_env(num_envs=4)
     assert made[-1].seeded == int(np.random.RandomState(4243).randint(0, 2 ** 31 - 1))
 
-    # recycle_dicts: "auto" recycles the dictionary trees only where RLlib copies every observation at once (Dict spaces: the
-    # grid kinds); the Box-space feature kinds rebuild per tick; the env attribute / the environment variable force a mode
+    # recycle_dicts: "auto" recycles the dictionary trees where RLlib copies every observation at once (Dict spaces: the grid
+    # kinds); the Box-space feature kinds keep the recycled machinery but hand out fresh observation rows / info dictionaries
+    # every tick ("fresh_obs"); the env attribute / the environment variable force a mode
     from contracts_amd.environments.feature_envs import HarvestFeatures
     assert plain.to_base_env(num_envs=4).recycle_dicts is True
     hf = HarvestFeatures(num_agents=2, horizon=50, rng="private")
+    assert hf.to_base_env(num_envs=4).recycle_dicts == "fresh_obs"
+    hf.vector_recycle_dicts = False
     assert hf.to_base_env(num_envs=4).recycle_dicts is False
     hf.vector_recycle_dicts = True
     assert hf.to_base_env(num_envs=4).recycle_dicts is True

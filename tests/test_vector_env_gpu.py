@@ -533,7 +533,7 @@ def test_a_sampler_that_holds_observations_for_several_ticks(kind, n, contract):
     keys = ["a%d" % i for i in range(n)]
     box_space = kind in ("harvest_features", "cleanup_features")
     default = BatchedBaseEnv(kind, E, n, **kw)
-    assert default.recycle_dicts is (not box_space)
+    assert default.recycle_dicts == ("fresh_obs" if box_space else True)  # Box spaces: recycled machinery, fresh rows / info dicts per tick
     rebuilt = default if box_space else BatchedBaseEnv(kind, E, n, recycle_dicts=False, **kw)
     checked = BatchedBaseEnv(kind, E, n, recycle_dicts="checked", **kw)
     assert checked.recycle_dicts == "checked"
@@ -588,6 +588,30 @@ def test_a_sampler_that_holds_observations_for_several_ticks(kind, n, contract):
                 # rewritten since (age 2: by this very tick); what np.asarray() of the stale wrapper reads is never the kept value's
                 # owner any more — the wrapper's hooks are what protects the consumer
     assert stale_seen > 0
+    # a sampler that keeps the TOP-LEVEL mappings of tick t and first indexes them at t + 2 must get StaleDictError
+    # too — not wrappers stamped with the newer epoch over the newer tick's data
+    a = rs.randint(na, size=(E, n))
+    ad = {e: {k: int(a[e, i]) for i, k in enumerate(keys)} for e in range(E)}
+    checked.send_actions(ad)
+    o_kept, _, _, i_kept, _ = checked.poll()
+    first = o_kept[sample[0]]  # indexed in its own tick: fine, and stays readable for one more tick
+    for _ in range(2):
+        checked.send_actions(ad)
+        checked.poll()
+    with pytest.raises(StaleDictError):
+        o_kept[sample[1]]
+    with pytest.raises(StaleDictError):
+        i_kept[sample[1]]
+    with pytest.raises(StaleDictError):
+        equal(first, first)
+    import pickle
+    fresh_o = checked.poll  # (a pickled stamped array comes back with its dtype)
+    checked.send_actions(ad)
+    o_now, _, _, i_now, _ = checked.poll()
+    some = i_now[sample[0]]["a0"].get("feature_obs") if not (kind == "cleanup_features") else None
+    if some is not None:
+        back = pickle.loads(pickle.dumps(some))
+        assert isinstance(back, np.ndarray) and back.dtype == np.float64 and np.array_equal(back, np.asarray(some.copy()))
     for v in {id(default): default, id(rebuilt): rebuilt, id(checked): checked}.values():
         v.stop()
 

@@ -6,8 +6,8 @@ cd $R
 timeout 900 python -m pytest tests/test_write_through_gpu.py tests/test_bench_multirank_gpu.py -m gpu -x -q 2>&1 | tail -3
 for i in 1 2; do
   for thr in 0 1000000000000; do
-    CE_OBS_WT_MAX_BYTES=$thr timeout 600 python3 bench.py --no-configs --no-boundary --no-counter-rng --no-cpu-baseline > $OUT/b_$thr_$i.json 2>/dev/null
-    python3 - $OUT/b_$thr_$i.json $thr <<'PY'
+    CE_OBS_WT_MAX_BYTES=$thr timeout 600 python3 bench.py --no-configs --no-boundary --no-counter-rng --no-cpu-baseline > $OUT/b_${thr}_${i}.json 2>/dev/null
+    python3 - $OUT/b_${thr}_${i}.json $thr <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 cl = d["closed_loop"]
