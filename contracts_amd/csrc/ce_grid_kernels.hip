@@ -1552,7 +1552,13 @@ template <int KIND> DEVINL void custom_map_update(Env<KIND>& E) {
 // `obs` = base of the [E][obs_env_stride] plane this step's observation goes to.  RESTORE (fused rollouts): the map
 // bytes under the painted agents are put back afterwards (cell code only, agent bit cleared), so the LDS map stays the
 // env's map for the next step of the same launch.
-template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, const GridParams& p, CE_GPTR(uint8_t) obs, bool paint_agents) {
+struct NoHook {
+  DEVINL void operator()() const {}
+};
+// `round_hook()`: called once per view round (two agents' views), between a round's gathers and its stores — independent LDS work
+// of the caller's (the feature scan's chunks, compute_features) shares the round's waits
+template <int KIND, bool RESTORE = false, class HOOK = NoHook>
+DEVINL void write_obs(Env<KIND>& E, const GridParams& p, CE_GPTR(uint8_t) obs, bool paint_agents, HOOK&& round_hook = HOOK()) {
   typedef Geo<KIND> G;
   const u32 lane = E.lane;
   uint8_t* pm = E.L->pmap;
@@ -1653,6 +1659,7 @@ template <int KIND, bool RESTORE = false> DEVINL void write_obs(Env<KIND>& E, co
     for (u32 a = 0; a < E.n; a += 2) {
       const u32 a1 = min(a + 1u, E.n - 1u);
       const u32x3 d0 = view_unit(a), d1 = view_unit(a1);
+      round_hook();
       put_unit(a, d0);
       put_unit(a1, d1);
     }
@@ -1802,8 +1809,17 @@ template <class P> DEVINL void store_feat2(P f, u32 idx, u32 lo, u32 hi, bool al
 
 // presA / presW (out): the presence ballots of the map as it is now (apple on apple cell lane + 64 r, waste likewise) — the
 // packed map state of a single-step launch is assembled from them (store_grid_bits) instead of scanning the map again
-template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned,
-                                                u64 (&presA)[3], u64 (&presW)[2]) {
+// `mid(scan_step)`: called once the key lists are published, with the scan's loop body as a callable (one 4-cell chunk per list
+// and call, a no-op once the lists are through); chunks mid() did not take are scanned afterwards.  The hook exists for the
+// round-6 experiment that ran the observation pass there (-DCE_FEATSCAN_INTERLEAVE, grid_step_core): the scan's LDS round
+// trips — two 16-byte reads and a wait per chunk, a chain nothing else fills: ablated, the scan is worth + 8 % on the resident
+// kernels for 3.5 % of their instructions (profiles/r06_phase_ablations.txt) — would travel with the views' own gathers.  It
+// costs registers the step kernel does not have (see there); the default passes no mid.
+struct NoMid {
+  template <class F> DEVINL void operator()(F&&) const {}
+};
+template <int KIND, class MID = NoMid> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& p, CE_GPTR(int16_t) features, u32 cleaned,
+                                                                   u64 (&presA)[3], u64 (&presW)[2], MID&& mid = MID()) {
   typedef Geo<KIND> G;
   const GridTables& T = *E.T;
   const u32 lane = E.lane, n = E.n;
@@ -1855,36 +1871,7 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
   const u32 sh = n <= 4 ? 4u : n <= 8 ? 3u : 2u;
   const u32 ga = lane >> sh, gl = lane & ((1u << sh) - 1u);
   const u32 prc = bperm(mycol | myrow << 8, ga);  // also the wave_sync-free way to get agent ga's position
-  wave_sync();
-  u32 ka = 0xffffffffu, kw = 0xffffffffu;
-#pragma unroll 1  // unrolling keeps 8 b128 loads in flight and costs an occupancy step
-  for (u32 kc = 0; kc < (diag::ablate_featscan ? 0u : (NCHUNK >> sh)); ++kc) {  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
-    const u32 c = gl + (kc << sh);
-    // key = manhattan << 16 | row << 8 | col in one v_sad_hi_u8 per cell (absent entries land at >= kNoKey)
-    const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
-    const u32 k0 = __builtin_amdgcn_sad_hi_u8(a4.x, prc, a4.x), k1 = __builtin_amdgcn_sad_hi_u8(a4.y, prc, a4.y);
-    const u32 k2 = __builtin_amdgcn_sad_hi_u8(a4.z, prc, a4.z), k3 = __builtin_amdgcn_sad_hi_u8(a4.w, prc, a4.w);
-    ka = min3u(min3u(ka, k0, k1), k2, k3);
-    if (KIND == CE_KIND_CLEANUP) {
-      const uint4 w4 = *reinterpret_cast<const uint4*>(keyW + 4 * c);
-      const u32 q0 = __builtin_amdgcn_sad_hi_u8(w4.x, prc, w4.x), q1 = __builtin_amdgcn_sad_hi_u8(w4.y, prc, w4.y);
-      const u32 q2 = __builtin_amdgcn_sad_hi_u8(w4.z, prc, w4.z), q3 = __builtin_amdgcn_sad_hi_u8(w4.w, prc, w4.w);
-      kw = min3u(min3u(kw, q0, q1), q2, q3);
-    }
-  }
-  ka = group_min_u32(ka, sh);
-  if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
-  if (ka >= kNoKey) ka = 0;  // [0, 0] sentinel when there is none
-  if (kw >= kNoKey) kw = 0;
-  if (!al && gl == 0 && ga < n) {  // odd row pitch: the group's first lane writes agent ga's closest-apple / -waste features
-    auto f = feat_env + __umul24(ga, nf);
-    store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
-    if (KIND == CE_KIND_CLEANUP) store_feat2(f, 8, (kw >> 8) & 0xffu, kw & 0xffu, al);
-  }
-  // dword-aligned rows (every harvest row, cleanup with an even n): agent lane a fetches its group's minima and
-  // writes its whole row as a few wide stores in ONE predicated block (it was ~10 dword stores in 3 blocks)
-  const u32 lead = E.is_agent ? lane << sh : 0u;
-  const u32 ka_a = bperm(ka, lead), kw_a = KIND == CE_KIND_CLEANUP ? bperm(kw, lead) : 0u;
+  // harvest: apples in each agent's 21-cell neighbourhood, read here — before mid() may paint the agents over the map
   u32 close_now = 0;
   if (KIND == CE_KIND_HARVEST) {
     if (n <= 8) {
@@ -1910,6 +1897,42 @@ template <int KIND> DEVINL u32 compute_features(Env<KIND>& E, const GridParams& 
       }
     }
   }
+  wave_sync();
+  u32 ka = 0xffffffffu, kw = 0xffffffffu;
+  u32 kc = 0;
+  const u32 chunks = diag::ablate_featscan ? 0u : (NCHUNK >> sh);  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
+  auto scan_step = [&]() {
+    if (kc >= chunks) return;
+    const u32 c = gl + (kc << sh);
+    ++kc;
+    // key = manhattan << 16 | row << 8 | col in one v_sad_hi_u8 per cell (absent entries land at >= kNoKey)
+    const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
+    const u32 k0 = __builtin_amdgcn_sad_hi_u8(a4.x, prc, a4.x), k1 = __builtin_amdgcn_sad_hi_u8(a4.y, prc, a4.y);
+    const u32 k2 = __builtin_amdgcn_sad_hi_u8(a4.z, prc, a4.z), k3 = __builtin_amdgcn_sad_hi_u8(a4.w, prc, a4.w);
+    ka = min3u(min3u(ka, k0, k1), k2, k3);
+    if (KIND == CE_KIND_CLEANUP) {
+      const uint4 w4 = *reinterpret_cast<const uint4*>(keyW + 4 * c);
+      const u32 q0 = __builtin_amdgcn_sad_hi_u8(w4.x, prc, w4.x), q1 = __builtin_amdgcn_sad_hi_u8(w4.y, prc, w4.y);
+      const u32 q2 = __builtin_amdgcn_sad_hi_u8(w4.z, prc, w4.z), q3 = __builtin_amdgcn_sad_hi_u8(w4.w, prc, w4.w);
+      kw = min3u(min3u(kw, q0, q1), q2, q3);
+    }
+  };
+  mid(scan_step);
+#pragma unroll 1  // unrolling keeps 8 b128 loads in flight and costs an occupancy step
+  while (kc < chunks) scan_step();
+  ka = group_min_u32(ka, sh);
+  if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
+  if (ka >= kNoKey) ka = 0;  // [0, 0] sentinel when there is none
+  if (kw >= kNoKey) kw = 0;
+  if (!al && gl == 0 && ga < n) {  // odd row pitch: the group's first lane writes agent ga's closest-apple / -waste features
+    auto f = feat_env + __umul24(ga, nf);
+    store_feat2(f, 6, (ka >> 8) & 0xffu, ka & 0xffu, al);
+    if (KIND == CE_KIND_CLEANUP) store_feat2(f, 8, (kw >> 8) & 0xffu, kw & 0xffu, al);
+  }
+  // dword-aligned rows (every harvest row, cleanup with an even n): agent lane a fetches its group's minima and
+  // writes its whole row as a few wide stores in ONE predicated block (it was ~10 dword stores in 3 blocks)
+  const u32 lead = E.is_agent ? lane << sh : 0u;
+  const u32 ka_a = bperm(ka, lead), kw_a = KIND == CE_KIND_CLEANUP ? bperm(kw, lead) : 0u;
   auto f = feat_env + __umul24(E.is_agent ? lane : 0u, nf);
   if (al) {
     typedef u32 u32x2 __attribute__((ext_vector_type(2)));
@@ -2227,18 +2250,38 @@ DEVINL void grid_step_core(Env<KIND>& E, const GridParams& p, const OUT& out, u3
   CE_STAMP(5);
   // ---------------- feature obs, infos, metrics ----------------
   u64 presA[3] = {0, 0, 0}, presW[2] = {0, 0};
-  const u32 feat8 = diag::ablate_features ? 0u : compute_features(E, p, out.features(), cleaned, presA, presW);
   // The observation (the bulk of the step's stores) goes out as early as the map allows, so that its stores drain
   // under the epilogue's arithmetic instead of at the wave's very end.  It paints the agents over the map bytes,
-  // hence after the feature pass and after the map state is packed; a done step with auto-reset writes the reset
-  // observation instead and keeps the late path.
+  // hence after the feature pass has read the map and after the map state is packed; a done step with auto-reset writes
+  // the reset observation instead and keeps the late path.  -DCE_FEATSCAN_INTERLEAVE runs it INSIDE the feature pass
+  // (compute_features' `mid`: the closest-apple / -waste scan only reads its key lists, so its chunks could ride along with
+  // the view rounds) — measured in round 6 and NOT the default: the merged live ranges spill 16 VGPRs in the headline
+  // instance (C4 per-step 4.40 -> 3.0 G, counter 4.97 -> 4.27, fused - 2.5 %: profiles/r06_ab_scan_interleave.txt).
   const bool obs_early = t != p.horizon;
-  if (obs_early) {
-    if (!FUSED) {  // a fused rollout keeps the map in LDS and packs it once, after its last step
-      if (diag::ablate_features) store_grid(E, p);
-      else store_grid_bits(E, p, presA, presW);  // the feature pass has just taken the map's presence ballots
+  auto obs_pass = [&](auto&& scan_step) {
+    if (!obs_early) return;
+    if (!FUSED) store_grid_bits(E, p, presA, presW);  // (a fused rollout keeps the map in LDS and packs it once, after its last step)
+    if (!diag::ablate_obs) {
+#ifdef CE_FEATSCAN_INTERLEAVE
+      write_obs<KIND, FUSED>(E, p, out.obs(), true, scan_step);
+#else
+      write_obs<KIND, FUSED>(E, p, out.obs(), true);
+#endif
     }
-    if (!diag::ablate_obs) write_obs<KIND, FUSED>(E, p, out.obs(), true);
+  };
+  u32 feat8 = 0;
+  if (diag::ablate_features) {
+    if (obs_early) {
+      if (!FUSED) store_grid(E, p);
+      if (!diag::ablate_obs) write_obs<KIND, FUSED>(E, p, out.obs(), true);
+    }
+  } else {
+#ifdef CE_FEATSCAN_INTERLEAVE
+    feat8 = compute_features(E, p, out.features(), cleaned, presA, presW, obs_pass);
+#else
+    feat8 = compute_features(E, p, out.features(), cleaned, presA, presW);
+    obs_pass([] {});
+#endif
   }
   const double rew_env = rew;  // the env's own reward (after collective / inequity aversion), before the contract
   // A quiet step — nobody ate, cleaned, fired or was hit: every reward, transfer and metric increment is zero — skips the
