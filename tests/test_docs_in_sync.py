@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05_bench_driver.json")
+LINE = os.path.join(ROOT, "profiles", "r06_bench_driver.json")
 
 
 def test_design_table_matches_the_committed_bench_line():
