@@ -844,14 +844,15 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         if self.mode == "global":
             gv = self.global_view_device(env_begin, cnt)
             self.engine.synchronize()
-            snap["image"] = gv[env_begin:env_begin + cnt].cpu().numpy()
+            u8 = gv[env_begin:env_begin + cnt].cpu().numpy()
         else:
             o = self.engine.download("obs", env_begin, env_count)  # uint8 [cnt, n, 15, 15, 3]
-            snap["image"] = np.ascontiguousarray(o.transpose(0, 2, 3, 1, 4)).reshape(o.shape[0], 15, 15, 3 * self.num_agents)
+            u8 = np.ascontiguousarray(o.transpose(0, 2, 3, 1, 4)).reshape(o.shape[0], 15, 15, 3 * self.num_agents)
+        snap["image"] = _ImageChunks(u8)  # value / 255 -> float64 (cleanup_new.py:300), chunks converted on the worker threads
         return snap
 
     def _obs_of(self, snap, e, acting=None):
-        return {"a0": {"image": snap["image"][e - snap["base"]] / 255}}
+        return {"a0": {"image": snap["image"].env(e - snap["base"])}}
 
     # ---- BaseEnv protocol ------------------------------------------------------------------------------------------
     def poll(self):
