@@ -145,7 +145,14 @@ def test_bench_default_line_has_every_config():
         assert abs(sm[key]["G"] - round(r["value"] / 1e9, 4)) < 1e-9 and sm[key]["parity_ok"] is True
     cpar = cr["parity_in_run"]  # the counter-mode kernels against the oracle's restatement of that stream, in the run
     assert cpar["ok"] is True and cpar["envs"] == 2048 and cpar["steps"] == 1152 and sm["counter_parity_ok"] is True
-    assert rf["traffic_ratio"] is None or (1.0 < rf["traffic_ratio"] < 3.0 and "profiles/traffic.json @" in rf["traffic_source"])
+    # roofline.traffic of the headline is measured IN the run (two rocprofv3 --pmc child passes); the committed constant stays beside it
+    assert rf["traffic_live"] in (True, False), rf
+    if rf["traffic_live"]:
+        assert "measured in this run" in rf["traffic_source"] and 1.0 < rf["traffic_ratio"] < 3.0 and compact["roofline"]["traffic_live"] is True
+        assert rf["traffic_committed"] and abs(rf["traffic"] / rf["traffic_committed"] - 1.0) < 0.15  # the two agree within the run-to-run spread
+    else:
+        assert rf["traffic_live_error"]
+    assert rf["traffic_committed_source"] is None or "profiles/traffic.json @" in rf["traffic_committed_source"]
     assert all("roofline_frac_is" in c["fused"] for c in row["configs"])
     # closed loop: the benchmark policy inside the step kernel (one launch per slice and tick), the launch loop in C (one host
     # call per tick), and the best row whose policy is a kernel of its own
