@@ -1860,9 +1860,14 @@ template <int KIND, class MID = NoMid> DEVINL u32 compute_features(Env<KIND>& E,
     if (!diag::ablate_featscan) keyA[lane + 64 * r] = f ? rc : kNoKey;
 #else
     // COMPACTED key lists (round 6): only the present cells, in cell order (rank = present cells before this one) — the scan
-    // below then runs ceil(present / cells-per-round) rounds per list instead of over every slot (a steady-state cleanup map
-    // holds ~50 of 119 waste cells and a few dozen of 103 apples)
-    if (!diag::ablate_featscan && f) keyA[napples + rank_in(fb, lane)] = rc;
+    // below then runs ceil(present / cells-per-round) rounds instead of one per 32 slots (a steady-state cleanup map holds ~50
+    // of 119 waste cells and a few dozen of 103 apples).  Every slot is first filled with kNoKey by its own lane, then the present
+    // cells overwrite their rank's slot: two DS stores of one wave execute in order, so the lists need no padding logic and the
+    // scan no per-list bounds
+    if (!diag::ablate_featscan) {
+      keyA[lane + 64 * r] = kNoKey;
+      if (f) keyA[napples + rank_in(fb, lane)] = rc;
+    }
 #endif
     napples += popc64(fb);
   }
@@ -1874,22 +1879,17 @@ template <int KIND, class MID = NoMid> DEVINL u32 compute_features(Env<KIND>& E,
 #ifdef CE_FEATSCAN_FULL_LISTS
       if (!diag::ablate_featscan) keyW[lane + 64 * r] = f ? cell_rc(E.WS[r]) : kNoKey;
 #else
-      if (!diag::ablate_featscan && f) keyW[nwaste + rank_in(presW[r], lane)] = cell_rc(E.WS[r]);
+      if (!diag::ablate_featscan) {
+        keyW[lane + 64 * r] = kNoKey;
+        if (f) keyW[nwaste + rank_in(presW[r], lane)] = cell_rc(E.WS[r]);
+      }
 #endif
       nwaste += popc64(presW[r]);
     }
   }
   const u32 sh = n <= 4 ? 4u : n <= 8 ? 3u : 2u;
   const u32 ga = lane >> sh, gl = lane & ((1u << sh) - 1u);
-#ifndef CE_FEATSCAN_FULL_LISTS
-  // each list is padded with kNoKey to a whole number of scan rounds (cells per round = 4 per lane x 2^sh lanes per agent group)
-  const u32 cpr = 4u << sh;
-  const u32 roundsA = (napples + cpr - 1u) >> (sh + 2u), roundsW = KIND == CE_KIND_CLEANUP ? (nwaste + cpr - 1u) >> (sh + 2u) : 0u;
-  if (!diag::ablate_featscan) {
-    if (napples + lane < (roundsA << (sh + 2u))) keyA[napples + lane] = kNoKey;  // (cpr <= 64: one masked store)
-    if (KIND == CE_KIND_CLEANUP && nwaste + lane < (roundsW << (sh + 2u))) keyW[nwaste + lane] = kNoKey;
-  }
-#endif
+
   const u32 prc = bperm(mycol | myrow << 8, ga);  // also the wave_sync-free way to get agent ga's position
   // harvest: apples in each agent's 21-cell neighbourhood, read here — before mid() may paint the agents over the map
   u32 close_now = 0;
@@ -1922,21 +1922,19 @@ template <int KIND, class MID = NoMid> DEVINL u32 compute_features(Env<KIND>& E,
   u32 kc = 0;
 #ifdef CE_FEATSCAN_FULL_LISTS
   const u32 chunks = diag::ablate_featscan ? 0u : (NCHUNK >> sh);  // wave-uniform trip count: every lane scans NCHUNK >> sh chunks
-  const u32 roundsA = chunks, roundsW = chunks;
 #else
-  const u32 chunks = diag::ablate_featscan ? 0u : max(roundsA, roundsW);  // wave-uniform: rounds of the longer list
+  // rounds of the longer list (cells per round = 4 per lane x 2^sh lanes per agent group); the shorter one reads kNoKey slots
+  const u32 longer = KIND == CE_KIND_CLEANUP ? max(napples, nwaste) : napples;
+  const u32 chunks = diag::ablate_featscan ? 0u : (longer + (4u << sh) - 1u) >> (sh + 2u);
 #endif
-  auto scan_step = [&]() {
-    if (kc >= chunks) return;
+  auto scan_round = [&]() {
     const u32 c = gl + (kc << sh);
     // key = manhattan << 16 | row << 8 | col in one v_sad_hi_u8 per cell (absent entries land at >= kNoKey)
-    if (kc < roundsA) {
-      const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
-      const u32 k0 = __builtin_amdgcn_sad_hi_u8(a4.x, prc, a4.x), k1 = __builtin_amdgcn_sad_hi_u8(a4.y, prc, a4.y);
-      const u32 k2 = __builtin_amdgcn_sad_hi_u8(a4.z, prc, a4.z), k3 = __builtin_amdgcn_sad_hi_u8(a4.w, prc, a4.w);
-      ka = min3u(min3u(ka, k0, k1), k2, k3);
-    }
-    if (KIND == CE_KIND_CLEANUP && kc < roundsW) {
+    const uint4 a4 = *reinterpret_cast<const uint4*>(keyA + 4 * c);
+    const u32 k0 = __builtin_amdgcn_sad_hi_u8(a4.x, prc, a4.x), k1 = __builtin_amdgcn_sad_hi_u8(a4.y, prc, a4.y);
+    const u32 k2 = __builtin_amdgcn_sad_hi_u8(a4.z, prc, a4.z), k3 = __builtin_amdgcn_sad_hi_u8(a4.w, prc, a4.w);
+    ka = min3u(min3u(ka, k0, k1), k2, k3);
+    if (KIND == CE_KIND_CLEANUP) {
       const uint4 w4 = *reinterpret_cast<const uint4*>(keyW + 4 * c);
       const u32 q0 = __builtin_amdgcn_sad_hi_u8(w4.x, prc, w4.x), q1 = __builtin_amdgcn_sad_hi_u8(w4.y, prc, w4.y);
       const u32 q2 = __builtin_amdgcn_sad_hi_u8(w4.z, prc, w4.z), q3 = __builtin_amdgcn_sad_hi_u8(w4.w, prc, w4.w);
@@ -1944,9 +1942,12 @@ template <int KIND, class MID = NoMid> DEVINL u32 compute_features(Env<KIND>& E,
     }
     ++kc;
   };
+  auto scan_step = [&]() {  // (what mid() gets: a no-op once the lists are through)
+    if (kc < chunks) scan_round();
+  };
   mid(scan_step);
 #pragma unroll 1  // unrolling keeps 8 b128 loads in flight and costs an occupancy step
-  while (kc < chunks) scan_step();
+  while (kc < chunks) scan_round();
   ka = group_min_u32(ka, sh);
   if (KIND == CE_KIND_CLEANUP) kw = group_min_u32(kw, sh);
   if (ka >= kNoKey) ka = 0;  // [0, 0] sentinel when there is none
