@@ -610,5 +610,17 @@ def test_custom_layout_rollouts_vs_oracle(kind, rng, fused):
             _compare(env, orc, fields, "step %d" % t)
             if rng == "counter":
                 assert np.array_equal(env.download("rng")[:, :3], orc.rng[:, :3])
+        # ce_global_view on a caller's layout (round 6): the colour map of every env, agents painted (every env has stepped)
+        from contracts_amd.environments.map_env import AGENT_RGB, CELL_RGB
+        gv = torch.empty((E, len(rows), len(rows[0]), 3), dtype=torch.uint8, device="cuda")
+        env.global_view(gv.data_ptr())
+        env.synchronize()
+        want = CELL_RGB[orc.grid].copy()
+        steps_taken = orc.timestep
+        for e in range(E):
+            if steps_taken[e] > 0:  # (an env whose last launch ended in an in-launch reset shows its map without agents)
+                for i, ag in enumerate(orc.agents[e]):
+                    want[e, ag[0], ag[1]] = AGENT_RGB[i]
+        assert np.array_equal(gv.cpu().numpy(), want)
         env.check_faults()
         env.close()
