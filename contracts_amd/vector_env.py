@@ -371,7 +371,6 @@ class _DictGeneration:
             self.dones[e] = {"__all__": False, "a0": False, "a1": False}  # the reference's dones dict (cleanup_new.py:242)
         self.reward_list = [self.rewards[e] for e in range(E)]
         self.done_list = [self.dones[e] for e in range(E)]
-        self.obs_list = [self.obs[e] for e in range(E)]
 
     def poison(self):
         """"checked": what a holder of this generation's previous hand-out would read from now on is NaN, not plausible data"""
