@@ -80,8 +80,6 @@ def test_fixed_point_draws_are_numpys_shuffle(length):
             y[i], y[J[i]] = y[J[i]], y[i]
         assert y == x, (length, seed)
         # numpy is now `used` words further down the same stream
-        ref = np.random.RandomState()
-        ref.set_state(twin.get_state())
         after = np.frombuffer(rs.bytes(16), dtype="<u4")
         assert np.array_equal(after, words[used:used + 4].astype(np.uint32)), (length, seed, used)
     if length == 119:  # the shipped list: three batches of 64 words, 14-16 passes on average
