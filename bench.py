@@ -528,6 +528,8 @@ def closed_loop(wl, E, device_index, num_slices, min_seconds=0.5, only=None):
     bounds = [(E * s // S, E * (s + 1) // S) for s in range(S)]
     pre = torch.empty((PREROLL, E, n), dtype=torch.uint8, device="cuda")
     env.synth_actions(SEED0 + 1, 0, PREROLL, pre.data_ptr())
+    env.synchronize()  # the generator runs on the null stream, the slices' streams are non-blocking: without this the first
+    # pre-roll launches can read planes that are not written yet (zeros in fresh memory, anything in a recycled torch block)
     env.rollout_device(pre.data_ptr(), PREROLL, [st.cuda_stream for st in streams])
     torch.cuda.synchronize()
 
@@ -760,6 +762,20 @@ def boundary(wl, E, device_index):
             pass
         k_incl += 1
     dt_incl = (time.perf_counter() - t1) / k_incl
+    # ... and once more with everything alive so far moved out of the garbage collector's sight (BatchedBaseEnv.freeze_gc): the
+    # tick above allocates 3 x 10^4 containers, i.e. a full collection every few ticks, each walking ~10^6 live objects
+    import gc
+    venv.freeze_gc()
+    t1, k_frz = time.perf_counter(), 0
+    while time.perf_counter() - t1 < 0.4 or k_frz < 3:
+        pl = planes[k_frz % 8]
+        venv.send_actions({e: dict(zip(keys, row)) for e, row in enumerate(pl.tolist())})
+        obs, rew, dones, infos, _ = venv.poll()
+        for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
+            pass
+        k_frz += 1
+    dt_frz = (time.perf_counter() - t1) / k_frz
+    gc.unfreeze()
     t1 = time.perf_counter()
     for k in range(2):
         venv.send_actions(action_dicts[k % 8])
@@ -776,6 +792,7 @@ def boundary(wl, E, device_index):
                             "ms_per_tick_max": ticks[-1] * 1e3,
                             "ms_building_action_dicts_not_timed": ms_build, "last_tick_ms": dict(venv.tick_timing),
                             "value_incl_action_dicts": E * n / dt_incl, "ms_per_step_incl_action_dicts": dt_incl * 1e3,
+                            "value_incl_action_dicts_gc_frozen": E * n / dt_frz, "ms_per_step_incl_action_dicts_gc_frozen": dt_frz * 1e3,
                             "value_with_consumer_copies": E * n / dt_copy, "ms_per_step_with_consumer_copies": dt_copy * 1e3,
                             "recycle_dicts": venv.recycle_dicts,
                             "contract": "what poll() returned at tick t is intact through t + 1 and rewritten in place by t + 2; "
@@ -824,16 +841,18 @@ def joint_boundary(wl, E, device_index, planes):
         dt = time.perf_counter() - t0
         row = {"tensor_value": E * n * steps / dt, "tensor_env_steps_per_s": E * steps / dt, "tensor_ms_per_step": dt / steps * 1e3}
         acts = [{e: {"a0": planes[k][e]} for e in range(E)} for k in range(2)]
-        venv.send_actions(acts[0])
-        venv.poll()
-        t0 = time.perf_counter()
-        for k in range(2):
-            venv.send_actions(acts[k])
+        ticks = []
+        for k in range(10):  # the first four are warm-up: both recycled image blocks get their pages there
+            t0 = time.perf_counter()
+            venv.send_actions(acts[k % 2])
             obs, rew, dones, infos, _ = venv.poll()
             for (e, o), r, d, i in zip(obs.items(), rew.values(), dones.values(), infos.values()):
                 pass
-        dt = (time.perf_counter() - t0) / 2
-        row.update({"dict_value": E * n / dt, "dict_env_steps_per_s": E / dt, "dict_ms_per_step": dt * 1e3, "unit": "agent-steps/s"})
+            ticks.append(time.perf_counter() - t0)
+        dt = sum(ticks[4:]) / len(ticks[4:])
+        row.update({"dict_value": E * n / dt, "dict_env_steps_per_s": E / dt, "dict_ms_per_step": dt * 1e3, "dict_ticks": len(ticks) - 4,
+                    "dict_ms_per_tick_max": max(ticks[4:]) * 1e3, "unit": "agent-steps/s"})
+        del obs, rew, dones, infos
         res[mode] = row
         venv.stop()
     return res
@@ -971,7 +990,9 @@ def run_rank(a):
         """the sections beside the headline must never take the line down with them: a failure is reported in place"""
         try:
             return fn(*args, **kw)
-        except Exception as exc:  # noqa: BLE001 (reported, not swallowed)
+        except Exception as exc:  # noqa: BLE001 (reported, not swallowed: in the line, with the traceback on stderr)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     if out is not None and world == 1 and not custom:

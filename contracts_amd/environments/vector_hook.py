@@ -109,6 +109,22 @@ def vector_seed0(env):
     return int(s)
 
 
+def _resolve_recycle(recycle_dicts, *envs):
+    """the recycling knob: the argument, else an env's `vector_recycle_dicts`, else CONTRACTS_AMD_VECTOR_RECYCLE, else 'auto'"""
+    for env in envs:
+        if recycle_dicts is None:
+            recycle_dicts = getattr(env, "vector_recycle_dicts", None)
+    if recycle_dicts is None:
+        import os
+        recycle_dicts = os.environ.get("CONTRACTS_AMD_VECTOR_RECYCLE", "auto")
+    if isinstance(recycle_dicts, str):
+        word = recycle_dicts.strip().lower()
+        if word not in _RECYCLE_WORDS:
+            raise ValueError("recycle_dicts / CONTRACTS_AMD_VECTOR_RECYCLE: %r is not one of %s" % (recycle_dicts, sorted(_RECYCLE_WORDS)))
+        recycle_dicts = _RECYCLE_WORDS[word]
+    return recycle_dicts
+
+
 def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_batch_wait_ms=0,
                 restart_failed_sub_environments=False, seed0=None, recycle_dicts=None):
     """see the module docstring; `env` is a base adapter or a SeparateContractSubgameStage around one.
@@ -129,8 +145,12 @@ def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_ba
                 seed0 = vector_seed0(env.base_env)
             if kw.get("rng", "mt19937") != "counter" and int(seed0) + num_envs - 1 > 0xffffffff:
                 raise ValueError("to_base_env: seed %d + %d sub-envs runs past 2**32 - 1 (np.random.seed's range)" % (seed0, num_envs))
+            # the joint env recycles image BLOCKS only (its dictionaries are new every tick); "checked" has nothing to wrap
+            # there and gets fresh arrays, like "off"
+            rec = _resolve_recycle(recycle_dicts, env, env.base_env)
             return BatchedJointBaseEnv(kind, num_envs, env.base_env.num_agents, mode="global" if env.global_obs else "concatenated",
-                                       seed0=seed0, device=getattr(env.base_env, "_device", 0), **kw)
+                                       seed0=seed0, device=getattr(env.base_env, "_device", 0),
+                                       recycle_images=False if rec in (False, "checked") else "auto", **kw)
     if isinstance(env, SeparateContractSubgameStage):
         base = env.base_env
         convolutional = env.convolutional
@@ -157,18 +177,7 @@ def to_base_env(env, make_env=None, num_envs=1, remote_envs=False, remote_env_ba
         # np.random.seed() takes 32 bits: replica i is seeded seed0 + i, and none of them may leave that range
         raise ValueError("to_base_env: seed %d + %d sub-envs runs past 2**32 - 1 (np.random.seed's range); seed the env lower "
                          "or use vector_rng='counter' (64-bit seeds)" % (seed0, num_envs))
-    if recycle_dicts is None:
-        recycle_dicts = getattr(env, "vector_recycle_dicts", None)
-    if recycle_dicts is None:
-        recycle_dicts = getattr(base, "vector_recycle_dicts", None)
-    if recycle_dicts is None:
-        import os
-        recycle_dicts = os.environ.get("CONTRACTS_AMD_VECTOR_RECYCLE", "auto")
-    if isinstance(recycle_dicts, str):
-        word = recycle_dicts.strip().lower()
-        if word not in _RECYCLE_WORDS:
-            raise ValueError("recycle_dicts / CONTRACTS_AMD_VECTOR_RECYCLE: %r is not one of %s" % (recycle_dicts, sorted(_RECYCLE_WORDS)))
-        recycle_dicts = _RECYCLE_WORDS[word]
+    recycle_dicts = _resolve_recycle(recycle_dicts, env, base)
     return BatchedBaseEnv(kind, num_envs, base.num_agents, seed0=seed0, convolutional=convolutional,
                           device=getattr(base, "_device", 0), recycle_dicts=recycle_dicts, **kw)
 

@@ -71,18 +71,41 @@ def _pool():
     if _POOL is None:
         import os
         from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)), thread_name_prefix="ce-obs")
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) - 1)), thread_name_prefix="ce-obs")
     return _POOL
+
+
+class _gc_paused:
+    """Holds the cyclic garbage collector off while a tick's dictionaries are built.  A 16 384-env tick allocates ~10^5
+    containers in a few milliseconds; with the collector's default thresholds that is one full collection per tick, and a full
+    collection walks every tracked object of the process (torch and numpy included) — 45-70 ms landing on whichever allocation
+    crosses the count, several times the tick itself (tools/joint_dict_rate.py).  None of these objects is cyclic: reference
+    counts free them.  The collector's state is restored on exit; nothing is frozen or exempted from later collections."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
+        return False
 
 
 class _ImageChunks:
     """the tick's observations as float64 (`uint8 / 255`, cleanup_new.py:258 / harvest_new.py:229), converted in chunks
     of _CHUNK envs by background threads while the caller walks the envs; small batches convert on demand"""
 
-    def __init__(self, raw):
+    def __init__(self, raw, out=None):
+        """`out`: a float64 block of raw's shape to convert into (a caller's recycled buffer) instead of fresh arrays"""
         self.raw = raw
         self.jobs = None
-        if raw.shape[0] >= 4 * _CHUNK:
+        if out is not None:
+            pool = _pool()
+            self.jobs = [pool.submit(np.true_divide, raw[c:c + _CHUNK], 255, out[c:c + _CHUNK]) for c in range(0, raw.shape[0], _CHUNK)]
+        elif raw.shape[0] >= 4 * _CHUNK:
             pool = _pool()
             self.jobs = [pool.submit(np.true_divide, raw[c:c + _CHUNK], 255) for c in range(0, raw.shape[0], _CHUNK)]
 
@@ -90,6 +113,15 @@ class _ImageChunks:
         if self.jobs is None:
             return self.raw[j] / 255
         return self.jobs[j // _CHUNK].result()[j % _CHUNK]
+
+    def rows(self):
+        """every env's image in env order (waits for the conversion chunk by chunk)"""
+        if self.jobs is None:
+            return list(self.raw / 255)
+        out = []
+        for job in self.jobs:
+            out.extend(job.result())
+        return out
 
 
 class _LazyEnvMap(Mapping):
@@ -503,7 +535,8 @@ class BatchedBaseEnv(_RLlibBaseEnv):
             return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: dict(zero_r)),
                     _LazyEnvMap(ids, lambda e: {"__all__": False}), _LazyEnvMap(ids, lambda e: {k: {} for k in self._keys}), {})
         if self._recycle:
-            return self._poll_recycled()
+            with _gc_paused():
+                return self._poll_recycled()
         ids, self._pending = self._pending, None
         eng = self.engine
         self._settle_faults()
@@ -795,6 +828,19 @@ class BatchedBaseEnv(_RLlibBaseEnv):
         views = _SubEnvs(self)
         return {e: views[e] for e in range(self.num_envs)} if as_dict else views
 
+    @staticmethod
+    def freeze_gc():
+        """Opt-in, process-wide: `gc.collect(); gc.freeze()` — every object alive now (torch, numpy, this env's recycled
+        dictionary trees: ~10^6 containers at E = 16 384) moves to the collector's permanent generation and is no longer walked
+        by full collections.  A sampler that allocates per tick (action dictionaries, batches) otherwise triggers one full
+        collection every few ticks, and each walks all of that: ≈ 85 ms against a 14 ms tick (bench.py: boundary.dict_protocol
+        value_incl_action_dicts vs ..._gc_frozen).  Call it once the loop is warm (after the second poll(): both generations
+        of trees exist then); `gc.unfreeze()` undoes it.  Reference counting is unaffected; only cycles among the frozen
+        objects are never reclaimed."""
+        import gc
+        gc.collect()
+        gc.freeze()
+
     def stop(self):
         self.engine.close()
 
@@ -811,19 +857,30 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         / 255 — produced on the device by ce_global_view, [E, H, W, 3] uint8, one launch and one copy per tick), under
         `mode="concatenated"` the n egocentric views stacked on the channel axis ([15, 15, 3 n]; the engine's `obs` buffer
         read as [E, 15, 15, n, 3], i.e. a strided view of what the step wrote).
-    Dictionaries are built lazily per env on access, as in BatchedBaseEnv's rebuilt path (the joint baseline has one agent per
-    env: E dictionaries of one entry each).  `poll_tensors()` additionally carries `global_view` (device uint8) under
-    mode="global"."""
+    The joint baseline has one agent per env — E dictionaries of one entry each — so a tick's four mappings are plain dicts
+    built in four passes over the batch, new every tick; the stacked views are transposed on the device, the float64 images
+    converted chunk by chunk on the worker threads into one of two recycled host blocks (`recycle_images`, see __init__: an
+    image array is valid through the next tick; pass False where a consumer keeps observations without copying them).
+    `poll_tensors()` additionally carries `global_view` (device uint8) under mode="global"."""
 
-    def __init__(self, kind, num_envs, num_agents, mode="concatenated", seed0=73907, **engine_kwargs):
+    def __init__(self, kind, num_envs, num_agents, mode="concatenated", seed0=73907, recycle_images="auto", **engine_kwargs):
         if kind not in _GRID:
             raise ValueError("BatchedJointBaseEnv serves the pixel grid kinds (cleanup_new / harvest_new), not %r" % (kind,))
         if mode not in ("global", "concatenated"):
             raise ValueError("mode must be 'global' or 'concatenated', not %r" % (mode,))
+        if recycle_images not in ("auto", True, False):
+            raise ValueError("recycle_images must be 'auto', True or False, not %r" % (recycle_images,))
         engine_kwargs.pop("contract", None)  # the joint baseline runs the bare base env (utils/ray_config_utils.py:159-176)
         BatchedBaseEnv.__init__(self, kind, num_envs, num_agents, contract=None, seed0=seed0, recycle_dicts=False, **engine_kwargs)
         self.mode = mode
         self._gv = None  # device buffer of the global views (torch owns it: plumbing)
+        # The float64 images of a stepped tick are converted into one of TWO host blocks used in turn — BatchedBaseEnv's
+        # recycling contract (what poll() returned at tick t is intact through t + 1 and rewritten in place by t + 2), for
+        # the image arrays only; the dictionaries around them are new every tick.  'auto' = on: the observation space is a
+        # Dict, which RLlib flattens (copies) as it receives it.  Fresh pages for 16 384 stacked views are 0.7 GB per tick:
+        # faulting them in and handing them back is three quarters of such a tick.  False: new arrays every tick.
+        self._recycle_images = recycle_images in ("auto", True)
+        self._img_ring, self._img_turn = [None, None], 0
 
     # ---- observations ----------------------------------------------------------------------------------------------
     def global_view_device(self, env_begin=0, env_count=None):
@@ -837,7 +894,7 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         self.engine.global_view(self._gv[env_begin:].data_ptr(), env_begin, cnt)
         return self._gv
 
-    def _obs_fields(self, env_begin=0, env_count=None):
+    def _obs_fields(self, env_begin=0, env_count=None, ring=False):
         snap = {"base": env_begin, "theta": None}
         cnt = self.num_envs - env_begin if env_count is None else env_count
         if self.mode == "global":
@@ -845,9 +902,18 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
             self.engine.synchronize()
             u8 = gv[env_begin:env_begin + cnt].cpu().numpy()
         else:
-            o = self.engine.download("obs", env_begin, env_count)  # uint8 [cnt, n, 15, 15, 3]
-            u8 = np.ascontiguousarray(o.transpose(0, 2, 3, 1, 4)).reshape(o.shape[0], 15, 15, 3 * self.num_agents)
-        snap["image"] = _ImageChunks(u8)  # value / 255 -> float64 (cleanup_new.py:300), chunks converted on the worker threads
+            # [cnt, n, 15, 15, 3] -> [cnt, 15, 15, n, 3] on the device (a strided read of what the step wrote, one dense copy
+            # out): the same transpose of 3-byte pixels on the host costs more than the tick's every other part together
+            self.engine.synchronize()
+            o = self.engine.torch_tensors()["obs"][env_begin:env_begin + cnt]
+            u8 = o.permute(0, 2, 3, 1, 4).contiguous().cpu().numpy().reshape(cnt, 15, 15, 3 * self.num_agents)
+        out = None
+        if ring and self._recycle_images and cnt == self.num_envs:  # (reset observations never take a turn of the ring)
+            self._img_turn ^= 1
+            out = self._img_ring[self._img_turn]
+            if out is None:
+                out = self._img_ring[self._img_turn] = np.empty(u8.shape, np.float64)
+        snap["image"] = _ImageChunks(u8, out)  # value / 255 -> float64 (cleanup_new.py:300), chunks converted on the worker threads
         return snap
 
     def _obs_of(self, snap, e, acting=None):
@@ -860,10 +926,13 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
             snap = self._obs_fields() if ids else None
             return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": 0.0}),
                     _LazyEnvMap(ids, lambda e: {"__all__": False}), _LazyEnvMap(ids, lambda e: {"a0": {}}), {})
+        with _gc_paused():
+            return self._poll_stepped()
+
+    def _poll_stepped(self):
         ids, self._pending = self._pending, None
         eng, n = self.engine, self.num_agents
         self._settle_faults()
-        snap = self._obs_fields()
         rew = eng.download("reward") if self._float_rewards else eng.download("base_reward")
         total = 0  # Python's sum(): 0 + r_a0 + r_a1 + ... left to right (ints stay ints, inequity-averse floats add in that order)
         for a in range(n):
@@ -878,23 +947,38 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         self._episode_over = set(self._done_ids)
         self._reset_obs = {}
         second = _SECOND_INFO[self.kind]
-        tot, inf = total.tolist(), info.tolist()
-
-        def dones(e):
-            d = bool(done[e])
-            return {"a0": d, "__all__": d}
-
-        return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": tot[e]}), _LazyEnvMap(ids, dones),
-                _LazyEnvMap(ids, lambda e: {"a0": {second: inf[e][1], "eaten_apples": inf[e][0], "feature_obs": fsum[e]}}), {})
+        tot, inf, dn = total.tolist(), info.tolist(), done.astype(bool).tolist()
+        # (the images last: their conversion threads fault in hundreds of MB of fresh float64 pages, and everything that
+        # allocates beside them — the downloads and list conversions above — waits on the same address-space lock)
+        snap = self._obs_fields(ring=True)
+        if list(ids) != list(range(self.num_envs)):  # (never from send_actions / send_actions_array: every env steps every tick)
+            return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": tot[e]}),
+                    _LazyEnvMap(ids, lambda e: {"a0": dn[e], "__all__": dn[e]}),
+                    _LazyEnvMap(ids, lambda e: {"a0": {second: inf[e][1], "eaten_apples": inf[e][0], "feature_obs": fsum[e]}}), {})
+        # One centralised agent per env and a sampler that walks every env: the four mappings are built in four passes over
+        # the batch (a lazily built entry costs a Python call per env and mapping — most of a 16 384-env tick)
+        rews = {e: {"a0": t} for e, t in enumerate(tot)}
+        dones = {e: {"a0": d, "__all__": d} for e, d in enumerate(dn)}
+        infos = {e: {"a0": {second: i[1], "eaten_apples": i[0], "feature_obs": f}} for e, (i, f) in enumerate(zip(inf, fsum))}
+        return {e: {"a0": {"image": im}} for e, im in enumerate(snap["image"].rows())}, rews, dones, infos, {}
 
     def send_actions(self, action_dict):
         """{env_id: {'a0': [action of a0, action of a1, ...]}} for every env: one [E, n] plane, one launch"""
         E, n = self.num_envs, self.num_agents
-        if len(action_dict) != E or any(e not in action_dict for e in range(E)):
+        if len(action_dict) != E:
             raise KeyError("send_actions needs actions for all %d sub-envs in one call" % E)
-        a = np.empty((E, n), np.int64)
-        for e in range(E):
-            a[e] = np.asarray(action_dict[e]["a0"]).reshape(-1)[:n]
+        try:
+            rows = [action_dict[e]["a0"] for e in range(E)]
+        except KeyError:
+            raise KeyError("send_actions needs actions for all %d sub-envs in one call" % E) from None
+        try:
+            a = np.asarray(rows, np.int64)
+        except (ValueError, TypeError):  # ragged or nested rows: one by one
+            a = None
+        if a is None or a.shape != (E, n):
+            a = np.empty((E, n), np.int64)
+            for e in range(E):
+                a[e] = np.asarray(rows[e]).reshape(-1)[:n]
         self.send_actions_array(a)
 
     def poll_tensors(self):

@@ -350,6 +350,7 @@ def test_eight_shard_global_range_on_one_gpu():
     whole = BatchedEnv(kind, E, n, **kw)
     acts = torch.empty((T, E, n), dtype=torch.uint8, device="cuda")
     whole.synth_actions(seed0 + 1, 0, T, acts.data_ptr())  # keyed by the global env index
+    whole.synchronize()  # (null stream; the slices' streams below are non-blocking)
     whole.seed(seed0=seed0)
     whole.reset()
     streams = [torch.cuda.Stream() for _ in range(3)]

@@ -710,3 +710,49 @@ def test_joint_baseline_through_the_batched_hook(name):
     assert np.array_equal(tt["reward"].cpu().numpy().sum(axis=1), orc.base_reward.sum(axis=1))
     venv.stop()
     base.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["global", "concatenated"])
+def test_joint_image_blocks_take_turns(mode):
+    """BatchedJointBaseEnv converts a stepped tick's float64 images into one of two host blocks used in turn: what poll() handed
+    out at tick t is untouched through t + 1 and rewritten at t + 2 (BatchedBaseEnv's recycling contract, for the image arrays
+    only; reset observations never take a turn); recycle_images=False hands out new arrays every tick; the hook maps the
+    recycling knob onto it ("off" / "checked" -> new arrays)."""
+    from contracts_amd.environments.cleanup_new import CleanupEnv
+    from contracts_amd.environments.two_stage_train import JointEnv
+    from contracts_amd.environments.vector_hook import to_base_env
+    from contracts_amd.vector_env import BatchedJointBaseEnv
+    E, n = 300, 3
+    rs = np.random.RandomState(12)
+    for recycle in ("auto", False):
+        venv = BatchedJointBaseEnv("cleanup", E, n, mode=mode, seed0=11, recycle_images=recycle)
+        first = venv.poll()[0]
+        r0 = first[7]["a0"]["image"]
+        r0_copy = r0.copy()
+        held = []
+        for t in range(5):
+            venv.send_actions_array(rs.randint(venv.engine.num_actions, size=(E, n)).astype(np.uint8))
+            obs, rew, dones, infos, _ = venv.poll()
+            assert type(obs) is dict and len(obs) == E and type(infos[E - 1]["a0"]["feature_obs"]) is np.ndarray
+            img = obs[7]["a0"]["image"]
+            held.append((img, img.copy()))
+            if t == 2:  # a reset observation in between does not disturb the turn order
+                ob = venv.try_reset(9)
+                assert not any(np.shares_memory(ob[9]["a0"]["image"], h[0]) for h in held)
+            if t >= 1:
+                assert np.array_equal(held[t - 1][0], held[t - 1][1]), t  # tick t - 1 is still what it was
+                assert not np.shares_memory(held[t][0], held[t - 1][0])
+            if t >= 2:
+                assert np.shares_memory(held[t][0], held[t - 2][0]) == (recycle == "auto"), t
+                if recycle is False:
+                    assert np.array_equal(held[t - 2][0], held[t - 2][1])
+        assert np.array_equal(r0, r0_copy)
+        venv.stop()
+    base = CleanupEnv(num_agents=n)
+    for word, want in (("off", False), ("checked", False), ("auto", True), (None, True)):
+        env = JointEnv(base, num_agents=n, global_obs=mode == "global", concatenated_obs=mode == "concatenated")
+        venv = to_base_env(env, num_envs=8, seed0=3, recycle_dicts=word)
+        assert isinstance(venv, BatchedJointBaseEnv) and venv._recycle_images is want
+        venv.stop()
+    base.close()

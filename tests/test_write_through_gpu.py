@@ -27,6 +27,7 @@ for kind, n, E, contract in (("cleanup", 8, 3001, "cleanup"), ("cleanup", 3, 700
     dt = torch.float32 if kind == "selfdrive" else torch.uint8
     acts = torch.empty((T, E, n), dtype=dt, device="cuda")
     env.synth_actions(5, 0, T, acts.data_ptr())
+    env.synchronize()  # (null stream; the slices' streams below are non-blocking)
     env.seed(seed0=11)
     env.reset()
     streams = [torch.cuda.Stream() for _ in range(3)]
