@@ -553,3 +553,29 @@ def test_bench_compact_line_stays_parseable_and_small():
     # a summary that would push the line over the cap is cut down to the headline row, never the record itself
     d["summary"] = dict(bench.summary(d), **{"pad%d" % i: "x" * 64 for i in range(64)})
     assert len(bench.compact(d, None)) < bench.COMPACT_MAX_BYTES
+
+
+def test_gc_pause_restores_the_collectors_state():
+    """vector_env._gc_paused (held while a tick's dictionaries are built): the collector is off inside, and afterwards exactly
+    what it was before — also when the caller runs with it disabled, when pauses nest, and when the body raises"""
+    import gc
+    from contracts_amd.vector_env import _gc_paused
+    was = gc.isenabled()
+    try:
+        gc.enable()
+        with _gc_paused():
+            assert not gc.isenabled()
+            with _gc_paused():
+                assert not gc.isenabled()
+            assert not gc.isenabled()
+        assert gc.isenabled()
+        with pytest.raises(KeyError):
+            with _gc_paused():
+                raise KeyError("x")
+        assert gc.isenabled()
+        gc.disable()
+        with _gc_paused():
+            assert not gc.isenabled()
+        assert not gc.isenabled()  # a caller that runs with the collector off keeps it off
+    finally:
+        (gc.enable if was else gc.disable)()
