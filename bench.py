@@ -883,7 +883,9 @@ def run_rank(a):
     if os.environ.get("CONTRACTS_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    group = parallel.Group(backend, "cuda:%d" % local_rank)
+    # CONTRACTS_BENCH_FORCE_DIST=1 (functional test, tests/test_bench_multirank_gpu.py): a one-rank run still builds its process
+    # group, so the barrier and the reductions of this file go through RCCL on a single-GPU box
+    group = parallel.Group(backend, "cuda:%d" % local_rank, force=os.environ.get("CONTRACTS_BENCH_FORCE_DIST") == "1")
 
     wl = dict(WORKLOADS["C4"])
     custom = bool(a.kind or a.agents)
@@ -912,7 +914,7 @@ def run_rank(a):
     # proof of the job's width that does not rest on --gpus: every rank adds 1 over the process group (an all-reduce SUM
     # over RCCL under nccl); per-rank clocks of the timed repeats as min / max over ranks
     ranks = {"ranks_seen": int(round(group.sum(1.0))), "world_size": world,
-             "backend": backend if world > 1 else "none (single process)",
+             "backend": backend if group._dist is not None else "none (single process)",
              "device": torch.cuda.get_device_properties(local_rank).name, "envs_per_rank": E,
              "ms_per_step_rank_min": head.get("ms_per_step_rank_min", head["ms_per_step"]),
              "ms_per_step_rank_max": head.get("ms_per_step_rank_max", head["ms_per_step"])}

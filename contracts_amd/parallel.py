@@ -127,12 +127,14 @@ class Group:
     """The process group of a run: rank bootstrap, barrier and the reductions the benchmark needs.  world == 1 never
     imports torch.distributed."""
 
-    def __init__(self, backend="nccl", device=None):
+    def __init__(self, backend="nccl", device=None, force=False):
+        """force: initialise the process group even at world == 1 (a one-rank communicator) — how the RCCL leg of this class
+        is exercised on a single-GPU box (tests/test_parallel_rccl_gpu.py); never set by bench.py"""
         self.rank, self.local_rank, self.world = rank_info()
         self.backend = backend
         self.device = device  # "cuda:k" for nccl, None / "cpu" for gloo
         self._dist = None
-        if self.world > 1:
+        if self.world > 1 or force:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

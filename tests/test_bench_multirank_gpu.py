@@ -65,6 +65,24 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """the driver's launcher with ONE rank and the process group forced on (backend nccl = RCCL): bench.py's own barrier, MAX /
+    MIN over the elapsed times and the ranks_seen SUM run through RCCL on device tensors — the calls an N-GPU run makes, on the
+    one communicator size a single-GPU box can hold (two RCCL ranks cannot share a device)"""
+    env = dict(os.environ, CONTRACTS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CONTRACTS_BENCH_BACKEND", None)
+    env.pop("CONTRACTS_BENCH_SHARE_GPU", None)
+    args = [a if a != "2" else "1" for a in ARGS]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    row, compact, _ = _lines(out)
+    assert row["n_gpus"] == 1 and row["ranks"]["ranks_seen"] == 1 and row["ranks"]["world_size"] == 1 and row["value"] > 0
+    assert row["config"]["global_envs"] == 2048 and compact["ranks_seen"] == 1 and row["ranks"]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_share_one_gpu():
     """the launch the driver uses for the 8-GPU scaling point (`torch.distributed.run --nproc-per-node 8 bench.py --gpus
     8`): eight rank processes, rendezvous, shard bases g * E, barrier + MAX over ranks, one line from rank 0 — here all on
