@@ -933,6 +933,7 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         ids, self._pending = self._pending, None
         eng, n = self.engine, self.num_agents
         self._settle_faults()
+        snap = self._obs_fields(ring=True)  # first: the worker threads convert the images while the rest of the tick is put together
         rew = eng.download("reward") if self._float_rewards else eng.download("base_reward")
         total = 0  # Python's sum(): 0 + r_a0 + r_a1 + ... left to right (ints stay ints, inequity-averse floats add in that order)
         for a in range(n):
@@ -948,9 +949,6 @@ class BatchedJointBaseEnv(BatchedBaseEnv):
         self._reset_obs = {}
         second = _SECOND_INFO[self.kind]
         tot, inf, dn = total.tolist(), info.tolist(), done.astype(bool).tolist()
-        # (the images last: their conversion threads fault in hundreds of MB of fresh float64 pages, and everything that
-        # allocates beside them — the downloads and list conversions above — waits on the same address-space lock)
-        snap = self._obs_fields(ring=True)
         if list(ids) != list(range(self.num_envs)):  # (never from send_actions / send_actions_array: every env steps every tick)
             return (_LazyEnvMap(ids, lambda e: self._obs_of(snap, e)), _LazyEnvMap(ids, lambda e: {"a0": tot[e]}),
                     _LazyEnvMap(ids, lambda e: {"a0": dn[e], "__all__": dn[e]}),
