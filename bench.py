@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 
 from contracts_amd import parallel  # noqa: E402  (no GPU / torch import at module level)
 
+T_START = time.monotonic()  # --time-budget counts from here (interpreter start, before torch is imported)
+
 SEED0 = 73907  # the reference's seed multiplier (runner.py:130)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PREROLL = 300
@@ -99,6 +101,10 @@ def parse():
     ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
                     help="file the full record goes to ('' = nowhere); the stdout line is the compact record (< 3 KB)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N self-launch: deadline of the whole job, s")
+    ap.add_argument("--time-budget", type=float, default=420.0,
+                    help="seconds from process start after which the OPTIONAL sections still to come (config rows, closed loop, "
+                         "boundary, counter stream, the configs' CPU baselines) are skipped and say so, so that the line — headline, "
+                         "roofline, cpu_baseline, parity_in_run — still prints on a slow box; a normal run takes ~70 s; 0 = no limit")
     return ap.parse_args()
 
 
@@ -964,9 +970,27 @@ def run_rank(a):
     # --config-seconds of timed wall per mode (single-GPU workloads: rank 0's GPU only would idle the others, so every
     # rank runs its shard of them too and the line reports the whole-job value)
     custom = custom or a.rng != "mt19937"  # (a line on the engine's own stream carries the headline rows only)
+    # --time-budget: the sections from here to the headline's CPU baseline are optional.  Once the run is `budget - reserve`
+    # seconds old (reserve = what the required tail — the headline's oracle sample and its parity check — takes) the ones still
+    # to come are skipped and listed, instead of letting a slow box push the whole line past whoever waits for it.  The clock is
+    # MAX-reduced over the ranks, so every rank takes the same branch (the config rows hold barriers).
+    reserve = 0.0 if (a.no_cpu_baseline or world > 1) else 2.0 * a.cpu_seconds + 30.0
+    skipped = []
+
+    def out_of_time(section, keep=None):
+        if not a.time_budget:
+            return False
+        spent = group.max(time.monotonic() - T_START)
+        if spent > a.time_budget - (reserve if keep is None else keep):
+            skipped.append(section)
+            return True
+        return False
+
     if not a.no_configs and not custom:
         rows = []
         for key in ("C2", "C3", "C5", "C1"):
+            if out_of_time("configs." + key):
+                continue
             w = WORKLOADS[key]
             w_fused = bool(a.fused_steps) and w["kind"] in FUSED_KINDS
             rr = Runner(group, w, w["E"], a.config_steps, min(W, 20), a.streams, local_rank, a.fused_steps if w_fused else 0)
@@ -998,14 +1022,14 @@ def run_rank(a):
             return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     if out is not None and world == 1 and not custom:
-        if not a.no_closed_loop:
+        if not a.no_closed_loop and not out_of_time("closed_loop"):
             out["closed_loop"] = cl = extra(closed_loop, WORKLOADS["C4"], E, local_rank, a.streams)
             # the same loop cut into 2 / 4 slices (one graph replay per slice and tick: fewer slices = fewer host calls per
             # tick, more slices = more overlap on the device); `value` stays with the headline's slice count unless one of
             # these one-host-iteration-per-step rows beats it
             sweep = {}
             for S2 in (2, 4):
-                if S2 == a.streams or "error" in cl:
+                if S2 == a.streams or "error" in cl or out_of_time("closed_loop.slices_sweep.%d" % S2):
                     continue
                 r2 = extra(closed_loop, WORKLOADS["C4"], E, local_rank, S2, 0.5,
                            ("policy_eager", "policy_graph", "policy_graph16", "policy_graph_all", "inkernel_eager", "inkernel_sliced", "inkernel_graph_all"))
@@ -1020,9 +1044,9 @@ def run_rank(a):
                 if "error" not in r2 and (r2.get("inkernel_policy") or {}).get("value", 0) > (cl.get("inkernel_policy") or {}).get("value", 0):
                     cl["inkernel_policy"] = dict(r2["inkernel_policy"], slices=S2)
             cl["slices_sweep"] = sweep
-        if not a.no_boundary:
+        if not a.no_boundary and not out_of_time("boundary"):
             out["boundary"] = extra(boundary, WORKLOADS["C4"], E, local_rank)
-        if not a.no_counter_rng:
+        if not a.no_counter_rng and not out_of_time("counter_rng"):
             out["counter_rng"] = extra(counter_rng, group, WORKLOADS["C4"], a, local_rank)
     if out is not None:
         if not a.no_cpu_baseline and world == 1:
@@ -1035,7 +1059,11 @@ def run_rank(a):
 
             with_parity(out, dict(wl, E=E), a.cpu_seconds)
             for row in out.get("configs", []):  # the CPU path beside every GPU config, same E rule / seeds / actions
+                if out_of_time("cpu_baseline." + row["config"], keep=0.0):
+                    row["cpu_baseline"] = {"skipped": "--time-budget %g s" % a.time_budget}
+                    continue
                 with_parity(row, WORKLOADS[row["config"]], a.config_cpu_seconds, single_thread_s=0.0)
+        out["time_budget"] = {"seconds": a.time_budget, "spent_s": round(time.monotonic() - T_START, 1), "skipped_sections": skipped}
         out["summary"] = summary(out)
         emit(out, a)
     group.close()
@@ -1089,7 +1117,7 @@ def compact(out, full_record=None):
     line["value"], line["ms_per_step"] = out.get("value"), out.get("ms_per_step")  # the two the driver cross-checks: unrounded
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > COMPACT_MAX_BYTES:  # never let the line outgrow the driver again: drop the digest before the record
-        line["summary"] = {k: v for k, v in (line.get("summary") or {}).items() if k in ("C4", "parity_all_ok", "parity_legs_run")}
+        line["summary"] = {k: v for k, v in (line.get("summary") or {}).items() if k in ("C4", "parity_all_ok", "parity_legs_run", "skipped_for_time")}
         text = json.dumps(line, separators=(",", ":"))
     return text
 
@@ -1152,6 +1180,8 @@ def summary(out):
         ran.append(sm["counter_parity_ok"])
     sm["parity_legs_run"] = len(ran)
     sm["parity_all_ok"] = all(ran) if ran else None  # None = no parity leg ran (--no-cpu-baseline, world > 1): not a pass
+    if (out.get("time_budget") or {}).get("skipped_sections"):  # a slow box: what the line does NOT carry, and why
+        sm["skipped_for_time"] = out["time_budget"]["skipped_sections"]
     return sm
 
 

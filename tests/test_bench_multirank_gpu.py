@@ -182,3 +182,23 @@ def test_bench_default_line_has_every_config():
     assert cl["inkernel_policy"]["issue"].startswith("inkernel") and sm["closed_loop_inkernel_G"] == round(cl["inkernel_policy"]["value"] / 1e9, 4)
     dp = bd["dict_protocol"]
     assert dp["recycle_dicts"] is True and dp["value"] > dp["value_incl_action_dicts"] > dp["value_with_consumer_copies"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_time_budget_keeps_the_required_parts():
+    """--time-budget: on a box slow enough to exhaust it (here: a budget of one second) the optional sections are skipped and
+    named, the line still carries the headline, its roofline, the CPU baseline and the parity check of the timed kernels"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.05", "--cpu-seconds", "1.0",
+           "--time-budget", "1", "--no-live-traffic", "--full", "--full-out", ""]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    row, compact, _ = _lines(out)
+    assert row["configs"] == [] and not ({"closed_loop", "boundary", "counter_rng"} & set(row))
+    sk = row["time_budget"]["skipped_sections"]
+    assert sk == ["configs.C2", "configs.C3", "configs.C5", "configs.C1", "closed_loop", "boundary", "counter_rng"], sk
+    assert compact["summary"]["skipped_for_time"] == sk and row["time_budget"]["seconds"] == 1.0
+    assert compact["value"] > 0 and 0 < compact["roofline"]["frac"] < 1 and compact["cpu_baseline"]["value"] > 0
+    assert compact["parity_in_run"]["ok"] is True and compact["summary"]["parity_legs_run"] == 1 and row["fused"]["value"] > 0
